@@ -1,0 +1,706 @@
+/*
+ * uwt_oracle.c — CPU ORACLE (test infrastructure; see uwt_oracle.h for the contract and the
+ * pinned semantics S1..S8).  Plain C restatement of the UW-SLAM direct-tracking path.
+ * Reference citations are relative to /root/reference.  PARITY UNPINNED (no reference goldens exist).
+ *
+ * Compile with -ffp-contract=off: every FMA in here is an explicit fmaf().
+ */
+#include "uwt_oracle.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* parameters                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+void uwo_default_params(uwo_params* p, int width, int height, float fx, float fy, float cx, float cy) {
+  memset(p, 0, sizeof(*p));
+  p->width = width;
+  p->height = height;
+  p->fx = fx; p->fy = fy; p->cx = cx; p->cy = cy;
+  p->n_levels = 5;        /* Options.cpp:26 */
+  p->first_level = 4;     /* Tracker.cpp:368 */
+  p->last_level = 1;      /* Tracker.cpp:369 */
+  p->max_iters = 50;      /* Tracker.cpp:366 */
+  p->epsilon = 0.001f;    /* Tracker.cpp:364 */
+  p->gain = 50.0f;        /* Tracker.cpp:559 */
+  p->z_factor = 1.0f;     /* Tracker.cpp:371 */
+  p->angle_factor = 1.0f; /* Tracker.cpp:372 */
+  p->depth_scale = 0.0002f; /* Tracker.cpp:1261 */
+  p->initial_error = 50000.0f; /* Tracker.cpp:393 */
+  p->early_exit = 1;
+  p->has_depth = 0;
+  p->handoff_scale_t = 0;
+  p->weights = UWO_WEIGHTS_IDENTITY;
+}
+
+/* Tracker::InitializePyramid, Tracker.cpp:297-340.  fx halves in double then narrows
+ * (:317 "fx_[lvl-1] * 0.5"), cx_l = (cx0 + 0.5) / 2^l - 0.5 in double then narrows (:319). */
+int uwo_level_intrinsics(const uwo_params* p, int lvl, uwo_level* out) {
+  if (lvl < 0 || lvl >= p->n_levels || lvl >= UWO_MAX_LEVELS) return UWO_ERR_INVALID_ARG;
+  float fx = p->fx, fy = p->fy;
+  for (int l = 1; l <= lvl; l++) {
+    fx = (float)((double)fx * 0.5);
+    fy = (float)((double)fy * 0.5);
+  }
+  out->w = p->width >> lvl;
+  out->h = p->height >> lvl;
+  out->fx = fx;
+  out->fy = fy;
+  if (lvl == 0) {
+    out->cx = p->cx;
+    out->cy = p->cy;
+  } else {
+    out->cx = (float)(((double)p->cx + 0.5) / (double)(1 << lvl) - 0.5);
+    out->cy = (float)(((double)p->cy + 0.5) / (double)(1 << lvl) - 0.5);
+  }
+  out->invfx = 1.0f / fx; /* :328 */
+  out->invfy = 1.0f / fy;
+  return UWO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* pyramid + gradients                                                                          */
+/* ------------------------------------------------------------------------------------------ */
+
+/* System.cpp:247 cv::resize(src, dst, Size(), 0.5, 0.5) — INTER_LINEAR at exactly 1/2 takes
+ * OpenCV's area fast path: (a+b+c+d+2)>>2. */
+void uwo_halve_u8(const uint8_t* src, int w, int h, uint8_t* dst) {
+  int w2 = w >> 1, h2 = h >> 1;
+  for (int y = 0; y < h2; y++) {
+    const uint8_t* r0 = src + (size_t)(2 * y) * w;
+    const uint8_t* r1 = r0 + w;
+    for (int x = 0; x < w2; x++)
+      dst[(size_t)y * w2 + x] = (uint8_t)((r0[2 * x] + r0[2 * x + 1] + r1[2 * x] + r1[2 * x + 1] + 2) >> 2);
+  }
+}
+
+/* System.cpp:249 same call on the 16-bit depth image (invalid zeros are averaged in). */
+void uwo_halve_u16(const uint16_t* src, int w, int h, uint16_t* dst) {
+  int w2 = w >> 1, h2 = h >> 1;
+  for (int y = 0; y < h2; y++) {
+    const uint16_t* r0 = src + (size_t)(2 * y) * w;
+    const uint16_t* r1 = r0 + w;
+    for (int x = 0; x < w2; x++)
+      dst[(size_t)y * w2 + x] =
+          (uint16_t)(((uint32_t)r0[2 * x] + r0[2 * x + 1] + r1[2 * x] + r1[2 * x + 1] + 2u) >> 2);
+  }
+}
+
+static inline int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) {
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+  }
+  return i;
+}
+
+/* Tracker.cpp:1133-1134.  The literal 3 binds to Scharr's `scale`; kernels stay integral
+ * ([3 10 3]·3 smoothing x [-1 0 1] derivative), so the result is exact in int and never
+ * saturates int16 (|g| <= 48·255). Correlation (not convolution): gx > 0 where I grows with x. */
+void uwo_scharr3(const uint8_t* src, int w, int h, int16_t* gx, int16_t* gy) {
+  for (int y = 0; y < h; y++) {
+    int ym = reflect101(y - 1, h), yp = reflect101(y + 1, h);
+    const uint8_t* rm = src + (size_t)ym * w;
+    const uint8_t* r0 = src + (size_t)y * w;
+    const uint8_t* rp = src + (size_t)yp * w;
+    for (int x = 0; x < w; x++) {
+      int xm = reflect101(x - 1, w), xp = reflect101(x + 1, w);
+      int sx = 3 * (rm[xp] - rm[xm]) + 10 * (r0[xp] - r0[xm]) + 3 * (rp[xp] - rp[xm]);
+      int sy = 3 * (rp[xm] - rm[xm]) + 10 * (rp[x] - rm[x]) + 3 * (rp[xp] - rm[xp]);
+      sx *= 3;
+      sy *= 3;
+      if (sx > 32767) sx = 32767;
+      if (sx < -32768) sx = -32768;
+      if (sy > 32767) sy = 32767;
+      if (sy < -32768) sy = -32768;
+      gx[(size_t)y * w + x] = (int16_t)sx;
+      gy[(size_t)y * w + x] = (int16_t)sy;
+    }
+  }
+}
+
+/* Tracker.cpp:1139-1142: convertScaleAbs (saturate |g| to u8) then addWeighted(0.5, 0.5)
+ * (cvRound = round-half-to-even). */
+void uwo_gradient_mag(const int16_t* gx, const int16_t* gy, int n, uint8_t* out) {
+  for (int i = 0; i < n; i++) {
+    int ax = abs((int)gx[i]), ay = abs((int)gy[i]);
+    if (ax > 255) ax = 255;
+    if (ay > 255) ay = 255;
+    double v = 0.5 * ax + 0.5 * ay;
+    long r = lrint(v); /* default rounding mode: to nearest even */
+    out[i] = (uint8_t)(r > 255 ? 255 : r);
+  }
+}
+
+/* Tracker::ObtainAllPoints, Tracker.cpp:1259-1310.  Depth is read through at<short> (signed). */
+void uwo_dense_points(const uint16_t* depth, int w, int h, int lvl, float depth_scale, float* pts) {
+  float factor_lvl = (float)((double)depth_scale / pow(2.0, (double)lvl)); /* :1266 */
+  for (int y = 0; y < h; y++) {
+    for (int x = 0; x < w; x++) {
+      float* p = pts + 4 * ((size_t)y * w + x);
+      if (depth) {
+        int16_t d = (int16_t)depth[(size_t)y * w + x];
+        if (d > 0) {
+          p[0] = (float)x; p[1] = (float)y; p[2] = (float)d * factor_lvl; p[3] = 1.0f; /* :1276-1278 */
+        } else {
+          p[0] = 0.0f; p[1] = 0.0f; p[2] = 1.0f; p[3] = 0.0f; /* :1290-1291 */
+        }
+      } else {
+        p[0] = (float)x; p[1] = (float)y; p[2] = 1.0f; p[3] = 1.0f; /* :1299-1302 */
+      }
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* SE(3) (Sophus SE3f / SO3f, Eigen quaternion kernels; S5, S6)                                */
+/* ------------------------------------------------------------------------------------------ */
+
+static inline float sin32(float x) { return (float)sin((double)x); }
+static inline float cos32(float x) { return (float)cos((double)x); }
+
+void uwo_se3_identity(float pose[7]) {
+  /* Tracker.cpp:385: SE3(SO3::exp(0), 0) — Taylor branch of expAndTheta gives (0,0,0,1). */
+  pose[0] = 0.0f; pose[1] = 0.0f; pose[2] = 0.0f; pose[3] = 1.0f;
+  pose[4] = 0.0f; pose[5] = 0.0f; pose[6] = 0.0f;
+}
+
+/* Eigen Quaternion::toRotationMatrix (generic). q = x y z w; R row-major 3x3. so3.hpp:286-288. */
+static void quat_to_R(const float q[4], float R[9]) {
+  float x = q[0], y = q[1], z = q[2], w = q[3];
+  float tx = 2.0f * x, ty = 2.0f * y, tz = 2.0f * z;
+  float twx = tx * w, twy = ty * w, twz = tz * w;
+  float txx = tx * x, txy = ty * x, txz = tz * x;
+  float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.0f - (tyy + tzz); R[1] = txy - twz;          R[2] = txz + twy;
+  R[3] = txy + twz;          R[4] = 1.0f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;          R[7] = tyz + twx;          R[8] = 1.0f - (txx + tyy);
+}
+
+/* Eigen generic quaternion product (Hamilton), coefficient order x y z w. */
+static void quat_mul(const float a[4], const float b[4], float o[4]) {
+  float ax = a[0], ay = a[1], az = a[2], aw = a[3];
+  float bx = b[0], by = b[1], bz = b[2], bw = b[3];
+  float w = aw * bw - ax * bx - ay * by - az * bz;
+  float x = aw * bx + ax * bw + ay * bz - az * by;
+  float y = aw * by + ay * bw + az * bx - ax * bz;
+  float z = aw * bz + az * bw + ax * by - ay * bx;
+  o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+
+/* Eigen QuaternionBase::_transformVector: uv = 2·(q.vec × v); v + w·uv + q.vec × uv.  so3.hpp:320-322. */
+static void quat_rotate(const float q[4], const float v[3], float o[3]) {
+  float qx = q[0], qy = q[1], qz = q[2], qw = q[3];
+  float ux = qy * v[2] - qz * v[1];
+  float uy = qz * v[0] - qx * v[2];
+  float uz = qx * v[1] - qy * v[0];
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  float cx = qy * uz - qz * uy;
+  float cy = qz * ux - qx * uz;
+  float cz = qx * uy - qy * ux;
+  o[0] = (v[0] + qw * ux) + cx;
+  o[1] = (v[1] + qw * uy) + cy;
+  o[2] = (v[2] + qw * uz) + cz;
+}
+
+/* SO3::expAndTheta, so3.hpp:534-566.  epsilon<float> = 1e-5 (common.hpp:154-158). */
+static void so3_exp_theta(const float om[3], float q[4], float* theta_out) {
+  float theta_sq = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
+  float theta = sqrtf(theta_sq);
+  float half_theta = 0.5f * theta;
+  float imag, real;
+  if (theta < 1e-5f) {
+    float theta_po4 = theta_sq * theta_sq;
+    imag = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * theta_po4;
+    real = 1.0f - (float)(1.0 / 8.0) * theta_sq + (float)(1.0 / 384.0) * theta_po4;
+  } else {
+    float s = sin32(half_theta);
+    imag = s / theta;
+    real = cos32(half_theta);
+  }
+  q[0] = imag * om[0]; q[1] = imag * om[1]; q[2] = imag * om[2]; q[3] = real;
+  *theta_out = theta;
+}
+
+/* SE3::exp, se3.hpp:723-744.  xi = [upsilon(3), omega(3)]. */
+void uwo_se3_exp(const float xi[6], float pose[7]) {
+  const float* up = xi;
+  const float* om = xi + 3;
+  float q[4], theta;
+  so3_exp_theta(om, q, &theta);
+  float Om[9] = {0.0f, -om[2], om[1], om[2], 0.0f, -om[0], -om[1], om[0], 0.0f}; /* so3.hpp:618-627 */
+  float Om2[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++)
+      Om2[3 * i + j] = (Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j]) + Om[3 * i + 2] * Om[6 + j];
+  float V[9];
+  if (theta < 1e-5f) {
+    quat_to_R(q, V); /* se3.hpp:734 "V = so3.matrix()" */
+  } else {
+    float theta_sq = theta * theta;
+    float c1 = (1.0f - cos32(theta)) / theta_sq;
+    float c2 = (theta - sin32(theta)) / (theta_sq * theta);
+    for (int i = 0; i < 9; i++) {
+      float id = (i == 0 || i == 4 || i == 8) ? 1.0f : 0.0f;
+      V[i] = (id + c1 * Om[i]) + c2 * Om2[i];
+    }
+  }
+  pose[0] = q[0]; pose[1] = q[1]; pose[2] = q[2]; pose[3] = q[3];
+  for (int i = 0; i < 3; i++) pose[4 + i] = (V[3 * i] * up[0] + V[3 * i + 1] * up[1]) + V[3 * i + 2] * up[2];
+}
+
+/* SE3::operator*= (se3.hpp:317-321) + SO3::operator*= with first-order renormalisation (so3.hpp:338-354). */
+void uwo_se3_mul(const float a[7], const float b[7], float out[7]) {
+  float rt[3];
+  quat_rotate(a, b + 4, rt);
+  float t0 = a[4] + rt[0], t1 = a[5] + rt[1], t2 = a[6] + rt[2];
+  float q[4];
+  quat_mul(a, b, q);
+  float sn = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (sn != 1.0f) {
+    float s = 2.0f / (1.0f + sn);
+    q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
+  }
+  out[0] = q[0]; out[1] = q[1]; out[2] = q[2]; out[3] = q[3];
+  out[4] = t0; out[5] = t1; out[6] = t2;
+}
+
+/* SE3::matrix(), se3.hpp:253-268. Row-major 4x4. */
+void uwo_se3_matrix(const float pose[7], float T[16]) {
+  float R[9];
+  quat_to_R(pose, R);
+  T[0] = R[0]; T[1] = R[1]; T[2] = R[2];  T[3] = pose[4];
+  T[4] = R[3]; T[5] = R[4]; T[6] = R[5];  T[7] = pose[5];
+  T[8] = R[6]; T[9] = R[7]; T[10] = R[8]; T[11] = pose[6];
+  T[12] = 0.0f; T[13] = 0.0f; T[14] = 0.0f; T[15] = 1.0f;
+}
+
+/* Level hand-off, Tracker.cpp:580-590: q.xyz *= 2, SE3(q, t) re-normalises (se3.hpp:446-448 →
+ * so3.hpp:431-439 → normalize() so3.hpp:270-276).  EstimatePoseFeatures also doubles t (:856). */
+int uwo_se3_handoff(float pose[7], int scale_t) {
+  float x = pose[0] * 2.0f, y = pose[1] * 2.0f, z = pose[2] * 2.0f, w = pose[3];
+  float len = sqrtf(x * x + y * y + z * z + w * w);
+  if (!(len >= 1e-5f)) return UWO_ERR_INVALID_ARG; /* SOPHUS_ENSURE would abort */
+  pose[0] = x / len; pose[1] = y / len; pose[2] = z / len; pose[3] = w / len;
+  if (scale_t) { pose[4] *= 2.0f; pose[5] *= 2.0f; pose[6] *= 2.0f; }
+  return UWO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* warp + per-point terms                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Tracker::WarpFunction, Tracker.cpp:1417-1471.  The 4x4·4xN product follows S1. */
+void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, float* warped) {
+  float T[16];
+  uwo_se3_matrix(pose, T);
+  float fx = L->fx, fy = L->fy, cx = L->cx, cy = L->cy, invfx = L->invfx, invfy = L->invfy;
+  for (int i = 0; i < n; i++) {
+    const float* p = pts + 4 * (size_t)i;
+    float z = p[2], w = p[3];
+    float X = (p[0] - cx) * invfx; /* :1439 */
+    X = X * z;                     /* :1440 */
+    float Y = (p[1] - cy) * invfy; /* :1443 */
+    Y = Y * z;                     /* :1444 */
+    float o[4];
+    for (int k = 0; k < 4; k++) {  /* :1450 rigid * P^T */
+      float s = T[4 * k] * X;
+      s = fmaf(T[4 * k + 1], Y, s);
+      s = fmaf(T[4 * k + 2], z, s);
+      s = fmaf(T[4 * k + 3], w, s);
+      o[k] = s;
+    }
+    float u = o[0] * fx; u = u / o[2]; u = u + cx; /* :1454-1456 */
+    float v = o[1] * fy; v = v / o[2]; v = v + cy; /* :1459-1461 */
+    u = u * o[3];                                   /* :1466 */
+    v = v * o[3];                                   /* :1467 */
+    float* q = warped + 4 * (size_t)i;
+    q[0] = u; q[1] = v; q[2] = o[2]; q[3] = o[3];
+  }
+}
+
+/* Tracker.cpp:432-490. Returns the number of valid rows written. */
+int uwo_residual_jacobian(const uint8_t* img1, const uint8_t* img2, const int16_t* gx1, const int16_t* gy1,
+                          const float* pts, const float* warped, int n, const uwo_level* L,
+                          float zf, float af, float* J, float* r, int32_t* idx) {
+  int w = L->w, h = L->h;
+  float fx = L->fx, fy = L->fy;
+  int nv = 0;
+  for (int i = 0; i < n; i++) {
+    float x1 = pts[4 * (size_t)i], y1 = pts[4 * (size_t)i + 1];
+    float x2 = warped[4 * (size_t)i], y2 = warped[4 * (size_t)i + 1], z2 = warped[4 * (size_t)i + 2];
+    float iz = 1.0f / z2; /* :447 */
+    if (y2 > 0.0f && y2 < (float)h && x2 > 0.0f && x2 < (float)w) { /* :450 */
+      if (z2 != 0.0f) {                                              /* :451 */
+        if (iz < 0.0f) iz = 0.0f;                                    /* :452-453 */
+        float Jw[2][6];
+        Jw[0][0] = fx * iz;                               /* :455 */
+        Jw[0][1] = 0.0f;
+        Jw[0][2] = -(fx * x2 * iz * iz) * zf;             /* :457 */
+        Jw[0][3] = -(fx * x2 * y2 * iz * iz) * af;        /* :458 */
+        Jw[0][4] = (fx * (1.0f + x2 * x2 * iz * iz)) * af; /* :459 */
+        Jw[0][5] = -fx * y2 * iz * af;                    /* :460 */
+        Jw[1][0] = 0.0f;
+        Jw[1][1] = fy * iz;                               /* :463 */
+        Jw[1][2] = -(fy * y2 * iz * iz) * zf;             /* :464 */
+        Jw[1][3] = -(fy * (1.0f + y2 * y2 * iz * iz)) * af; /* :465 */
+        Jw[1][4] = fy * x2 * y2 * iz * iz * af;           /* :466 */
+        Jw[1][5] = fy * x2 * iz * af;                     /* :467 */
+
+        int ix1 = (int)x1, iy1 = (int)y1; /* Mat::at(float,float) truncates */
+        int ix2 = (int)roundf(x2), iy2 = (int)roundf(y2); /* :472 */
+        if (ix2 > w - 1) ix2 = w - 1; /* S7 */
+        if (iy2 > h - 1) iy2 = h - 1;
+        int i1 = img1[(size_t)iy1 * w + ix1];
+        int i2 = img2[(size_t)iy2 * w + ix2];
+        float res = (float)(i2 - i1); /* :474 */
+        float jl0 = (float)gx1[(size_t)iy1 * w + ix1]; /* :476 */
+        float jl1 = (float)gy1[(size_t)iy1 * w + ix1]; /* :477 */
+        float* Jr = J + 6 * (size_t)nv;
+        for (int k = 0; k < 6; k++) { /* :479 Jl * Jw (S1) */
+          float s = jl0 * Jw[0][k];
+          s = fmaf(jl1, Jw[1][k], s);
+          Jr[k] = s;
+        }
+        r[nv] = res;
+        if (idx) idx[nv] = i;
+        nv++;
+      }
+    }
+  }
+  return nv;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* weights (Tracker.cpp:1571-1654)                                                              */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Tracker::MedianMat, :1571-1594: saturating convert to u8 (cvRound; negatives -> 0), 256-bin histogram. */
+float uwo_median_mat(const float* v, int n) {
+  int hist[256];
+  memset(hist, 0, sizeof(hist));
+  for (int i = 0; i < n; i++) {
+    long q = lrintf(v[i]);
+    if (q < 0) q = 0;
+    if (q > 255) q = 255;
+    hist[q]++;
+  }
+  float m = (float)(n / 2);
+  int bin = 0;
+  float med = -1.0f;
+  for (int i = 0; i < 256 && med < 0.0f; ++i) {
+    bin += hist[i];
+    if ((float)bin > m && med < 0.0f) med = (float)i;
+  }
+  return med;
+}
+
+/* Tracker::MedianAbsoluteDeviation, :1607-1619 */
+float uwo_mad(const float* v, int n) {
+  float c = 1.4826f;
+  float median = uwo_median_mat(v, n);
+  float* dev = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) dev[i] = fabsf(v[i] - median);
+  float mad = uwo_median_mat(dev, n);
+  free(dev);
+  return c * mad;
+}
+
+/* Tracker::TukeyFunctionWeights, :1626-1654 */
+void uwo_tukey_weights(const float* r, int n, float* w) {
+  float b = 4.6851f;
+  float MAD = uwo_mad(r, n);
+  if (MAD == 0.0f) MAD = 1.0f;
+  float inv_MAD = (float)(1.0 / (double)MAD);
+  float inv_b2 = (float)(1.0 / (double)(b * b));
+  for (int i = 0; i < n; i++) {
+    float x = r[i] * inv_MAD;
+    if (fabsf(x) <= b) {
+      float tukey = (float)(1.0 - (double)((x * x) * inv_b2));
+      w[i] = tukey * tukey;
+    } else {
+      w[i] = 0.0f;
+    }
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* error, normal equations, solve                                                               */
+/* ------------------------------------------------------------------------------------------ */
+
+/* Tracker.cpp:499-502 (S2, S8). w may be NULL (identity). */
+float uwo_error(const float* r, const float* w, int n, int64_t* sum_r2_out) {
+  double s = 0.0;
+  int64_t si = 0;
+  for (int i = 0; i < n; i++) {
+    float rw = w ? r[i] * w[i] : r[i];
+    s += (double)r[i] * (double)rw;
+    si += (int64_t)r[i] * (int64_t)r[i];
+  }
+  if (sum_r2_out) *sum_r2_out = si;
+  float inv_n = (float)(1.0 / (double)n); /* :499 */
+  return (float)((double)inv_n * s);
+}
+
+/* Tracker.cpp:554-561 (S2).  J <- w∘J ; r <- gain·r ; A = JᵀJ ; b = -Jᵀ(r∘w). */
+void uwo_normal_equations(const float* J, const float* r, const float* w, int n, float gain, float A[36], float b[6]) {
+  double Ad[36], bd[6];
+  memset(Ad, 0, sizeof(Ad));
+  memset(bd, 0, sizeof(bd));
+  for (int i = 0; i < n; i++) {
+    float wi = w ? w[i] : 1.0f;
+    float Jr[6];
+    for (int k = 0; k < 6; k++) Jr[k] = wi * J[6 * (size_t)i + k]; /* :556 */
+    float rg = r[i] * gain;                                        /* :559 */
+    float rw = rg * wi;                                            /* :561 Residuals.mul(W) */
+    for (int a = 0; a < 6; a++) {
+      for (int c = 0; c < 6; c++) Ad[6 * a + c] += (double)Jr[a] * (double)Jr[c];
+      bd[a] += (double)Jr[a] * (double)rw;
+    }
+  }
+  for (int k = 0; k < 36; k++) A[k] = (float)Ad[k];
+  for (int k = 0; k < 6; k++) b[k] = (float)(-bd[k]);
+}
+
+/* cv::Mat::inv() default DECOMP_LU on CV_32F (Tracker.cpp:564; S3): OpenCV 3.x hal LU —
+ * partial pivoting on |A[j][i]|, singular if |pivot| < 10·FLT_EPSILON (result zeroed),
+ * d = -1/pivot, row updates A[j][k] += alpha·A[i][k], the pivot slot keeps 1/pivot, back
+ * substitution multiplies by it. */
+int uwo_inv6(const float Ain[36], float X[36]) {
+  const int m = 6;
+  float A[36];
+  memcpy(A, Ain, sizeof(A));
+  for (int i = 0; i < 36; i++) X[i] = 0.0f;
+  for (int i = 0; i < m; i++) X[7 * i] = 1.0f;
+  const float eps = FLT_EPSILON * 10;
+  for (int i = 0; i < m; i++) {
+    int k = i;
+    for (int j = i + 1; j < m; j++)
+      if (fabsf(A[j * m + i]) > fabsf(A[k * m + i])) k = j;
+    if (fabsf(A[k * m + i]) < eps) {
+      for (int q = 0; q < 36; q++) X[q] = 0.0f;
+      return 0;
+    }
+    if (k != i) {
+      for (int j = i; j < m; j++) { float t = A[i * m + j]; A[i * m + j] = A[k * m + j]; A[k * m + j] = t; }
+      for (int j = 0; j < m; j++) { float t = X[i * m + j]; X[i * m + j] = X[k * m + j]; X[k * m + j] = t; }
+    }
+    float d = -1.0f / A[i * m + i];
+    for (int j = i + 1; j < m; j++) {
+      float alpha = A[j * m + i] * d;
+      for (int q = i + 1; q < m; q++) A[j * m + q] = A[j * m + q] + alpha * A[i * m + q];
+      for (int q = 0; q < m; q++) X[j * m + q] = X[j * m + q] + alpha * X[i * m + q];
+    }
+    A[i * m + i] = -d;
+  }
+  for (int i = m - 1; i >= 0; i--)
+    for (int j = 0; j < m; j++) {
+      float s = X[i * m + j];
+      for (int q = i + 1; q < m; q++) s = s - A[i * m + q] * X[q * m + j];
+      X[i * m + j] = s * A[i * m + i];
+    }
+  return 1;
+}
+
+/* Tracker.cpp:564 deltaMat = A.inv() * b (S4). */
+void uwo_solve_delta(const float A[36], const float b[6], float delta[6]) {
+  float Ai[36];
+  uwo_inv6(A, Ai);
+  for (int i = 0; i < 6; i++) {
+    double s = 0.0;
+    for (int j = 0; j < 6; j++) s += (double)Ai[6 * i + j] * (double)b[j];
+    delta[i] = (float)s;
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Tracker::EstimatePose, Tracker.cpp:362-597                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+int uwo_estimate_pose(const uwo_params* p, const uwo_frame* prev, const uwo_frame* cur,
+                      float pose_out[7], uwo_trace* trace, int32_t* n_trace) {
+  if (p->first_level >= p->n_levels || p->last_level < 0 || p->last_level > p->first_level) return UWO_ERR_INVALID_ARG;
+  int cap = (trace && n_trace) ? *n_trace : 0;
+  int nt = 0;
+  int status = UWO_OK;
+  float pose[7];
+  uwo_se3_identity(pose); /* :385 */
+
+  uwo_level L0;
+  uwo_level_intrinsics(p, p->last_level, &L0);
+  size_t nmax = (size_t)L0.w * L0.h;
+  float* pts = (float*)malloc(sizeof(float) * 4 * nmax);
+  float* warped = (float*)malloc(sizeof(float) * 4 * nmax);
+  float* J = (float*)malloc(sizeof(float) * 6 * nmax);
+  float* r = (float*)malloc(sizeof(float) * nmax);
+  float* wts = (float*)malloc(sizeof(float) * nmax);
+
+  for (int lvl = p->first_level; lvl >= p->last_level && status == UWO_OK; lvl--) { /* :389 */
+    uwo_level L;
+    uwo_level_intrinsics(p, lvl, &L);
+    int n = L.w * L.h;
+    float last_error = p->initial_error; /* :393 */
+    uwo_dense_points(p->has_depth ? prev->depth[lvl] : NULL, L.w, L.h, lvl, p->depth_scale, pts); /* :401 */
+
+    for (int k = 0; k < p->max_iters; k++) { /* :414 */
+      uwo_warp(pts, n, pose, &L, warped); /* :422 */
+      int nv = uwo_residual_jacobian(prev->img[lvl], cur->img[lvl], prev->gx[lvl], prev->gy[lvl], pts, warped, n, &L,
+                                     p->z_factor, p->angle_factor, J, r, NULL);
+      if (nv == 0) { status = UWO_ERR_NO_VALID_POINTS; break; } /* reference: cv::Exception on empty Mat product */
+      const float* W = NULL;
+      if (p->weights == UWO_WEIGHTS_TUKEY_REFERENCE) { uwo_tukey_weights(r, nv, wts); W = wts; } /* :495-496 */
+      int64_t sr2 = 0;
+      float error = uwo_error(r, W, nv, &sr2); /* :499-502 */
+
+      uwo_trace* tr = (nt < cap) ? &trace[nt] : NULL;
+      if (tr) {
+        memset(tr, 0, sizeof(*tr));
+        tr->level = lvl; tr->iter = k; tr->n_valid = nv; tr->sum_r2 = sr2; tr->error = error;
+      }
+      int exit_now = 0;
+      if (p->early_exit) { /* :508 */
+        if (error >= last_error || k == p->max_iters - 1 || fabsf(error - last_error) < p->epsilon) exit_now = 1;
+      }
+      if (exit_now) {
+        if (tr) { tr->exited = 1; memcpy(tr->pose, pose, sizeof(pose)); }
+        nt++;
+        break;
+      }
+      last_error = error; /* :529 */
+
+      float A[36], b[6], delta[6];
+      uwo_normal_equations(J, r, W, nv, p->gain, A, b); /* :554-561 */
+      uwo_solve_delta(A, b, delta);                    /* :564 */
+      float dT[7], np[7];
+      uwo_se3_exp(delta, dT);                          /* :574 */
+      uwo_se3_mul(pose, dT, np);
+      memcpy(pose, np, sizeof(pose));
+      if (tr) {
+        memcpy(tr->A, A, sizeof(A)); memcpy(tr->b, b, sizeof(b)); memcpy(tr->delta, delta, sizeof(delta));
+        memcpy(tr->pose, pose, sizeof(pose));
+      }
+      nt++;
+    }
+    if (status != UWO_OK) break;
+    if (lvl != 0) { /* :580 */
+      if (uwo_se3_handoff(pose, p->handoff_scale_t) != UWO_OK) status = UWO_ERR_INVALID_ARG;
+    }
+  }
+  free(pts); free(warped); free(J); free(r); free(wts);
+  memcpy(pose_out, pose, sizeof(pose)); /* :595 */
+  if (n_trace) *n_trace = nt < cap ? nt : cap;
+  return status;
+}
+
+/* System::AddFrame pyramid loop + Tracker::ApplyGradient + EstimatePose for one pair. */
+int uwo_align_pair(const uwo_params* p, const uint8_t* ref_gray, const uint8_t* tgt_gray,
+                   const uint16_t* ref_depth, const uint16_t* tgt_depth,
+                   float pose_out[7], uwo_trace* trace, int32_t* n_trace) {
+  (void)tgt_depth; /* the tracker reads only the previous frame's depth (Tracker.cpp:401) */
+  if (p->n_levels < 1 || p->n_levels > UWO_MAX_LEVELS) return UWO_ERR_INVALID_ARG;
+  if ((p->width % (1 << (p->n_levels - 1))) || (p->height % (1 << (p->n_levels - 1)))) return UWO_ERR_INVALID_ARG;
+  uwo_frame fr[2];
+  memset(fr, 0, sizeof(fr));
+  void* owned[2][UWO_MAX_LEVELS][4];
+  memset(owned, 0, sizeof(owned));
+  const uint8_t* gray[2] = {ref_gray, tgt_gray};
+  for (int f = 0; f < 2; f++) {
+    for (int l = 0; l < p->n_levels; l++) {
+      int w = p->width >> l, h = p->height >> l;
+      size_t n = (size_t)w * h;
+      if (l == 0) {
+        fr[f].img[0] = gray[f];
+        if (f == 0 && p->has_depth) fr[f].depth[0] = ref_depth;
+      } else {
+        uint8_t* im = (uint8_t*)malloc(n);
+        uwo_halve_u8(fr[f].img[l - 1], w * 2, h * 2, im);
+        fr[f].img[l] = im; owned[f][l][0] = im;
+        if (f == 0 && p->has_depth) {
+          uint16_t* d = (uint16_t*)malloc(n * 2);
+          uwo_halve_u16(fr[f].depth[l - 1], w * 2, h * 2, d);
+          fr[f].depth[l] = d; owned[f][l][1] = d;
+        }
+      }
+      if (f == 0) { /* gradients of the previous frame only are consumed (Tracker.cpp:407-408) */
+        int16_t* gx = (int16_t*)malloc(n * 2);
+        int16_t* gy = (int16_t*)malloc(n * 2);
+        uwo_scharr3(fr[f].img[l], w, h, gx, gy);
+        fr[f].gx[l] = gx; fr[f].gy[l] = gy; owned[f][l][2] = gx; owned[f][l][3] = gy;
+      }
+    }
+  }
+  int st = uwo_estimate_pose(p, &fr[0], &fr[1], pose_out, trace, n_trace);
+  for (int f = 0; f < 2; f++)
+    for (int l = 0; l < UWO_MAX_LEVELS; l++)
+      for (int k = 0; k < 4; k++) free(owned[f][l][k]);
+  return st;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* LS, LeastSquares.cpp:30-209                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+
+void uwo_ls_initialize(uwo_ls* ls) { memset(ls, 0, sizeof(*ls)); } /* :30-37 */
+
+/* :204-209.  Eigen evaluates (J·Jᵀ)·weight coefficient-wise; b -= J·(res·weight). */
+void uwo_ls_update(uwo_ls* ls, const float J[6], float res, float weight) {
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) ls->A[6 * i + j] = ls->A[6 * i + j] + (J[i] * J[j]) * weight;
+  float rw = res * weight;
+  for (int i = 0; i < 6; i++) ls->b[i] = ls->b[i] - J[i] * rw;
+  ls->error = ls->error + res * res * weight;
+  ls->num_constraints += 1;
+}
+
+/* :148-202.  28 accumulators x 4 lanes: (J_i·w)·J_j ; (res·w)·J_i ; (res·w)·res.  The reference adds 6
+ * to num_constraints per 4 points (:201, quirk C-6); quirk_plus6 = 0 adds the correct 4. */
+void uwo_ls_update4(uwo_ls* ls, const float J[6][4], const float res[4], const float weight[4], int quirk_plus6) {
+  int s = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++, s++)
+      for (int l = 0; l < 4; l++) ls->sse[4 * s + l] = ls->sse[4 * s + l] + (J[i][l] * weight[l]) * J[j][l];
+  for (int i = 0; i < 6; i++, s++)
+    for (int l = 0; l < 4; l++) ls->sse[4 * s + l] = ls->sse[4 * s + l] + (res[l] * weight[l]) * J[i][l];
+  for (int l = 0; l < 4; l++) ls->sse[4 * s + l] = ls->sse[4 * s + l] + (res[l] * weight[l]) * res[l];
+  ls->num_constraints += quirk_plus6 ? 6 : 4;
+}
+
+/* :39-139.  Lanes folded left to right, added into A's first-row (upper) / other-rows (lower)
+ * slot, mirrored to the symmetric slot; b -= fold; error += fold. */
+void uwo_ls_finish_no_divide(uwo_ls* ls) {
+  int s = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++, s++) {
+      const float* a = ls->sse + 4 * s;
+      float f = a[0] + a[1] + a[2] + a[3];
+      if (i == j) {
+        ls->A[6 * i + i] = ls->A[6 * i + i] + f;
+      } else if (i == 0) {
+        ls->A[6 * 0 + j] = ls->A[6 * 0 + j] + f; /* A(j,0) = (A(0,j) += f) */
+        ls->A[6 * j + 0] = ls->A[6 * 0 + j];
+      } else {
+        ls->A[6 * j + i] = ls->A[6 * j + i] + f; /* A(i,j) = (A(j,i) += f) */
+        ls->A[6 * i + j] = ls->A[6 * j + i];
+      }
+    }
+  for (int i = 0; i < 6; i++, s++) {
+    const float* a = ls->sse + 4 * s;
+    ls->b[i] = ls->b[i] - (a[0] + a[1] + a[2] + a[3]);
+  }
+  const float* a = ls->sse + 4 * s;
+  ls->error = ls->error + (a[0] + a[1] + a[2] + a[3]);
+}
+
+/* :141-146 */
+void uwo_ls_finish(uwo_ls* ls) {
+  uwo_ls_finish_no_divide(ls);
+  float n = (float)ls->num_constraints;
+  for (int i = 0; i < 36; i++) ls->A[i] = ls->A[i] / n;
+  for (int i = 0; i < 6; i++) ls->b[i] = ls->b[i] / n;
+  ls->error = ls->error / n;
+}

@@ -1,0 +1,167 @@
+/*
+ * uwt_oracle.h — CPU ORACLE for the UW-SLAM direct SE(3) tracking hot path.
+ *
+ * THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path (uw-slam_amd/csrc,
+ * libuwt_hip.so) never links, imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the reference (MecatronicaUSB/uw-slam) ships no tests, golden vectors
+ * or fixtures for this path and cannot be compiled in this image (needs OpenCV 3.2 + contrib
+ * + CUDA, Eigen3, Ceres, ROS — all absent).  This file is a plain-C restatement
+ * of the reference algorithm; every function cites the reference file:line it follows.
+ * Third-party arithmetic that is not under /root/reference (OpenCV 3.2 resize / Scharr /
+ * gemm / Mat::inv, Eigen3 quaternion kernels) is restated from the published algorithms;
+ * the choices are listed under "Pinned semantics" below and in DESIGN.md.
+ *
+ * Pinned semantics (S1..S8), all IEEE-754 binary32 unless stated:
+ *  S1  small products (4x4·4xN warp, 1x2·2x6 Jacobian row): k-sequential f32 FMA chain
+ *      s = a0*b0; s = fma(a1,b1,s); ...
+ *  S2  N-long reductions (JᵀJ, Jᵀr, rᵀr): sequential f64 accumulation of exact f32 products,
+ *      rounded to f32 once (OpenCV's non-BLAS gemm accumulates f32 data in double).
+ *      Σr² is an exact integer (residuals are integer differences of u8).
+ *  S3  cv::Mat::inv() = DECOMP_LU: f32 Gaussian elimination with partial pivoting,
+ *      pivot threshold 10·FLT_EPSILON, singular ⇒ all-zero inverse; no FMA contraction.
+ *  S4  6x6·6x1 solve product: f64 accumulate, round to f32.
+ *  S5  sinf/cosf := (float)sin/cos((double)x); sqrtf, 1/x, a/b correctly rounded.
+ *  S6  Sophus / Eigen quaternion formulas: generic (non-SIMD) left-to-right f32, no FMA.
+ *  S7  nearest-neighbour index round(x2) may equal the dimension (reference reads out of
+ *      bounds, Tracker.cpp:450,472); the oracle clamps the index to dim-1.
+ *  S8  error = (float)((double)(float)(1.0/N) * (double)Σ w r²)  (scaled-gemm form of
+ *      Tracker.cpp:499-502).
+ *
+ * Build with -ffp-contract=off (oracle/Makefile does).
+ */
+#ifndef UWT_ORACLE_H
+#define UWT_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UWO_MAX_LEVELS 8
+
+/* status codes (mirrors include/uwt.h) */
+enum {
+  UWO_OK = 0,
+  UWO_ERR_INVALID_ARG = 1,
+  UWO_ERR_NO_VALID_POINTS = 2
+};
+
+enum { UWO_WEIGHTS_IDENTITY = 0, UWO_WEIGHTS_TUKEY_REFERENCE = 1 };
+
+typedef struct uwo_params {
+  int32_t width, height;     /* level-0 size */
+  float fx, fy, cx, cy;      /* level-0 intrinsics (K) */
+  int32_t n_levels;          /* PYRAMID_LEVELS (Options.cpp:26) */
+  int32_t first_level;       /* coarsest level iterated (Tracker.cpp:368) */
+  int32_t last_level;        /* finest level iterated   (Tracker.cpp:369) */
+  int32_t max_iters;         /* Tracker.cpp:366 */
+  float epsilon;             /* Tracker.cpp:364 */
+  float gain;                /* Tracker.cpp:559 */
+  float z_factor;            /* Tracker.cpp:371 */
+  float angle_factor;        /* Tracker.cpp:372 */
+  float depth_scale;         /* Tracker.cpp:1261 */
+  float initial_error;       /* Tracker.cpp:393 */
+  int32_t early_exit;        /* 1: reference termination rule; 0: exactly max_iters updates/level */
+  int32_t has_depth;
+  int32_t handoff_scale_t;   /* 0: EstimatePose (:580-590); 1: EstimatePoseFeatures (:856) */
+  int32_t weights;           /* UWO_WEIGHTS_* */
+} uwo_params;
+
+typedef struct uwo_level {
+  int32_t w, h;
+  float fx, fy, cx, cy, invfx, invfy;
+} uwo_level;
+
+/* one row per GN iteration (fixtures / parity traces) */
+typedef struct uwo_trace {
+  int32_t level, iter, n_valid, exited;   /* exited: 1 if the exit test fired at this iteration */
+  int64_t sum_r2;                         /* Σ r² (exact; identity weights) */
+  float error;
+  float A[36];
+  float b[6];
+  float delta[6];
+  float pose[7];                          /* qx qy qz qw tx ty tz after this iteration */
+} uwo_trace;
+
+void uwo_default_params(uwo_params* p, int width, int height, float fx, float fy, float cx, float cy);
+
+/* Tracker::InitializePyramid, Tracker.cpp:297-340 */
+int uwo_level_intrinsics(const uwo_params* p, int lvl, uwo_level* out);
+
+/* System::AddFrame pyramid loop, System.cpp:246-251 (cv::resize ½ == 2x2 mean, round half up) */
+void uwo_halve_u8(const uint8_t* src, int w, int h, uint8_t* dst);
+void uwo_halve_u16(const uint16_t* src, int w, int h, uint16_t* dst);
+
+/* Tracker::ApplyGradient, Tracker.cpp:1133-1134: cv::Scharr(.., CV_16S, dx, dy, scale=3, delta=0, BORDER_REFLECT_101) */
+void uwo_scharr3(const uint8_t* src, int w, int h, int16_t* gx, int16_t* gy);
+/* gradient_ magnitude image, Tracker.cpp:1136-1142 (convertScaleAbs + addWeighted 0.5/0.5), u8 */
+void uwo_gradient_mag(const int16_t* gx, const int16_t* gy, int n, uint8_t* out);
+
+/* Tracker::ObtainAllPoints, Tracker.cpp:1259-1310: dense N x 4 table [x y z w] */
+void uwo_dense_points(const uint16_t* depth_or_null, int w, int h, int lvl, float depth_scale, float* pts);
+
+/* SE3 helpers; pose = qx qy qz qw tx ty tz */
+void uwo_se3_identity(float pose[7]);
+void uwo_se3_exp(const float xi[6], float pose[7]);                 /* sophus/se3.hpp:723-744 */
+void uwo_se3_mul(const float a[7], const float b[7], float out[7]); /* se3.hpp:317-321, so3.hpp:338-354 */
+void uwo_se3_matrix(const float pose[7], float T[16]);              /* se3.hpp:253-268 (row-major 4x4) */
+int  uwo_se3_handoff(float pose[7], int scale_t);                   /* Tracker.cpp:580-590 */
+
+/* Tracker::WarpFunction, Tracker.cpp:1417-1471 */
+void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, float* warped);
+
+/* per-point loop of Tracker::EstimatePose, Tracker.cpp:432-490.
+ * J (n x 6) and r (n) receive the valid rows compacted; idx (n, optional) their point index. */
+int uwo_residual_jacobian(const uint8_t* img1, const uint8_t* img2, const int16_t* gx1, const int16_t* gy1,
+                          const float* pts, const float* warped, int n, const uwo_level* L,
+                          float z_factor, float angle_factor, float* J, float* r, int32_t* idx);
+
+/* weights, Tracker.cpp:1571-1654 */
+float uwo_median_mat(const float* v, int n);
+float uwo_mad(const float* v, int n);
+void  uwo_tukey_weights(const float* r, int n, float* w);
+
+/* error + normal equations + solve, Tracker.cpp:495-564 */
+float uwo_error(const float* r, const float* w, int n, int64_t* sum_r2_out);
+void  uwo_normal_equations(const float* J, const float* r, const float* w, int n, float gain, float A[36], float b[6]);
+int   uwo_inv6(const float A[36], float Ainv[36]);  /* returns 0 when singular (Ainv zeroed) */
+void  uwo_solve_delta(const float A[36], const float b[6], float delta[6]);
+
+/* one frame's pyramid data as the tracker consumes it */
+typedef struct uwo_frame {
+  const uint8_t* img[UWO_MAX_LEVELS];
+  const uint16_t* depth[UWO_MAX_LEVELS]; /* NULL if !has_depth */
+  const int16_t* gx[UWO_MAX_LEVELS];
+  const int16_t* gy[UWO_MAX_LEVELS];
+} uwo_frame;
+
+/* Tracker::EstimatePose, Tracker.cpp:362-597.  trace may be NULL; *n_trace in: capacity, out: rows. */
+int uwo_estimate_pose(const uwo_params* p, const uwo_frame* prev, const uwo_frame* cur,
+                      float pose_out[7], uwo_trace* trace, int32_t* n_trace);
+
+/* convenience: level-0 images in, pyramid + gradients + EstimatePose; (the CPU-baseline unit of work) */
+int uwo_align_pair(const uwo_params* p, const uint8_t* ref_gray, const uint8_t* tgt_gray,
+                   const uint16_t* ref_depth, const uint16_t* tgt_depth,
+                   float pose_out[7], uwo_trace* trace, int32_t* n_trace);
+
+/* LS, LeastSquares.cpp:30-209 */
+typedef struct uwo_ls {
+  float A[36];
+  float b[6];
+  float error;
+  int32_t num_constraints;
+  float sse[4 * 28];
+} uwo_ls;
+void uwo_ls_initialize(uwo_ls* ls);
+void uwo_ls_update(uwo_ls* ls, const float J[6], float res, float weight);
+void uwo_ls_update4(uwo_ls* ls, const float J[6][4], const float res[4], const float weight[4], int quirk_plus6);
+void uwo_ls_finish_no_divide(uwo_ls* ls);
+void uwo_ls_finish(uwo_ls* ls);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
