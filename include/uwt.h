@@ -1,0 +1,171 @@
+/*
+ * uwt.h — C ABI of the MI355X-native direct SE(3) tracker (libuwt_hip.so).
+ *
+ * Drop-in boundary for UW-SLAM's per-frame direct-tracking hot path.  Each entry point names the reference
+ * interface it replaces (paths relative to the reference repo).  Plain pointers and sizes only; every call
+ * returns an int status (UWT_OK == 0).  The caller owns all host buffers; a uwt_ctx owns its device buffers
+ * and its HIP stream.  One ctx per host thread per GPU.  Calls are synchronous unless named *_async.
+ *
+ * The library is HIP-only: there is no CPU fallback.  uwt_create() fails with UWT_ERR_NO_DEVICE when no
+ * gfx950 device is visible.
+ */
+#ifndef UWT_H
+#define UWT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UWT_MAX_LEVELS 8
+#define UWT_ABI_VERSION 1
+
+enum uwt_status_code {
+  UWT_OK = 0,
+  UWT_ERR_INVALID_ARG = 1,
+  UWT_ERR_NO_VALID_POINTS = 2, /* reference: cv::Exception from the empty Mat product, src/Tracker.cpp:501 */
+  UWT_ERR_HIP = 3,
+  UWT_ERR_NO_DEVICE = 4,
+  UWT_ERR_CAPACITY = 5
+};
+
+enum uwt_plane { UWT_PLANE_IMAGE = 0, UWT_PLANE_DEPTH = 1, UWT_PLANE_GRADX = 2, UWT_PLANE_GRADY = 3 };
+
+/* All solver constants the reference hard-codes as locals of Tracker::EstimatePose* (src/Tracker.cpp:364-372,
+ * 634-640) and as link-time globals (src/Options.cpp:26-28), as one POD. */
+typedef struct uwt_params {
+  int32_t width, height;     /* level-0 size; must be divisible by 2^(n_levels-1)                       */
+  float fx, fy, cx, cy;      /* level-0 intrinsics = K passed to Tracker::InitializePyramid              */
+  int32_t n_levels;          /* PYRAMID_LEVELS, src/Options.cpp:26 (5)                                   */
+  int32_t first_level;       /* coarsest level iterated, src/Tracker.cpp:368 (4)                         */
+  int32_t last_level;        /* finest level iterated,   src/Tracker.cpp:369 (1)                         */
+  int32_t max_iters;         /* src/Tracker.cpp:366 (50)                                                 */
+  float epsilon;             /* src/Tracker.cpp:364 (1e-3)                                               */
+  float gain;                /* residual gain, src/Tracker.cpp:559 (50)                                  */
+  float z_factor;            /* src/Tracker.cpp:371 (1)                                                  */
+  float angle_factor;        /* src/Tracker.cpp:372 (1)                                                  */
+  float depth_scale;         /* src/Tracker.cpp:1261 (0.0002)                                            */
+  float initial_error;       /* last_error seed, src/Tracker.cpp:393 (50000)                             */
+  int32_t early_exit;        /* 1: reference exit test src/Tracker.cpp:508; 0: exactly max_iters updates */
+  int32_t has_depth;         /* Tracker(bool _depth_available)                                           */
+  int32_t handoff_scale_t;   /* 0: EstimatePose (:580-590); 1: EstimatePoseFeatures (:856)               */
+  int32_t max_frames;        /* frame-slot capacity of the context                                       */
+  int32_t max_pairs;         /* largest batch of pairs per call                                          */
+  int32_t device;            /* HIP device ordinal                                                       */
+} uwt_params;
+
+/* per-level camera model = the vectors Tracker::InitializePyramid fills (include/Tracker.h:516-528) */
+typedef struct uwt_level {
+  int32_t w, h;
+  float fx, fy, cx, cy, invfx, invfy;
+} uwt_level;
+
+typedef struct uwt_stats {
+  int32_t status;     /* per-pair uwt_status_code */
+  int32_t iterations; /* residual evaluations over all levels */
+  int32_t n_valid;    /* valid points of the last evaluation */
+  float error;        /* error of the last evaluation (src/Tracker.cpp:499-502) */
+} uwt_stats;
+
+/* normal-equation accumulators of one residual evaluation (the 28 LS accumulators, src/LeastSquares.cpp:151-199,
+ * plus the constraint count): A upper triangle row-major (A00 A01 .. A05 A11 .. A55), jtr = +Σ J·r (un-gained). */
+typedef struct uwt_accum {
+  double A[21];
+  double jtr[6];
+  int64_t sum_r2;
+  int32_t n_valid;
+  int32_t pad;
+} uwt_accum;
+
+typedef struct uwt_ctx uwt_ctx;
+
+/* ---- lifecycle -------------------------------------------------------------------------------------------- */
+
+/* Fills the reference's EstimatePose constants (src/Tracker.cpp:364-372) for a w x h camera. */
+int uwt_default_params(uwt_params* p, int32_t width, int32_t height, float fx, float fy, float cx, float cy);
+
+/* new Tracker(depth) + Tracker::InitializePyramid(w, h, K)  (src/System.cpp:121-122, src/Tracker.cpp:272, 297-340) */
+int uwt_create(const uwt_params* p, uwt_ctx** out);
+/* Tracker::~Tracker (src/Tracker.cpp:280-293) */
+int uwt_destroy(uwt_ctx* ctx);
+/* reads back w_/h_/fx_/fy_/cx_/cy_/invfx_/invfy_[lvl] (include/Tracker.h:516-526) */
+int uwt_level_info(const uwt_ctx* ctx, int32_t lvl, uwt_level* out);
+const char* uwt_status_string(int status);
+const char* uwt_last_error(const uwt_ctx* ctx);
+int uwt_abi_version(void);
+
+/* ---- frames (the Frame data the tracker borrows: images_, depths_, gradientX_, gradientY_; include/System.h:85-89) */
+
+/* Frame::images_[0] / depths_[0] of one frame from host memory with row strides in BYTES (cv::Mat::step).
+ * Replaces the imread result handed to the pyramid loop in System::AddFrame (src/System.cpp:228, 243). */
+int uwt_set_frame(uwt_ctx* ctx, int32_t slot, const uint8_t* gray, size_t row_stride,
+                  const uint16_t* depth_or_null, size_t depth_row_stride);
+/* n tightly packed frames (w*h elements each) into slots first_slot .. first_slot+n-1 */
+int uwt_upload_frames(uwt_ctx* ctx, int32_t first_slot, int32_t n, const uint8_t* gray, const uint16_t* depth_or_null);
+/* device pointer of a plane of a slot (so a producer can write level-0 frames in place, inputs resident in HBM) */
+int uwt_plane_device_ptr(uwt_ctx* ctx, int32_t slot, int32_t lvl, int32_t plane, void** out);
+/* copy one plane of one slot back to the host (tight rows) */
+int uwt_get_plane(uwt_ctx* ctx, int32_t slot, int32_t lvl, int32_t plane, void* host_out);
+
+/* the resize loop of System::AddFrame for levels 1..n_levels-1 (src/System.cpp:246-251), n frames at once */
+int uwt_build_pyramids(uwt_ctx* ctx, int32_t first_slot, int32_t n);
+/* Tracker::ApplyGradient(Frame*) (src/Tracker.cpp:1127-1134) for n frames at once */
+int uwt_apply_gradient(uwt_ctx* ctx, int32_t first_slot, int32_t n);
+
+/* ---- tracking --------------------------------------------------------------------------------------------- */
+
+/* Tracker::EstimatePose(previous, current) (src/Tracker.cpp:362-597) for n_pairs independent pairs.
+ * poses_out: n_pairs x 7 floats (qx qy qz qw tx ty tz) = previous_frame->rigid_transformation_ (:595).
+ * Dense points (Tracker::ObtainAllPoints, :1259-1310) are implicit: the pixel grid is never materialised. */
+int uwt_estimate_pose_batch(uwt_ctx* ctx, int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
+                            float* poses_out, uwt_stats* stats_out_or_null);
+
+/* Whole per-frame path for a resident batch: pyramids of slots [first_slot, first_slot+n_frames), gradients of
+ * the same slots, then EstimatePose for the pairs — enqueued on the context stream, results written to DEVICE
+ * memory (d_poses_out: n_pairs x 7 floats, d_stats_out_or_null: n_pairs uwt_stats).  uwt_sync() to wait. */
+int uwt_track_batch_async(uwt_ctx* ctx, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only,
+                          int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
+                          float* d_poses_out, uwt_stats* d_stats_out_or_null);
+int uwt_sync(uwt_ctx* ctx);
+/* the HIP stream (hipStream_t) the context launches on, for event timing by the caller */
+int uwt_stream(uwt_ctx* ctx, void** out);
+/* average device time in ms of the residual/Jacobian/reduction kernel launches and their count since the last
+ * reset (HIP events on the context stream; only recorded while profiling is enabled) */
+int uwt_profile_enable(uwt_ctx* ctx, int32_t on);
+int uwt_profile_read(uwt_ctx* ctx, double* residual_ms_total, int64_t* residual_launches, int64_t* residual_pixels);
+
+/* ---- per-stage entry points (each kernel parity-testable alone; host buffers, synchronous) ------------------ */
+
+/* cv::resize(src, dst, Size(), 0.5, 0.5) as used at src/System.cpp:247 / :249 */
+int uwt_halve_u8(uwt_ctx* ctx, const uint8_t* src, int32_t w, int32_t h, uint8_t* dst);
+int uwt_halve_u16(uwt_ctx* ctx, const uint16_t* src, int32_t w, int32_t h, uint16_t* dst);
+/* cv::Scharr(src, dst, CV_16S, 1|0, 0|1, scale=3, 0, BORDER_DEFAULT) as used at src/Tracker.cpp:1133-1134 */
+int uwt_scharr3(uwt_ctx* ctx, const uint8_t* src, int32_t w, int32_t h, int16_t* gx, int16_t* gy);
+/* Tracker::WarpFunction(points, T, lvl) (src/Tracker.cpp:1417-1471): n x 4 in, n x 4 out */
+int uwt_warp(uwt_ctx* ctx, int32_t lvl, const float* pts, int32_t n, const float pose[7], float* warped_out);
+/* one pass of the per-point loop of EstimatePose (src/Tracker.cpp:432-490) + the reduction, for one pair at one
+ * level under `pose`.  Optional per-pixel dumps (level w*h entries, row-major): J_out (x6), r_out, valid_out. */
+int uwt_residual_jacobian(uwt_ctx* ctx, int32_t ref_slot, int32_t tgt_slot, int32_t lvl, const float pose[7],
+                          uwt_accum* acc_out, float* J_out_or_null, float* r_out_or_null, uint8_t* valid_out_or_null);
+/* LS::initialize + n x LS::update(J, r, w) + LS::finishNoDivide / finish  (src/LeastSquares.cpp:30-37, 204-209,
+ * 39-146) on the GPU reduction.  A: 36 row-major, b: 6 (stored sign: b = -Σ w r J), error, count. */
+int uwt_ls_accumulate(uwt_ctx* ctx, const float* J, const float* r, const float* w_or_null, int32_t n, int32_t divide,
+                      float A[36], float b[6], float* error, int32_t* num_constraints);
+/* Sophus::SE3f::exp (thirdparty/sophus/se3.hpp:723-744) */
+int uwt_se3_exp(uwt_ctx* ctx, const float xi[6], float pose_out[7]);
+/* SE3f::operator* (se3.hpp:285-321) */
+int uwt_se3_mul(uwt_ctx* ctx, const float a[7], const float b[7], float out[7]);
+/* SE3f::matrix() (se3.hpp:253-268), row-major 4x4 */
+int uwt_se3_matrix(uwt_ctx* ctx, const float pose[7], float T_out[16]);
+/* level hand-off of EstimatePose (src/Tracker.cpp:580-590) */
+int uwt_se3_handoff(uwt_ctx* ctx, float pose_inout[7], int32_t scale_t);
+/* deltaMat = A.inv() * b (src/Tracker.cpp:564); Ainv_out_or_null receives cv::Mat::inv()'s result */
+int uwt_solve_delta(uwt_ctx* ctx, const float A[36], const float b[6], float delta_out[6], float* Ainv_out_or_null,
+                    int32_t* nonsingular_out_or_null);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,74 @@
+"""CPU-side checks of the drop-in boundary: the shared library loads, exports every symbol include/uwt.h declares,
+and refuses to run without a gfx950 device (no CPU fallback).  No compute calls here."""
+import importlib
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    importlib.import_module("uw-slam_amd").build_native()
+    return importlib.import_module("uw-slam_amd.capi")
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "uwt.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(uwt_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(capi):
+    lib = capi.lib()
+    declared = header_symbols()
+    assert len(declared) >= 28
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(capi.SYMBOLS) == declared
+    assert lib.uwt_abi_version() == 1
+
+
+def test_struct_layouts_match_header(capi):
+    import ctypes as C
+    assert C.sizeof(capi.Params) == 22 * 4
+    assert C.sizeof(capi.Level) == 8 * 4
+    assert C.sizeof(capi.Stats) == 16
+    assert C.sizeof(capi.Accum) == 21 * 8 + 6 * 8 + 8 + 8
+
+
+def test_default_params_are_the_reference_constants(capi):
+    p = capi.default_params(640, 480, 525.0, 525.0, 319.5, 239.5)
+    # src/Tracker.cpp:364-372, 393, 559, 1261; src/Options.cpp:26
+    assert (p.n_levels, p.first_level, p.last_level, p.max_iters) == (5, 4, 1, 50)
+    assert p.epsilon == pytest.approx(1e-3) and p.gain == 50.0 and p.initial_error == 50000.0
+    assert p.z_factor == 1.0 and p.angle_factor == 1.0 and p.depth_scale == pytest.approx(2e-4)
+    assert p.early_exit == 1 and p.handoff_scale_t == 0
+    assert capi.lib().uwt_status_string(2) == b"no valid points"
+
+
+def test_no_gpu_means_loud_failure_not_fallback(capi):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = capi.default_params(64, 48, 64.0, 64.0, 31.5, 23.5, n_levels=3, first_level=2, last_level=0)
+    with pytest.raises(capi.UwtError) as e:
+        capi.Context(p)
+    assert e.value.status == capi.ERR_NO_DEVICE
+
+
+def test_product_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under uw-slam_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("uw-slam_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"\boracle\b", txt) and f not in ("__init__.py",):
+                        for line in txt.splitlines():
+                            if re.search(r"import .*oracle|from oracle|uwt_oracle|libuwt_oracle|oracle/", line):
+                                bad.append((f, line.strip()))
+    assert not bad, bad

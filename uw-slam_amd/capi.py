@@ -1,0 +1,293 @@
+"""ctypes binding of libuwt_hip.so (the C ABI in include/uwt.h).  Plumbing only: every call lands in the HIP
+library; there is no Python or CPU implementation of the path here.  Import fails loudly when the shared
+library has not been built (run `python -c "import __graft_entry__ as g; g.build()"`).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libuwt_hip.so")
+
+OK, ERR_INVALID_ARG, ERR_NO_VALID_POINTS, ERR_HIP, ERR_NO_DEVICE, ERR_CAPACITY = range(6)
+PLANE_IMAGE, PLANE_DEPTH, PLANE_GRADX, PLANE_GRADY = range(4)
+MAX_LEVELS = 8
+
+
+class Params(C.Structure):
+    _fields_ = [
+        ("width", C.c_int32), ("height", C.c_int32),
+        ("fx", C.c_float), ("fy", C.c_float), ("cx", C.c_float), ("cy", C.c_float),
+        ("n_levels", C.c_int32), ("first_level", C.c_int32), ("last_level", C.c_int32), ("max_iters", C.c_int32),
+        ("epsilon", C.c_float), ("gain", C.c_float), ("z_factor", C.c_float), ("angle_factor", C.c_float),
+        ("depth_scale", C.c_float), ("initial_error", C.c_float),
+        ("early_exit", C.c_int32), ("has_depth", C.c_int32), ("handoff_scale_t", C.c_int32),
+        ("max_frames", C.c_int32), ("max_pairs", C.c_int32), ("device", C.c_int32),
+    ]
+
+
+class Level(C.Structure):
+    _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
+                ("cx", C.c_float), ("cy", C.c_float), ("invfx", C.c_float), ("invfy", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("status", C.c_int32), ("iterations", C.c_int32), ("n_valid", C.c_int32), ("error", C.c_float)]
+
+
+class Accum(C.Structure):
+    _fields_ = [("A", C.c_double * 21), ("jtr", C.c_double * 6), ("sum_r2", C.c_int64),
+                ("n_valid", C.c_int32), ("pad", C.c_int32)]
+
+
+# every symbol include/uwt.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "uwt_abi_version", "uwt_status_string", "uwt_last_error", "uwt_default_params", "uwt_create", "uwt_destroy",
+    "uwt_level_info", "uwt_set_frame", "uwt_upload_frames", "uwt_plane_device_ptr", "uwt_get_plane",
+    "uwt_build_pyramids", "uwt_apply_gradient", "uwt_estimate_pose_batch", "uwt_track_batch_async", "uwt_sync",
+    "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
+    "uwt_warp", "uwt_residual_jacobian", "uwt_ls_accumulate", "uwt_se3_exp", "uwt_se3_mul", "uwt_se3_matrix",
+    "uwt_se3_handoff", "uwt_solve_delta",
+]
+
+_lib = None
+
+
+class UwtError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("uwt status %d: %s" % (status, msg))
+        self.status = status
+
+
+def lib():
+    """Loads libuwt_hip.so; raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libuwt_hip.so not built at %s — run __graft_entry__.build()" % LIB_PATH)
+        _lib = C.CDLL(LIB_PATH)
+        _lib.uwt_status_string.restype = C.c_char_p
+        _lib.uwt_last_error.restype = C.c_char_p
+        _lib.uwt_last_error.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def default_params(width, height, fx, fy, cx, cy, **over):
+    p = Params()
+    st = lib().uwt_default_params(C.byref(p), width, height, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy))
+    if st:
+        raise UwtError(st, "uwt_default_params")
+    for k, v in over.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+class Context:
+    """Owns one uwt_ctx (device buffers + stream) — the state behind a reference `Tracker` instance."""
+
+    def __init__(self, params):
+        self.params = params
+        self._h = C.c_void_p()
+        st = lib().uwt_create(C.byref(params), C.byref(self._h))
+        if st:
+            raise UwtError(st, lib().uwt_status_string(st).decode())
+        self.w, self.h = params.width, params.height
+
+    def close(self):
+        if self._h:
+            lib().uwt_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st, allow=()):
+        if st and st not in allow:
+            raise UwtError(st, lib().uwt_last_error(self._h).decode())
+        return st
+
+    # -- frames
+    def level_info(self, lvl):
+        L = Level()
+        self._chk(lib().uwt_level_info(self._h, lvl, C.byref(L)))
+        return L
+
+    def set_frame(self, slot, gray, depth=None):
+        gray = np.asarray(gray)
+        assert gray.dtype == np.uint8 and gray.shape == (self.h, self.w) and gray.strides[1] == 1
+        dp, ds = None, 0
+        if depth is not None:
+            depth = np.asarray(depth)
+            assert depth.dtype == np.uint16 and depth.shape == (self.h, self.w) and depth.strides[1] == 2
+            dp, ds = _p(depth, C.c_uint16), depth.strides[0]
+        self._chk(lib().uwt_set_frame(self._h, slot, _p(gray, C.c_uint8), C.c_size_t(gray.strides[0]), dp, C.c_size_t(ds)))
+
+    def upload_frames(self, first_slot, gray, depth=None):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        n = gray.shape[0]
+        assert gray.shape[1:] == (self.h, self.w)
+        dp = None
+        if depth is not None:
+            depth = np.ascontiguousarray(depth, np.uint16)
+            assert depth.shape == gray.shape
+            dp = _p(depth, C.c_uint16)
+        self._chk(lib().uwt_upload_frames(self._h, first_slot, n, _p(gray, C.c_uint8), dp))
+
+    def plane_device_ptr(self, slot, lvl, plane):
+        out = C.c_void_p()
+        self._chk(lib().uwt_plane_device_ptr(self._h, slot, lvl, plane, C.byref(out)))
+        return out.value
+
+    def get_plane(self, slot, lvl, plane):
+        L = self.level_info(lvl)
+        dt = {PLANE_IMAGE: np.uint8, PLANE_DEPTH: np.uint16, PLANE_GRADX: np.int16, PLANE_GRADY: np.int16}[plane]
+        out = np.empty((L.h, L.w), dt)
+        self._chk(lib().uwt_get_plane(self._h, slot, lvl, plane, out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def build_pyramids(self, first_slot, n):
+        self._chk(lib().uwt_build_pyramids(self._h, first_slot, n))
+
+    def apply_gradient(self, first_slot, n):
+        self._chk(lib().uwt_apply_gradient(self._h, first_slot, n))
+
+    # -- tracking
+    def estimate_pose_batch(self, ref_slots, tgt_slots, raise_on_pair_failure=False):
+        ref = np.ascontiguousarray(ref_slots, np.int32)
+        tgt = np.ascontiguousarray(tgt_slots, np.int32)
+        n = ref.size
+        poses = np.empty((n, 7), np.float32)
+        stats = (Stats * n)()
+        st = lib().uwt_estimate_pose_batch(self._h, n, _p(ref, C.c_int32), _p(tgt, C.c_int32), _p(poses, C.c_float), stats)
+        self._chk(st, allow=() if raise_on_pair_failure else (ERR_NO_VALID_POINTS, ERR_INVALID_ARG))
+        return poses, [dict(status=s.status, iterations=s.iterations, n_valid=s.n_valid, error=s.error) for s in stats]
+
+    def track_batch_async(self, first_slot, n_frames, ref_slots, tgt_slots, d_poses_ptr, d_stats_ptr=None):
+        ref = np.ascontiguousarray(ref_slots, np.int32)
+        tgt = np.ascontiguousarray(tgt_slots, np.int32)
+        self._chk(lib().uwt_track_batch_async(self._h, first_slot, n_frames, 0, ref.size, _p(ref, C.c_int32),
+                                              _p(tgt, C.c_int32), C.c_void_p(d_poses_ptr),
+                                              C.c_void_p(d_stats_ptr) if d_stats_ptr else None))
+
+    def sync(self):
+        self._chk(lib().uwt_sync(self._h))
+
+    def stream(self):
+        out = C.c_void_p()
+        self._chk(lib().uwt_stream(self._h, C.byref(out)))
+        return out.value
+
+    def profile_enable(self, on=True):
+        self._chk(lib().uwt_profile_enable(self._h, int(on)))
+
+    def profile_read(self):
+        ms, n, px = C.c_double(), C.c_int64(), C.c_int64()
+        self._chk(lib().uwt_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(px)))
+        return ms.value, n.value, px.value
+
+    # -- per-stage entry points
+    def halve_u8(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.empty((h // 2, w // 2), np.uint8)
+        self._chk(lib().uwt_halve_u8(self._h, _p(img, C.c_uint8), w, h, _p(out, C.c_uint8)))
+        return out
+
+    def halve_u16(self, img):
+        img = np.ascontiguousarray(img, np.uint16)
+        h, w = img.shape
+        out = np.empty((h // 2, w // 2), np.uint16)
+        self._chk(lib().uwt_halve_u16(self._h, _p(img, C.c_uint16), w, h, _p(out, C.c_uint16)))
+        return out
+
+    def scharr3(self, img):
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        gx = np.empty((h, w), np.int16)
+        gy = np.empty((h, w), np.int16)
+        self._chk(lib().uwt_scharr3(self._h, _p(img, C.c_uint8), w, h, _p(gx, C.c_int16), _p(gy, C.c_int16)))
+        return gx, gy
+
+    def warp(self, lvl, pts, pose):
+        pts = np.ascontiguousarray(pts, np.float32)
+        pose = np.ascontiguousarray(pose, np.float32)
+        out = np.empty_like(pts)
+        self._chk(lib().uwt_warp(self._h, lvl, _p(pts, C.c_float), pts.shape[0], _p(pose, C.c_float), _p(out, C.c_float)))
+        return out
+
+    def residual_jacobian(self, ref_slot, tgt_slot, lvl, pose, dump=True):
+        pose = np.ascontiguousarray(pose, np.float32)
+        L = self.level_info(lvl)
+        n = L.w * L.h
+        acc = Accum()
+        J = np.empty((n, 6), np.float32) if dump else None
+        r = np.empty(n, np.float32) if dump else None
+        v = np.empty(n, np.uint8) if dump else None
+        self._chk(lib().uwt_residual_jacobian(self._h, ref_slot, tgt_slot, lvl, _p(pose, C.c_float), C.byref(acc),
+                                              _p(J, C.c_float) if dump else None, _p(r, C.c_float) if dump else None,
+                                              _p(v, C.c_uint8) if dump else None))
+        A = np.zeros((6, 6))
+        s = 0
+        for i in range(6):
+            for j in range(i, 6):
+                A[i, j] = A[j, i] = acc.A[s]
+                s += 1
+        return dict(A=A, jtr=np.array(acc.jtr), sum_r2=int(acc.sum_r2), n_valid=int(acc.n_valid), J=J, r=r, valid=v)
+
+    def ls_accumulate(self, J, r, w=None, divide=False):
+        J = np.ascontiguousarray(J, np.float32)
+        r = np.ascontiguousarray(r, np.float32)
+        A = np.empty(36, np.float32)
+        b = np.empty(6, np.float32)
+        err, cnt = C.c_float(), C.c_int32()
+        wp = None
+        if w is not None:
+            w = np.ascontiguousarray(w, np.float32)
+            wp = _p(w, C.c_float)
+        self._chk(lib().uwt_ls_accumulate(self._h, _p(J, C.c_float), _p(r, C.c_float), wp, r.size, int(divide),
+                                          _p(A, C.c_float), _p(b, C.c_float), C.byref(err), C.byref(cnt)))
+        return A.reshape(6, 6), b, err.value, cnt.value
+
+    def se3_exp(self, xi):
+        xi = np.ascontiguousarray(xi, np.float32)
+        out = np.empty(7, np.float32)
+        self._chk(lib().uwt_se3_exp(self._h, _p(xi, C.c_float), _p(out, C.c_float)))
+        return out
+
+    def se3_mul(self, a, b):
+        a = np.ascontiguousarray(a, np.float32)
+        b = np.ascontiguousarray(b, np.float32)
+        out = np.empty(7, np.float32)
+        self._chk(lib().uwt_se3_mul(self._h, _p(a, C.c_float), _p(b, C.c_float), _p(out, C.c_float)))
+        return out
+
+    def se3_matrix(self, pose):
+        pose = np.ascontiguousarray(pose, np.float32)
+        out = np.empty(16, np.float32)
+        self._chk(lib().uwt_se3_matrix(self._h, _p(pose, C.c_float), _p(out, C.c_float)))
+        return out.reshape(4, 4)
+
+    def se3_handoff(self, pose, scale_t=0):
+        pose = np.array(pose, np.float32)
+        self._chk(lib().uwt_se3_handoff(self._h, _p(pose, C.c_float), int(scale_t)))
+        return pose
+
+    def solve_delta(self, A, b):
+        A = np.ascontiguousarray(A, np.float32).reshape(36)
+        b = np.ascontiguousarray(b, np.float32)
+        d = np.empty(6, np.float32)
+        Ai = np.empty(36, np.float32)
+        ok = C.c_int32()
+        self._chk(lib().uwt_solve_delta(self._h, _p(A, C.c_float), _p(b, C.c_float), _p(d, C.c_float), _p(Ai, C.c_float),
+                                        C.byref(ok)))
+        return d, Ai.reshape(6, 6), bool(ok.value)

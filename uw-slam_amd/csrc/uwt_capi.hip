@@ -1,0 +1,775 @@
+// uwt_capi.hip — host side of libuwt_hip.so: the C ABI declared in include/uwt.h over the gfx950 kernels.
+// HIP only; there is no CPU path in this library.
+#include "../../include/uwt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "uwt_kernels.h"
+
+using namespace uwt;
+
+static_assert(sizeof(StatsOut) == sizeof(uwt_stats), "uwt_stats layout");
+
+struct uwt_ctx {
+  uwt_params p;
+  uwt_level info[UWT_MAX_LEVELS];
+  LevelK lv[UWT_MAX_LEVELS];
+  int vec = 1;                          // pixels per vector group (4 when every level width is a multiple of 4)
+  int slices[UWT_MAX_LEVELS];
+  int groups_per_block[UWT_MAX_LEVELS];
+  hipStream_t stream = nullptr;
+  uint8_t* img[UWT_MAX_LEVELS] = {};
+  uint16_t* depth[UWT_MAX_LEVELS] = {};
+  int16_t* gx[UWT_MAX_LEVELS] = {};
+  int16_t* gy[UWT_MAX_LEVELS] = {};
+  PairState* state = nullptr;
+  int* d_ref = nullptr;
+  int* d_tgt = nullptr;
+  uint32_t* partials = nullptr;
+  size_t partial_records = 0;
+  float* d_poses = nullptr;
+  StatsOut* d_stats = nullptr;
+  int* d_active = nullptr;              // early-exit polling counters
+  int* h_active = nullptr;              // pinned
+  void* scratch = nullptr;              // per-stage entry points
+  size_t scratch_bytes = 0;
+  bool profiling = false;
+  std::vector<hipEvent_t> ev_pool;      // start/stop pairs
+  size_t ev_used = 0;
+  double prof_ms = 0.0;
+  long long prof_launches = 0, prof_pixels = 0;
+  std::string last_error;
+};
+
+namespace {
+
+constexpr int kGroupsPerThread = 4;  // x VEC pixels per thread per launch (fixed ⇒ results independent of batch size)
+
+int fail(uwt_ctx* c, int code, const std::string& msg) {
+  if (c) c->last_error = msg;
+  return code;
+}
+
+#define HIPCHK(ctx, expr)                                                                                   \
+  do {                                                                                                      \
+    hipError_t e_ = (expr);                                                                                 \
+    if (e_ != hipSuccess)                                                                                   \
+      return fail(ctx, UWT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                     \
+  } while (0)
+
+int ensure_scratch(uwt_ctx* c, size_t bytes) {
+  if (bytes <= c->scratch_bytes) return UWT_OK;
+  if (c->scratch) HIPCHK(c, hipFree(c->scratch));
+  c->scratch = nullptr;
+  c->scratch_bytes = 0;
+  HIPCHK(c, hipMalloc(&c->scratch, bytes));
+  c->scratch_bytes = bytes;
+  return UWT_OK;
+}
+
+bool slot_range_ok(const uwt_ctx* c, int first, int n) { return first >= 0 && n >= 0 && first + n <= c->p.max_frames; }
+
+// Tracker::InitializePyramid (src/Tracker.cpp:297-340): fx halves in double then narrows (:317);
+// cx_l = (cx0 + 0.5) / 2^l - 0.5 evaluated in double (:319); invfx = 1 / fx in float (:328).
+void init_levels(uwt_ctx* c) {
+  const uwt_params& p = c->p;
+  float fx = p.fx, fy = p.fy;
+  for (int l = 0; l < p.n_levels; l++) {
+    if (l > 0) {
+      fx = (float)((double)fx * 0.5);
+      fy = (float)((double)fy * 0.5);
+    }
+    uwt_level& I = c->info[l];
+    I.w = p.width >> l;
+    I.h = p.height >> l;
+    I.fx = fx;
+    I.fy = fy;
+    I.cx = l == 0 ? p.cx : (float)(((double)p.cx + 0.5) / (double)(1 << l) - 0.5);
+    I.cy = l == 0 ? p.cy : (float)(((double)p.cy + 0.5) / (double)(1 << l) - 0.5);
+    I.invfx = 1.0f / fx;
+    I.invfy = 1.0f / fy;
+    LevelK& L = c->lv[l];
+    L.w = I.w; L.h = I.h; L.n = I.w * I.h;
+    L.fx = I.fx; L.fy = I.fy; L.cx = I.cx; L.cy = I.cy; L.invfx = I.invfx; L.invfy = I.invfy;
+    L.zscale = (float)((double)p.depth_scale / std::pow(2.0, (double)l));  // src/Tracker.cpp:1266
+    L.magic = (uint32_t)((0x100000000ull + (uint64_t)I.w - 1) / (uint64_t)I.w);
+  }
+}
+
+template <typename T>
+int launch_halve(uwt_ctx* c, const T* src, T* dst, int w_out, int h_out, size_t sfs, size_t dfs, int n_frames) {
+  if (n_frames == 0) return UWT_OK;
+  if (w_out % 4 == 0) {
+    const int groups = (w_out / 4) * h_out;
+    hipLaunchKernelGGL((k_halve<T, 4>), dim3((groups + kBlock - 1) / kBlock, n_frames), dim3(kBlock), 0, c->stream, src,
+                       dst, w_out, h_out, sfs, dfs);
+  } else {
+    const int groups = w_out * h_out;
+    hipLaunchKernelGGL((k_halve<T, 1>), dim3((groups + kBlock - 1) / kBlock, n_frames), dim3(kBlock), 0, c->stream, src,
+                       dst, w_out, h_out, sfs, dfs);
+  }
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
+int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int w, int h, size_t fs, int n_frames) {
+  if (n_frames == 0) return UWT_OK;
+  const int tiles = ((w + kGradTW - 1) / kGradTW) * ((h + kGradTH - 1) / kGradTH);
+  hipLaunchKernelGGL(k_scharr3, dim3(tiles, n_frames), dim3(kBlock), 0, c->stream, src, gx, gy, w, h, fs);
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
+template <int VEC, bool DEPTH, bool UNIT, bool DUMP>
+void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs) {
+  hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+}
+
+int launch_residual(uwt_ctx* c, const ResidualArgs& a, int n_pairs, bool dump) {
+  const bool depth = c->p.has_depth != 0;
+  const bool unit = (a.zf == 1.0f && a.af == 1.0f);
+  const int key = (c->vec == 4 ? 8 : 0) | (depth ? 4 : 0) | (unit ? 2 : 0) | (dump ? 1 : 0);
+  hipStream_t s = c->stream;
+  switch (key) {
+    case 0: launch_residual_t<1, false, false, false>(s, a, n_pairs); break;
+    case 1: launch_residual_t<1, false, false, true>(s, a, n_pairs); break;
+    case 2: launch_residual_t<1, false, true, false>(s, a, n_pairs); break;
+    case 3: launch_residual_t<1, false, true, true>(s, a, n_pairs); break;
+    case 4: launch_residual_t<1, true, false, false>(s, a, n_pairs); break;
+    case 5: launch_residual_t<1, true, false, true>(s, a, n_pairs); break;
+    case 6: launch_residual_t<1, true, true, false>(s, a, n_pairs); break;
+    case 7: launch_residual_t<1, true, true, true>(s, a, n_pairs); break;
+    case 8: launch_residual_t<4, false, false, false>(s, a, n_pairs); break;
+    case 9: launch_residual_t<4, false, false, true>(s, a, n_pairs); break;
+    case 10: launch_residual_t<4, false, true, false>(s, a, n_pairs); break;
+    case 11: launch_residual_t<4, false, true, true>(s, a, n_pairs); break;
+    case 12: launch_residual_t<4, true, false, false>(s, a, n_pairs); break;
+    case 13: launch_residual_t<4, true, false, true>(s, a, n_pairs); break;
+    case 14: launch_residual_t<4, true, true, false>(s, a, n_pairs); break;
+    default: launch_residual_t<4, true, true, true>(s, a, n_pairs); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
+ResidualArgs residual_args(uwt_ctx* c, int lvl) {
+  ResidualArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.img = c->img[lvl];
+  a.gx = c->gx[lvl];
+  a.gy = c->gy[lvl];
+  a.depth = c->depth[lvl];
+  a.ref_slots = c->d_ref;
+  a.tgt_slots = c->d_tgt;
+  a.state = c->state;
+  a.L = c->lv[lvl];
+  a.zf = c->p.z_factor;
+  a.af = c->p.angle_factor;
+  a.groups_per_block = c->groups_per_block[lvl];
+  a.slices = c->slices[lvl];
+  a.partials = c->partials;
+  return a;
+}
+
+int prof_begin(uwt_ctx* c, size_t* idx) {
+  if (c->ev_used + 2 > c->ev_pool.size()) {
+    for (int i = 0; i < 64; i++) {
+      hipEvent_t e;
+      HIPCHK(c, hipEventCreate(&e));
+      c->ev_pool.push_back(e);
+    }
+  }
+  *idx = c->ev_used;
+  c->ev_used += 2;
+  HIPCHK(c, hipEventRecord(c->ev_pool[*idx], c->stream));
+  return UWT_OK;
+}
+
+int prof_collect(uwt_ctx* c) {  // after a stream sync
+  for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i], c->ev_pool[i + 1]));
+    c->prof_ms += ms;
+  }
+  c->ev_used = 0;
+  return UWT_OK;
+}
+
+// Tracker::EstimatePose for a batch, enqueued on the stream (src/Tracker.cpp:362-597)
+int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats) {
+  const uwt_params& p = c->p;
+  const int tb = 128;
+  hipLaunchKernelGGL(k_init_state, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs,
+                     p.initial_error);
+  HIPCHK(c, hipGetLastError());
+  for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
+    ResidualArgs ra = residual_args(c, lvl);
+    UpdateArgs ua;
+    ua.partials = c->partials;
+    ua.state = c->state;
+    ua.slices = c->slices[lvl];
+    ua.max_iters = p.max_iters;
+    ua.early_exit = p.early_exit;
+    ua.epsilon = p.epsilon;
+    ua.gain = p.gain;
+    ua.active = nullptr;
+    int next_poll = 2;
+    for (int k = 0; k < p.max_iters; k++) {
+      size_t ev = 0;
+      if (c->profiling) {
+        int st = prof_begin(c, &ev);
+        if (st) return st;
+      }
+      int st = launch_residual(c, ra, n_pairs, false);
+      if (st) return st;
+      if (c->profiling) {
+        HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
+        c->prof_launches += 1;
+        c->prof_pixels += (long long)n_pairs * c->lv[lvl].n;
+      }
+      ua.k = k;
+      const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
+      ua.active = poll ? c->d_active : nullptr;
+      if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
+      hipLaunchKernelGGL(k_gn_update, dim3(n_pairs), dim3(64), 0, c->stream, ua);
+      HIPCHK(c, hipGetLastError());
+      if (poll) {  // reference-mode early exit: stop launching once every pair has left this level
+        HIPCHK(c, hipMemcpyAsync(c->h_active, c->d_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*c->h_active == 0) break;
+        next_poll *= 2;
+      }
+    }
+    hipLaunchKernelGGL(k_level_end, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs, lvl,
+                       p.handoff_scale_t, p.initial_error);
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_write_out, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs, d_poses,
+                     d_stats);
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
+int upload_pairs(uwt_ctx* c, int n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots) {
+  if (!ref_slots || !tgt_slots || n_pairs < 1) return fail(c, UWT_ERR_INVALID_ARG, "null pair lists or n_pairs < 1");
+  if (n_pairs > c->p.max_pairs) return fail(c, UWT_ERR_CAPACITY, "n_pairs exceeds max_pairs");
+  for (int i = 0; i < n_pairs; i++)
+    if (ref_slots[i] < 0 || ref_slots[i] >= c->p.max_frames || tgt_slots[i] < 0 || tgt_slots[i] >= c->p.max_frames)
+      return fail(c, UWT_ERR_INVALID_ARG, "pair slot out of range");
+  HIPCHK(c, hipMemcpyAsync(c->d_ref, ref_slots, sizeof(int) * n_pairs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_tgt, tgt_slots, sizeof(int) * n_pairs, hipMemcpyHostToDevice, c->stream));
+  return UWT_OK;
+}
+
+int run_se3_op(uwt_ctx* c, int op, const float* a, int na, const float* b, int nb, float* out, int nout, int* flag) {
+  if (!c) return UWT_ERR_INVALID_ARG;
+  int st = ensure_scratch(c, 4096);
+  if (st) return st;
+  float* d = (float*)c->scratch;  // [0,64) a, [64,128) b, [128,256) out, [256] flag
+  HIPCHK(c, hipMemcpyAsync(d, a, sizeof(float) * na, hipMemcpyHostToDevice, c->stream));
+  if (b) HIPCHK(c, hipMemcpyAsync(d + 64, b, sizeof(float) * nb, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_se3_ops, dim3(1), dim3(1), 0, c->stream, op, d, d + 64, d + 128, (int*)(d + 256));
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(out, d + 128, sizeof(float) * nout, hipMemcpyDeviceToHost, c->stream));
+  int f = 1;
+  HIPCHK(c, hipMemcpyAsync(&f, d + 256, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (flag) *flag = f;
+  return UWT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int uwt_abi_version(void) { return UWT_ABI_VERSION; }
+
+const char* uwt_status_string(int status) {
+  switch (status) {
+    case UWT_OK: return "ok";
+    case UWT_ERR_INVALID_ARG: return "invalid argument";
+    case UWT_ERR_NO_VALID_POINTS: return "no valid points";
+    case UWT_ERR_HIP: return "HIP error";
+    case UWT_ERR_NO_DEVICE: return "no gfx950 device";
+    case UWT_ERR_CAPACITY: return "capacity exceeded";
+    default: return "unknown status";
+  }
+}
+
+const char* uwt_last_error(const uwt_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int uwt_default_params(uwt_params* p, int32_t width, int32_t height, float fx, float fy, float cx, float cy) {
+  if (!p) return UWT_ERR_INVALID_ARG;
+  std::memset(p, 0, sizeof(*p));
+  p->width = width; p->height = height;
+  p->fx = fx; p->fy = fy; p->cx = cx; p->cy = cy;
+  p->n_levels = 5;          // src/Options.cpp:26
+  p->first_level = 4;       // src/Tracker.cpp:368
+  p->last_level = 1;        // :369
+  p->max_iters = 50;        // :366
+  p->epsilon = 0.001f;      // :364
+  p->gain = 50.0f;          // :559
+  p->z_factor = 1.0f;       // :371
+  p->angle_factor = 1.0f;   // :372
+  p->depth_scale = 0.0002f; // :1261
+  p->initial_error = 50000.0f;  // :393
+  p->early_exit = 1;
+  p->has_depth = 0;
+  p->handoff_scale_t = 0;
+  p->max_frames = 2;
+  p->max_pairs = 1;
+  p->device = 0;
+  return UWT_OK;
+}
+
+int uwt_create(const uwt_params* p, uwt_ctx** out) {
+  if (!p || !out) return UWT_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (p->n_levels < 1 || p->n_levels > UWT_MAX_LEVELS || p->width < 1 || p->height < 1) return UWT_ERR_INVALID_ARG;
+  const int div = 1 << (p->n_levels - 1);
+  if (p->width % div || p->height % div) return UWT_ERR_INVALID_ARG;
+  if (p->first_level >= p->n_levels || p->last_level < 0 || p->last_level > p->first_level) return UWT_ERR_INVALID_ARG;
+  if (p->max_iters < 1 || p->max_frames < 1 || p->max_pairs < 1) return UWT_ERR_INVALID_ARG;
+  if ((uint64_t)p->width * p->height * p->width >= 0x100000000ull) return UWT_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || p->device < 0 || p->device >= ndev) return UWT_ERR_NO_DEVICE;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, p->device) != hipSuccess) return UWT_ERR_NO_DEVICE;
+  if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return UWT_ERR_NO_DEVICE;  // code objects are gfx950 only
+
+  uwt_ctx* c = new (std::nothrow) uwt_ctx();
+  if (!c) return UWT_ERR_CAPACITY;
+  c->p = *p;
+  init_levels(c);
+  c->vec = 4;
+  for (int l = 0; l < p->n_levels; l++)
+    if (c->lv[l].w % 4) c->vec = 1;
+  size_t max_slices = 1;
+  for (int l = 0; l < p->n_levels; l++) {
+    const int n_groups = c->lv[l].n / c->vec;
+    c->groups_per_block[l] = kBlock * kGroupsPerThread;
+    c->slices[l] = (n_groups + c->groups_per_block[l] - 1) / c->groups_per_block[l];
+    if ((size_t)c->slices[l] > max_slices) max_slices = c->slices[l];
+  }
+  c->partial_records = max_slices * (size_t)p->max_pairs;
+
+#define CREATE_CHK(expr)                                                             \
+  do {                                                                               \
+    hipError_t e_ = (expr);                                                          \
+    if (e_ != hipSuccess) {                                                          \
+      std::fprintf(stderr, "uwt_create: %s: %s\n", #expr, hipGetErrorString(e_));    \
+      uwt_destroy(c);                                                                \
+      return UWT_ERR_HIP;                                                            \
+    }                                                                                \
+  } while (0)
+  CREATE_CHK(hipSetDevice(p->device));
+  CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  for (int l = 0; l < p->n_levels; l++) {
+    const size_t n = (size_t)c->lv[l].n * p->max_frames;
+    CREATE_CHK(hipMalloc((void**)&c->img[l], n));
+    CREATE_CHK(hipMalloc((void**)&c->gx[l], n * 2));
+    CREATE_CHK(hipMalloc((void**)&c->gy[l], n * 2));
+    if (p->has_depth) CREATE_CHK(hipMalloc((void**)&c->depth[l], n * 2));
+  }
+  CREATE_CHK(hipMalloc((void**)&c->state, sizeof(PairState) * p->max_pairs));
+  CREATE_CHK(hipMalloc((void**)&c->d_ref, sizeof(int) * p->max_pairs));
+  CREATE_CHK(hipMalloc((void**)&c->d_tgt, sizeof(int) * p->max_pairs));
+  CREATE_CHK(hipMalloc((void**)&c->partials, c->partial_records * kRecWords * sizeof(uint32_t)));
+  CREATE_CHK(hipMalloc((void**)&c->d_poses, sizeof(float) * 7 * p->max_pairs));
+  CREATE_CHK(hipMalloc((void**)&c->d_stats, sizeof(StatsOut) * p->max_pairs));
+  CREATE_CHK(hipMalloc((void**)&c->d_active, sizeof(int)));
+  CREATE_CHK(hipHostMalloc((void**)&c->h_active, sizeof(int)));
+#undef CREATE_CHK
+  *out = c;
+  return UWT_OK;
+}
+
+int uwt_destroy(uwt_ctx* c) {
+  if (!c) return UWT_ERR_INVALID_ARG;
+  (void)hipSetDevice(c->p.device);
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  for (int l = 0; l < UWT_MAX_LEVELS; l++) {
+    if (c->img[l]) (void)hipFree(c->img[l]);
+    if (c->depth[l]) (void)hipFree(c->depth[l]);
+    if (c->gx[l]) (void)hipFree(c->gx[l]);
+    if (c->gy[l]) (void)hipFree(c->gy[l]);
+  }
+  if (c->state) (void)hipFree(c->state);
+  if (c->d_ref) (void)hipFree(c->d_ref);
+  if (c->d_tgt) (void)hipFree(c->d_tgt);
+  if (c->partials) (void)hipFree(c->partials);
+  if (c->d_poses) (void)hipFree(c->d_poses);
+  if (c->d_stats) (void)hipFree(c->d_stats);
+  if (c->d_active) (void)hipFree(c->d_active);
+  if (c->h_active) (void)hipHostFree(c->h_active);
+  if (c->scratch) (void)hipFree(c->scratch);
+  for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+  return UWT_OK;
+}
+
+int uwt_level_info(const uwt_ctx* c, int32_t lvl, uwt_level* out) {
+  if (!c || !out || lvl < 0 || lvl >= c->p.n_levels) return UWT_ERR_INVALID_ARG;
+  *out = c->info[lvl];
+  return UWT_OK;
+}
+
+int uwt_set_frame(uwt_ctx* c, int32_t slot, const uint8_t* gray, size_t row_stride, const uint16_t* depth,
+                  size_t depth_row_stride) {
+  if (!c || !gray || !slot_range_ok(c, slot, 1)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: bad slot/pointer");
+  const int w = c->p.width, h = c->p.height;
+  if (row_stride < (size_t)w) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: row stride < width");
+  HIPCHK(c, hipMemcpy2DAsync(c->img[0] + (size_t)slot * w * h, w, gray, row_stride, w, h, hipMemcpyHostToDevice, c->stream));
+  if (c->p.has_depth) {
+    if (!depth || depth_row_stride < (size_t)w * 2) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: depth required");
+    HIPCHK(c, hipMemcpy2DAsync(c->depth[0] + (size_t)slot * w * h, (size_t)w * 2, depth, depth_row_stride, (size_t)w * 2, h,
+                               hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
+int uwt_upload_frames(uwt_ctx* c, int32_t first_slot, int32_t n, const uint8_t* gray, const uint16_t* depth) {
+  if (!c || !gray || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_upload_frames: bad range");
+  const size_t px = (size_t)c->p.width * c->p.height;
+  HIPCHK(c, hipMemcpyAsync(c->img[0] + first_slot * px, gray, px * n, hipMemcpyHostToDevice, c->stream));
+  if (c->p.has_depth) {
+    if (!depth) return fail(c, UWT_ERR_INVALID_ARG, "uwt_upload_frames: depth required");
+    HIPCHK(c, hipMemcpyAsync(c->depth[0] + first_slot * px, depth, px * n * 2, hipMemcpyHostToDevice, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
+static int plane_ptr(uwt_ctx* c, int slot, int lvl, int plane, void** out, size_t* bytes) {
+  if (!c || !out || !slot_range_ok(c, slot, 1) || lvl < 0 || lvl >= c->p.n_levels) return UWT_ERR_INVALID_ARG;
+  const size_t n = c->lv[lvl].n;
+  switch (plane) {
+    case UWT_PLANE_IMAGE: *out = c->img[lvl] + slot * n; *bytes = n; break;
+    case UWT_PLANE_DEPTH:
+      if (!c->p.has_depth) return UWT_ERR_INVALID_ARG;
+      *out = c->depth[lvl] + slot * n; *bytes = n * 2; break;
+    case UWT_PLANE_GRADX: *out = c->gx[lvl] + slot * n; *bytes = n * 2; break;
+    case UWT_PLANE_GRADY: *out = c->gy[lvl] + slot * n; *bytes = n * 2; break;
+    default: return UWT_ERR_INVALID_ARG;
+  }
+  return UWT_OK;
+}
+
+int uwt_plane_device_ptr(uwt_ctx* c, int32_t slot, int32_t lvl, int32_t plane, void** out) {
+  size_t bytes;
+  int st = plane_ptr(c, slot, lvl, plane, out, &bytes);
+  return st ? fail(c, st, "uwt_plane_device_ptr: bad slot/level/plane") : UWT_OK;
+}
+
+int uwt_get_plane(uwt_ctx* c, int32_t slot, int32_t lvl, int32_t plane, void* host_out) {
+  void* d;
+  size_t bytes;
+  int st = plane_ptr(c, slot, lvl, plane, &d, &bytes);
+  if (st || !host_out) return fail(c, UWT_ERR_INVALID_ARG, "uwt_get_plane: bad slot/level/plane");
+  HIPCHK(c, hipMemcpyAsync(host_out, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
+static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n) {
+  for (int l = 1; l < c->p.n_levels; l++) {
+    const size_t ns = c->lv[l - 1].n, nd = c->lv[l].n;
+    int st = launch_halve<uint8_t>(c, c->img[l - 1] + first_slot * ns, c->img[l] + first_slot * nd, c->lv[l].w, c->lv[l].h, ns, nd, n);
+    if (st) return st;
+    if (c->p.has_depth) {
+      st = launch_halve<uint16_t>(c, c->depth[l - 1] + first_slot * ns, c->depth[l] + first_slot * nd, c->lv[l].w, c->lv[l].h, ns, nd, n);
+      if (st) return st;
+    }
+  }
+  return UWT_OK;
+}
+
+static int enqueue_gradients(uwt_ctx* c, int first_slot, int n) {
+  for (int l = 0; l < c->p.n_levels; l++) {
+    const size_t nl = c->lv[l].n;
+    int st = launch_scharr(c, c->img[l] + first_slot * nl, c->gx[l] + first_slot * nl, c->gy[l] + first_slot * nl, c->lv[l].w,
+                           c->lv[l].h, nl, n);
+    if (st) return st;
+  }
+  return UWT_OK;
+}
+
+int uwt_build_pyramids(uwt_ctx* c, int32_t first_slot, int32_t n) {
+  if (!c || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_build_pyramids: bad range");
+  int st = enqueue_pyramids(c, first_slot, n);
+  if (st) return st;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
+int uwt_apply_gradient(uwt_ctx* c, int32_t first_slot, int32_t n) {
+  if (!c || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_apply_gradient: bad range");
+  int st = enqueue_gradients(c, first_slot, n);
+  if (st) return st;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
+int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
+                            float* poses_out, uwt_stats* stats_out) {
+  if (!c || !poses_out) return fail(c, UWT_ERR_INVALID_ARG, "uwt_estimate_pose_batch: null argument");
+  int st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
+  if (st) return st;
+  st = enqueue_estimate(c, n_pairs, c->d_poses, c->d_stats);
+  if (st) return st;
+  HIPCHK(c, hipMemcpyAsync(poses_out, c->d_poses, sizeof(float) * 7 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+  std::vector<uwt_stats> tmp(n_pairs);
+  HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_stats, sizeof(uwt_stats) * n_pairs, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->profiling) {
+    st = prof_collect(c);
+    if (st) return st;
+  }
+  int worst = UWT_OK;
+  for (int i = 0; i < n_pairs; i++) {
+    if (stats_out) stats_out[i] = tmp[i];
+    if (tmp[i].status != UWT_OK && worst == UWT_OK) worst = tmp[i].status;
+  }
+  if (worst) return fail(c, worst, "uwt_estimate_pose_batch: at least one pair failed (see stats)");
+  return UWT_OK;
+}
+
+int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only, int32_t n_pairs,
+                          const int32_t* ref_slots, const int32_t* tgt_slots, float* d_poses_out, uwt_stats* d_stats_out) {
+  if (!c || !d_poses_out || !slot_range_ok(c, first_slot, n_frames))
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_track_batch_async: bad argument");
+  (void)grad_refs_only;  // gradients are cheap next to the GN loop; all prepared frames get them (ApplyGradient on both frames, src/System.cpp:197-213)
+  int st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
+  if (st) return st;
+  st = enqueue_pyramids(c, first_slot, n_frames);
+  if (st) return st;
+  st = enqueue_gradients(c, first_slot, n_frames);
+  if (st) return st;
+  return enqueue_estimate(c, n_pairs, d_poses_out, reinterpret_cast<StatsOut*>(d_stats_out));
+}
+
+int uwt_sync(uwt_ctx* c) {
+  if (!c) return UWT_ERR_INVALID_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (c->profiling) return prof_collect(c);
+  return UWT_OK;
+}
+
+int uwt_stream(uwt_ctx* c, void** out) {
+  if (!c || !out) return UWT_ERR_INVALID_ARG;
+  *out = (void*)c->stream;
+  return UWT_OK;
+}
+
+int uwt_profile_enable(uwt_ctx* c, int32_t on) {
+  if (!c) return UWT_ERR_INVALID_ARG;
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->ev_used = 0;
+  c->profiling = on != 0;
+  c->prof_ms = 0.0;
+  c->prof_launches = 0;
+  c->prof_pixels = 0;
+  return UWT_OK;
+}
+
+int uwt_profile_read(uwt_ctx* c, double* ms_total, int64_t* launches, int64_t* pixels) {
+  if (!c) return UWT_ERR_INVALID_ARG;
+  if (ms_total) *ms_total = c->prof_ms;
+  if (launches) *launches = c->prof_launches;
+  if (pixels) *pixels = c->prof_pixels;
+  return UWT_OK;
+}
+
+/* ---- per-stage entry points ---------------------------------------------------------------------------------- */
+
+int uwt_halve_u8(uwt_ctx* c, const uint8_t* src, int32_t w, int32_t h, uint8_t* dst) {
+  if (!c || !src || !dst || w < 2 || h < 2 || (w & 1) || (h & 1)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_halve_u8");
+  const size_t ns = (size_t)w * h, nd = ns / 4, off = (ns + 255) & ~(size_t)255;
+  int st = ensure_scratch(c, off + nd);
+  if (st) return st;
+  uint8_t* d = (uint8_t*)c->scratch;
+  HIPCHK(c, hipMemcpyAsync(d, src, ns, hipMemcpyHostToDevice, c->stream));
+  st = launch_halve<uint8_t>(c, d, d + off, w / 2, h / 2, ns, nd, 1);
+  if (st) return st;
+  HIPCHK(c, hipMemcpyAsync(dst, d + off, nd, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
+int uwt_halve_u16(uwt_ctx* c, const uint16_t* src, int32_t w, int32_t h, uint16_t* dst) {
+  if (!c || !src || !dst || w < 2 || h < 2 || (w & 1) || (h & 1)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_halve_u16");
+  const size_t ns = (size_t)w * h, nd = ns / 4, off = (ns * 2 + 255) & ~(size_t)255;
+  int st = ensure_scratch(c, off + nd * 2);
+  if (st) return st;
+  uint8_t* d = (uint8_t*)c->scratch;
+  HIPCHK(c, hipMemcpyAsync(d, src, ns * 2, hipMemcpyHostToDevice, c->stream));
+  st = launch_halve<uint16_t>(c, (uint16_t*)d, (uint16_t*)(d + off), w / 2, h / 2, ns, nd, 1);
+  if (st) return st;
+  HIPCHK(c, hipMemcpyAsync(dst, d + off, nd * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
+int uwt_scharr3(uwt_ctx* c, const uint8_t* src, int32_t w, int32_t h, int16_t* gx, int16_t* gy) {
+  if (!c || !src || !gx || !gy || w < 1 || h < 1) return fail(c, UWT_ERR_INVALID_ARG, "uwt_scharr3");
+  const size_t n = (size_t)w * h, off = (n + 255) & ~(size_t)255;
+  int st = ensure_scratch(c, off + n * 4);
+  if (st) return st;
+  uint8_t* d = (uint8_t*)c->scratch;
+  int16_t* dgx = (int16_t*)(d + off);
+  int16_t* dgy = dgx + n;
+  HIPCHK(c, hipMemcpyAsync(d, src, n, hipMemcpyHostToDevice, c->stream));
+  st = launch_scharr(c, d, dgx, dgy, w, h, n, 1);
+  if (st) return st;
+  HIPCHK(c, hipMemcpyAsync(gx, dgx, n * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(gy, dgy, n * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
+int uwt_warp(uwt_ctx* c, int32_t lvl, const float* pts, int32_t n, const float pose[7], float* warped_out) {
+  if (!c || !pts || !pose || !warped_out || n < 1 || lvl < 0 || lvl >= c->p.n_levels)
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_warp");
+  const size_t bytes = sizeof(float) * 4 * (size_t)n;
+  int st = ensure_scratch(c, bytes * 2);
+  if (st) return st;
+  float4* din = (float4*)c->scratch;
+  float4* dout = din + n;
+  HIPCHK(c, hipMemcpyAsync(din, pts, bytes, hipMemcpyHostToDevice, c->stream));
+  Pose P;
+  for (int k = 0; k < 4; k++) P.q[k] = pose[k];
+  for (int k = 0; k < 3; k++) P.t[k] = pose[4 + k];
+  hipLaunchKernelGGL(k_warp_table, dim3((n + 255) / 256), dim3(256), 0, c->stream, din, dout, n, P, c->lv[lvl]);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(warped_out, dout, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
+int uwt_residual_jacobian(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, int32_t lvl, const float pose[7],
+                          uwt_accum* acc_out, float* J_out, float* r_out, uint8_t* valid_out) {
+  if (!c || !pose || !acc_out || lvl < 0 || lvl >= c->p.n_levels || !slot_range_ok(c, ref_slot, 1) || !slot_range_ok(c, tgt_slot, 1))
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_residual_jacobian");
+  int st = upload_pairs(c, 1, &ref_slot, &tgt_slot);
+  if (st) return st;
+  const size_t n = c->lv[lvl].n;
+  const bool dump = J_out || r_out || valid_out;
+  if (dump) {
+    st = ensure_scratch(c, n * (6 * 4 + 4 + 1) + 512);
+    if (st) return st;
+  }
+  ResidualArgs a = residual_args(c, lvl);
+  a.state = nullptr;
+  for (int k = 0; k < 4; k++) a.pose.q[k] = pose[k];
+  for (int k = 0; k < 3; k++) a.pose.t[k] = pose[4 + k];
+  if (dump) {
+    a.dumpJ = (float*)c->scratch;
+    a.dumpR = a.dumpJ + 6 * n;
+    a.dumpV = (uint8_t*)(a.dumpR + n);
+  }
+  st = launch_residual(c, a, 1, dump);
+  if (st) return st;
+  std::vector<uint32_t> recs((size_t)a.slices * kRecWords);
+  HIPCHK(c, hipMemcpyAsync(recs.data(), c->partials, recs.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  if (J_out) HIPCHK(c, hipMemcpyAsync(J_out, a.dumpJ, n * 24, hipMemcpyDeviceToHost, c->stream));
+  if (r_out) HIPCHK(c, hipMemcpyAsync(r_out, a.dumpR, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (valid_out) HIPCHK(c, hipMemcpyAsync(valid_out, a.dumpV, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memset(acc_out, 0, sizeof(*acc_out));
+  for (int s = 0; s < a.slices; s++) {  // same slice-ordered f64 fold as k_gn_update
+    const uint32_t* r = recs.data() + (size_t)s * kRecWords;
+    for (int k = 0; k < 21; k++) { float f; std::memcpy(&f, r + k, 4); acc_out->A[k] += (double)f; }
+    for (int k = 0; k < 6; k++) { float f; std::memcpy(&f, r + 21 + k, 4); acc_out->jtr[k] += (double)f; }
+    acc_out->n_valid += (int32_t)r[27];
+    acc_out->sum_r2 += (int64_t)(((uint64_t)r[29] << 32) | r[28]);
+  }
+  return UWT_OK;
+}
+
+int uwt_ls_accumulate(uwt_ctx* c, const float* J, const float* r, const float* w, int32_t n, int32_t divide, float A[36],
+                      float b[6], float* error, int32_t* num_constraints) {
+  if (!c || !J || !r || !A || !b || !error || !num_constraints || n < 0) return fail(c, UWT_ERR_INVALID_ARG, "uwt_ls_accumulate");
+  const int blocks = n == 0 ? 1 : std::min(1024, (n + kBlock - 1) / kBlock);
+  const size_t fl = (size_t)n * 8 + (size_t)blocks * 28 + 64;
+  int st = ensure_scratch(c, fl * 4);
+  if (st) return st;
+  float* dJ = (float*)c->scratch;
+  float* dr = dJ + (size_t)n * 6;
+  float* dw = dr + n;
+  float* dp = dw + n;
+  if (n) {
+    HIPCHK(c, hipMemcpyAsync(dJ, J, sizeof(float) * 6 * n, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dr, r, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    if (w) HIPCHK(c, hipMemcpyAsync(dw, w, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+  }
+  hipLaunchKernelGGL(k_ls_accumulate, dim3(blocks), dim3(kBlock), 0, c->stream, dJ, dr, w ? dw : nullptr, n, dp);
+  HIPCHK(c, hipGetLastError());
+  std::vector<float> parts((size_t)blocks * 28);
+  HIPCHK(c, hipMemcpyAsync(parts.data(), dp, parts.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  double s[28] = {0};
+  for (int bl = 0; bl < blocks; bl++)
+    for (int k = 0; k < 28; k++) s[k] += (double)parts[(size_t)bl * 28 + k];
+  int q = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++, q++) { A[6 * i + j] = (float)s[q]; A[6 * j + i] = (float)s[q]; }
+  for (int i = 0; i < 6; i++) b[i] = (float)(-s[21 + i]);  // LS stores b = -Σ w r J (src/LeastSquares.cpp:206)
+  *error = (float)s[27];
+  *num_constraints = n;  // one per LS::update call (:208)
+  if (divide) {          // LS::finish (:141-146)
+    const float nf = (float)n;
+    for (int i = 0; i < 36; i++) A[i] = A[i] / nf;
+    for (int i = 0; i < 6; i++) b[i] = b[i] / nf;
+    *error = *error / nf;
+  }
+  return UWT_OK;
+}
+
+int uwt_se3_exp(uwt_ctx* c, const float xi[6], float pose_out[7]) {
+  if (!xi || !pose_out) return UWT_ERR_INVALID_ARG;
+  return run_se3_op(c, 0, xi, 6, nullptr, 0, pose_out, 7, nullptr);
+}
+
+int uwt_se3_mul(uwt_ctx* c, const float a[7], const float b[7], float out[7]) {
+  if (!a || !b || !out) return UWT_ERR_INVALID_ARG;
+  return run_se3_op(c, 1, a, 7, b, 7, out, 7, nullptr);
+}
+
+int uwt_se3_matrix(uwt_ctx* c, const float pose[7], float T_out[16]) {
+  if (!pose || !T_out) return UWT_ERR_INVALID_ARG;
+  return run_se3_op(c, 2, pose, 7, nullptr, 0, T_out, 16, nullptr);
+}
+
+int uwt_se3_handoff(uwt_ctx* c, float pose[7], int32_t scale_t) {
+  if (!pose) return UWT_ERR_INVALID_ARG;
+  float out[7];
+  int flag = 1;
+  int st = run_se3_op(c, scale_t ? 4 : 3, pose, 7, nullptr, 0, out, 7, &flag);
+  if (st) return st;
+  if (!flag) return fail(c, UWT_ERR_INVALID_ARG, "uwt_se3_handoff: quaternion close to zero (SOPHUS_ENSURE)");
+  std::memcpy(pose, out, sizeof(out));
+  return UWT_OK;
+}
+
+int uwt_solve_delta(uwt_ctx* c, const float A[36], const float b[6], float delta_out[6], float* Ainv_out, int32_t* nonsingular) {
+  if (!A || !b || !delta_out) return UWT_ERR_INVALID_ARG;
+  float out[42];
+  int flag = 0;
+  int st = run_se3_op(c, 5, A, 36, b, 6, out, 42, &flag);
+  if (st) return st;
+  std::memcpy(delta_out, out, 6 * sizeof(float));
+  if (Ainv_out) std::memcpy(Ainv_out, out + 6, 36 * sizeof(float));
+  if (nonsingular) *nonsingular = flag;
+  return UWT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,591 @@
+// uwt_kernels.h — gfx950 kernels of the direct SE(3) tracking path.
+//
+//   k_halve_*      System::AddFrame pyramid loop            (src/System.cpp:246-251)
+//   k_scharr3      Tracker::ApplyGradient                   (src/Tracker.cpp:1133-1134)
+//   k_residual     WarpFunction + per-point loop + the 28-accumulator LS reduction, fused
+//                  (src/Tracker.cpp:1417-1471, 432-490; src/LeastSquares.cpp:148-209)
+//   k_gn_update    error / exit test / normal equations / solve / pose update (src/Tracker.cpp:495-574)
+//   k_level_end    level hand-off                           (src/Tracker.cpp:580-590)
+//
+// Memory-bound integer/float stencil + gather + reduction work: no MFMA.  Wave = 64 lanes, blocks of 256.
+// Build with -ffp-contract=off: the per-pixel float sequence is part of the contract (every FMA is explicit).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "uwt_math.h"
+
+namespace uwt {
+
+constexpr int kBlock = 256;
+constexpr int kAccFloats = 27;   // 21 upper-triangle JᵀJ + 6 Jᵀr
+constexpr int kRecWords = 32;    // one partial record: 27 f32, n_valid u32, Σr² u64, 2 pad words (128 B)
+
+struct LevelK {
+  int w, h, n;
+  float fx, fy, cx, cy, invfx, invfy;
+  float zscale;     // depth_scale / 2^lvl (src/Tracker.cpp:1266)
+  uint32_t magic;   // ceil(2^32 / w): idx / w == umulhi(idx, magic) for idx * w < 2^32
+};
+
+struct PairState {
+  Pose pose;
+  float last_error;
+  float error;
+  int level_done;
+  int status;
+  int iters;
+  int n_valid;
+};
+
+// ------------------------------------------------------------------------------------------------------------
+// pyramid: 2x2 mean with round-half-up == cv::resize(.., 0.5, 0.5) on u8 / u16 (src/System.cpp:247, 249)
+// One thread produces VEC horizontally adjacent outputs from two 2·VEC-wide input row segments.
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int VEC>
+__global__ __launch_bounds__(kBlock) void k_halve(const T* __restrict__ src, T* __restrict__ dst, int w_out, int h_out,
+                                                  size_t src_frame_stride, size_t dst_frame_stride) {
+  const int groups_per_row = w_out / VEC;
+  const int g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= groups_per_row * h_out) return;
+  const int y = g / groups_per_row;
+  const int x = (g - y * groups_per_row) * VEC;
+  const T* s0 = src + (size_t)blockIdx.y * src_frame_stride + (size_t)(2 * y) * (2 * w_out) + 2 * x;
+  const T* s1 = s0 + 2 * w_out;
+  T* d = dst + (size_t)blockIdx.y * dst_frame_stride + (size_t)y * w_out + x;
+  T a[2 * VEC], b[2 * VEC], o[VEC];
+  if constexpr (VEC == 4 && sizeof(T) == 1) {
+    *reinterpret_cast<uint2*>(a) = *reinterpret_cast<const uint2*>(s0);
+    *reinterpret_cast<uint2*>(b) = *reinterpret_cast<const uint2*>(s1);
+  } else if constexpr (VEC == 4 && sizeof(T) == 2) {
+    *reinterpret_cast<uint4*>(a) = *reinterpret_cast<const uint4*>(s0);
+    *reinterpret_cast<uint4*>(b) = *reinterpret_cast<const uint4*>(s1);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2 * VEC; i++) { a[i] = s0[i]; b[i] = s1[i]; }
+  }
+#pragma unroll
+  for (int i = 0; i < VEC; i++)
+    o[i] = (T)(((uint32_t)a[2 * i] + (uint32_t)a[2 * i + 1] + (uint32_t)b[2 * i] + (uint32_t)b[2 * i + 1] + 2u) >> 2);
+  if constexpr (VEC == 4 && sizeof(T) == 1) {
+    *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<uint32_t*>(o);
+  } else if constexpr (VEC == 4 && sizeof(T) == 2) {
+    *reinterpret_cast<uint2*>(d) = *reinterpret_cast<uint2*>(o);
+  } else {
+#pragma unroll
+    for (int i = 0; i < VEC; i++) d[i] = o[i];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// gradients: 3 x Scharr, reflect-101 border, exact in int (src/Tracker.cpp:1133-1134).
+// A 64x16 output tile per block; the (64+2)x(16+2) u8 source patch is staged in LDS once, every output then
+// reads its 8 neighbours from LDS.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kGradTW = 64, kGradTH = 16;
+
+__device__ inline int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  if (i < 0) i = -i;
+  if (i >= n) i = 2 * (n - 1) - i;
+  return i;
+}
+
+__global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
+                                                    int16_t* __restrict__ gy, int w, int h, size_t frame_stride) {
+  __shared__ uint8_t tile[kGradTH + 2][kGradTW + 4];
+  const int tiles_x = (w + kGradTW - 1) / kGradTW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int x0 = tx * kGradTW, y0 = ty * kGradTH;
+  const uint8_t* img = src + (size_t)blockIdx.y * frame_stride;
+  for (int i = threadIdx.x; i < (kGradTH + 2) * (kGradTW + 2); i += kBlock) {
+    const int ly = i / (kGradTW + 2), lx = i - ly * (kGradTW + 2);
+    const int sy = reflect101(min(y0 + ly - 1, h), h), sx = reflect101(min(x0 + lx - 1, w), w);
+    tile[ly][lx] = img[(size_t)sy * w + sx];
+  }
+  __syncthreads();
+  const int lx = threadIdx.x & (kGradTW - 1);
+#pragma unroll
+  for (int r = 0; r < kGradTH / (kBlock / kGradTW); r++) {
+    const int ly = (threadIdx.x / kGradTW) + r * (kBlock / kGradTW);
+    const int x = x0 + lx, y = y0 + ly;
+    if (x < w && y < h) {
+      const int a = tile[ly][lx], b = tile[ly][lx + 1], c = tile[ly][lx + 2];
+      const int d = tile[ly + 1][lx], f = tile[ly + 1][lx + 2];
+      const int g = tile[ly + 2][lx], hh = tile[ly + 2][lx + 1], k = tile[ly + 2][lx + 2];
+      const int sx = 3 * (3 * (c - a) + 10 * (f - d) + 3 * (k - g));
+      const int sy = 3 * (3 * (g - a) + 10 * (hh - b) + 3 * (k - c));
+      const size_t o = (size_t)blockIdx.y * frame_stride + (size_t)y * w + x;
+      gx[o] = (int16_t)sx;  // |s| <= 48*255*... = 12240 < 32767: never saturates
+      gy[o] = (int16_t)sy;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per-pixel terms: WarpFunction (src/Tracker.cpp:1439-1467) + validity / Jw / residual / Jl·Jw (:447-479).
+// Float op order is the contract (mirrors oracle S1): small products are k-sequential FMA chains, everything
+// else separate mul/add, divisions correctly rounded.
+// ------------------------------------------------------------------------------------------------------------
+struct WarpK {
+  float T[12];
+};
+
+__device__ __forceinline__ void warp_point(const LevelK& L, const WarpK& K, float xf, float yf, float z, float& u,
+                                           float& v, float& zp) {
+  float X = (xf - L.cx) * L.invfx;
+  X = X * z;
+  float Y = (yf - L.cy) * L.invfy;
+  Y = Y * z;
+  float xp = K.T[0] * X;
+  xp = __builtin_fmaf(K.T[1], Y, xp);
+  xp = __builtin_fmaf(K.T[2], z, xp);
+  xp = xp + K.T[3];  // fma(T03, w = 1, xp)
+  float yp = K.T[4] * X;
+  yp = __builtin_fmaf(K.T[5], Y, yp);
+  yp = __builtin_fmaf(K.T[6], z, yp);
+  yp = yp + K.T[7];
+  zp = K.T[8] * X;
+  zp = __builtin_fmaf(K.T[9], Y, zp);
+  zp = __builtin_fmaf(K.T[10], z, zp);
+  zp = zp + K.T[11];
+  u = xp * L.fx;
+  u = u / zp;
+  u = u + L.cx;
+  v = yp * L.fy;
+  v = v / zp;
+  v = v + L.cy;
+}
+
+__device__ __forceinline__ int round_pos(float x) {  // C round() for x > 0
+  const float t = truncf(x);
+  return (int)t + ((x - t) >= 0.5f ? 1 : 0);
+}
+
+template <bool UNIT_FACTORS>
+__device__ __forceinline__ bool pixel_terms(const LevelK& L, const WarpK& K, float zf, float af, float xf, float yf,
+                                            float z, const uint8_t* __restrict__ I2, int i1, int gxi, int gyi,
+                                            float J[6], int& ri) {
+  float x2, y2, z2;
+  warp_point(L, K, xf, yf, z, x2, y2, z2);
+  float iz = 1.0f / z2;
+  const bool valid = (y2 > 0.f) && (y2 < (float)L.h) && (x2 > 0.f) && (x2 < (float)L.w) && (z2 != 0.f);
+  if (!valid) return false;
+  if (iz < 0.f) iz = 0.f;
+  const float fx = L.fx, fy = L.fy;
+  float a0 = fx * iz;
+  float a2 = -(((fx * x2) * iz) * iz);
+  float a3 = -((((fx * x2) * y2) * iz) * iz);
+  float a4 = fx * (1.0f + ((x2 * x2) * iz) * iz);
+  float a5 = ((-fx) * y2) * iz;
+  float b1 = fy * iz;
+  float b2 = -(((fy * y2) * iz) * iz);
+  float b3 = -(fy * (1.0f + ((y2 * y2) * iz) * iz));
+  float b4 = (((fy * x2) * y2) * iz) * iz;
+  float b5 = (fy * x2) * iz;
+  if constexpr (!UNIT_FACTORS) {
+    a2 = a2 * zf; a3 = a3 * af; a4 = a4 * af; a5 = a5 * af;
+    b2 = b2 * zf; b3 = b3 * af; b4 = b4 * af; b5 = b5 * af;
+  }
+  int ix2 = round_pos(x2), iy2 = round_pos(y2);
+  ix2 = min(ix2, L.w - 1);  // reference reads one past the edge here (src/Tracker.cpp:450,472); clamp
+  iy2 = min(iy2, L.h - 1);
+  const int i2 = I2[iy2 * L.w + ix2];
+  ri = i2 - i1;
+  const float g0 = (float)gxi, g1 = (float)gyi;
+  J[0] = g0 * a0;                                   // fma(g1, 0, g0*a0)
+  J[1] = g1 * b1;                                   // fma(g1, b1, g0*0)
+  J[2] = __builtin_fmaf(g1, b2, g0 * a2);
+  J[3] = __builtin_fmaf(g1, b3, g0 * a3);
+  J[4] = __builtin_fmaf(g1, b4, g0 * a4);
+  J[5] = __builtin_fmaf(g1, b5, g0 * a5);
+  return true;
+}
+
+__device__ __forceinline__ void accumulate(float acc[kAccFloats], const float J[6], float r) {
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++, s++) acc[s] = __builtin_fmaf(J[i], J[j], acc[s]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) acc[21 + i] = __builtin_fmaf(J[i], r, acc[21 + i]);
+}
+
+// Deterministic block reduction of the per-thread accumulators through LDS (fixed order, no atomics):
+// stage 1 transposes 29 rows x 256 threads into LDS; stage 2: 232 threads each fold 32 columns, 29 threads
+// fold the 8 segment sums.  Writes one 128-B record.
+__device__ __forceinline__ void block_reduce_store(const float acc[kAccFloats], uint32_t sum_r2, uint32_t n_valid,
+                                                   uint32_t* __restrict__ rec) {
+  __shared__ uint32_t red[29][kBlock];
+  __shared__ float seg_f[kAccFloats][8];
+  __shared__ unsigned long long seg_u[2][8];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int v = 0; v < kAccFloats; v++) red[v][tid] = __float_as_uint(acc[v]);
+  red[27][tid] = n_valid;
+  red[28][tid] = sum_r2;
+  __syncthreads();
+  if (tid < 29 * 8) {
+    const int v = tid >> 3, seg = tid & 7;
+    if (v < kAccFloats) {
+      float s = 0.f;
+#pragma unroll 8
+      for (int j = 0; j < 32; j++) s += __uint_as_float(red[v][seg * 32 + ((j + tid) & 31)]);
+      seg_f[v][seg] = s;
+    } else {
+      unsigned long long s = 0;
+#pragma unroll 8
+      for (int j = 0; j < 32; j++) s += red[v][seg * 32 + ((j + tid) & 31)];
+      seg_u[v - kAccFloats][seg] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < kAccFloats) {
+    float s = seg_f[tid][0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) s += seg_f[tid][k];
+    rec[tid] = __float_as_uint(s);
+  } else if (tid == 27) {
+    unsigned long long s = 0;
+    for (int k = 0; k < 8; k++) s += seg_u[0][k];
+    rec[27] = (uint32_t)s;
+  } else if (tid == 28) {
+    unsigned long long s = 0;
+    for (int k = 0; k < 8; k++) s += seg_u[1][k];
+    rec[28] = (uint32_t)(s & 0xffffffffu);
+    rec[29] = (uint32_t)(s >> 32);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_residual: one launch = one Gauss-Newton residual evaluation of one pyramid level for a whole batch.
+// grid = (slices, pairs); each block walks `groups_per_block` groups of VEC consecutive pixels of its pair's
+// reference level (implicit dense point table), gathers the target level, accumulates in registers and writes
+// one partial record.  Reference planes are read with one VEC-wide load per plane per group.
+// ------------------------------------------------------------------------------------------------------------
+struct ResidualArgs {
+  const uint8_t* img;       // level plane of all frame slots: [slot][n]
+  const int16_t* gx;
+  const int16_t* gy;
+  const uint16_t* depth;    // nullptr when !DEPTH
+  const int* ref_slots;
+  const int* tgt_slots;
+  const PairState* state;   // nullptr: use `pose` (per-stage entry point)
+  Pose pose;
+  LevelK L;
+  float zf, af;
+  int groups_per_block;
+  int slices;
+  uint32_t* partials;       // [pair][slice][kRecWords]
+  float* dumpJ;             // optional per-pixel dumps (DUMP only)
+  float* dumpR;
+  uint8_t* dumpV;
+};
+
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP>
+__global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
+  const int pair = blockIdx.y;
+  Pose pose;
+  if (a.state) {
+    const PairState st = a.state[pair];
+    if (st.level_done || st.status) return;
+    pose = st.pose;
+  } else {
+    pose = a.pose;
+  }
+  WarpK K;
+  pose_to_T12(pose, K.T);
+  const LevelK L = a.L;
+  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
+  const uint8_t* __restrict__ I1 = a.img + ref_off;
+  const uint8_t* __restrict__ I2 = a.img + tgt_off;
+  const int16_t* __restrict__ GX = a.gx + ref_off;
+  const int16_t* __restrict__ GY = a.gy + ref_off;
+  const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
+
+  float acc[kAccFloats];
+#pragma unroll
+  for (int i = 0; i < kAccFloats; i++) acc[i] = 0.f;
+  uint32_t sum_r2 = 0, n_valid = 0;
+
+  const int n_groups = L.n / VEC;
+  const int g_begin = blockIdx.x * a.groups_per_block;
+  const int g_end = min(g_begin + a.groups_per_block, n_groups);
+  for (int g = g_begin + threadIdx.x; g < g_end; g += kBlock) {
+    const uint32_t idx = (uint32_t)g * VEC;
+    const uint32_t y = __umulhi(idx, L.magic);
+    const uint32_t x = idx - y * L.w;
+    uint8_t i1[VEC];
+    int16_t gxv[VEC], gyv[VEC];
+    uint16_t dv[VEC];
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<uint32_t*>(i1) = *reinterpret_cast<const uint32_t*>(I1 + idx);
+      *reinterpret_cast<uint2*>(gxv) = *reinterpret_cast<const uint2*>(GX + idx);
+      *reinterpret_cast<uint2*>(gyv) = *reinterpret_cast<const uint2*>(GY + idx);
+      if constexpr (DEPTH) *reinterpret_cast<uint2*>(dv) = *reinterpret_cast<const uint2*>(DP + idx);
+    } else {
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        i1[j] = I1[idx + j]; gxv[j] = GX[idx + j]; gyv[j] = GY[idx + j];
+        if constexpr (DEPTH) dv[j] = DP[idx + j];
+      }
+    }
+    const float yf = (float)y;
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      float z = 1.0f;
+      bool ok = true;
+      if constexpr (DEPTH) {
+        const int d = (int)(int16_t)dv[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
+        ok = d > 0;
+        z = (float)d * L.zscale;
+      }
+      float J[6];
+      int ri = 0;
+      if (ok) ok = pixel_terms<UNIT_FACTORS>(L, K, a.zf, a.af, (float)(x + j), yf, z, I2, (int)i1[j], (int)gxv[j], (int)gyv[j], J, ri);
+      if (ok) {
+        accumulate(acc, J, (float)ri);
+        sum_r2 += (uint32_t)(ri * ri);
+        n_valid += 1;
+      }
+      if constexpr (DUMP) {
+        const size_t p = (size_t)pair * L.n + idx + j;
+        if (a.dumpV) a.dumpV[p] = ok ? 1 : 0;
+        if (a.dumpR) a.dumpR[p] = ok ? (float)ri : 0.f;
+        if (a.dumpJ)
+          for (int k = 0; k < 6; k++) a.dumpJ[p * 6 + k] = ok ? J[k] : 0.f;
+      }
+    }
+  }
+  block_reduce_store(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + blockIdx.x) * kRecWords);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_gn_update: one wave per pair.  Lanes 0..26 fold the block partials of one accumulator in slice order in
+// f64; lane 0 then runs the scalar tail of the iteration: error (src/Tracker.cpp:499-502), exit test (:508),
+// A/b (:554-561), A.inv()*b (:564), pose <- pose * exp(delta) (:574).
+// ------------------------------------------------------------------------------------------------------------
+struct UpdateArgs {
+  const uint32_t* partials;
+  PairState* state;
+  int slices;
+  int k;             // iteration index at this level
+  int max_iters;
+  int early_exit;
+  float epsilon;
+  float gain;
+  int* active;       // optional: counts the pairs still iterating after this update (early-exit polling)
+};
+
+__device__ inline void fold_partials(const uint32_t* __restrict__ recs, int slices, int lane, double& colsum,
+                                     long long& isum) {
+  colsum = 0.0;
+  isum = 0;
+  if (lane < kAccFloats) {
+    for (int s = 0; s < slices; s++) colsum += (double)__uint_as_float(recs[(size_t)s * kRecWords + lane]);
+  } else if (lane == 27) {
+    for (int s = 0; s < slices; s++) isum += recs[(size_t)s * kRecWords + 27];
+  } else if (lane == 28) {
+    for (int s = 0; s < slices; s++)
+      isum += (long long)(((unsigned long long)recs[(size_t)s * kRecWords + 29] << 32) | recs[(size_t)s * kRecWords + 28]);
+  }
+}
+
+__global__ __launch_bounds__(64) void k_gn_update(const UpdateArgs a) {
+  const int pair = blockIdx.x, lane = threadIdx.x;
+  PairState st = a.state[pair];
+  if (st.level_done || st.status) return;
+  __shared__ double sums[kAccFloats];
+  __shared__ long long isums[2];
+  double cs;
+  long long is;
+  fold_partials(a.partials + (size_t)pair * a.slices * kRecWords, a.slices, lane, cs, is);
+  if (lane < kAccFloats) sums[lane] = cs;
+  else if (lane < 29) isums[lane - 27] = is;
+  __syncthreads();
+  if (lane != 0) return;
+
+  const int n = (int)isums[0];
+  const long long sr2 = isums[1];
+  st.iters += 1;
+  st.n_valid = n;
+  if (n == 0) {
+    st.status = 2;  // UWT_ERR_NO_VALID_POINTS
+    st.level_done = 1;
+    a.state[pair] = st;
+    return;
+  }
+  const float inv_n = (float)(1.0 / (double)n);                 // src/Tracker.cpp:499
+  const float error = (float)((double)inv_n * (double)sr2);     // :501, scaled-gemm form
+  st.error = error;
+  if (a.early_exit &&
+      (error >= st.last_error || a.k == a.max_iters - 1 || fabsf(error - st.last_error) < a.epsilon)) {  // :508
+    st.level_done = 1;
+    a.state[pair] = st;
+    return;
+  }
+  st.last_error = error;  // :529
+  float A[36], b[6], delta[6];
+  int s = 0;
+  for (int i = 0; i < 6; i++)
+    for (int j = i; j < 6; j++, s++) {
+      const float v = (float)sums[s];
+      A[6 * i + j] = v;
+      A[6 * j + i] = v;
+    }
+  for (int i = 0; i < 6; i++) b[i] = (float)(-((double)a.gain * sums[21 + i]));  // :559-561
+  solve_delta(A, b, delta, nullptr);                                              // :564
+  Pose d, np;
+  se3_exp(delta, d);                                                              // :574
+  se3_mul(st.pose, d, np);
+  st.pose = np;
+  a.state[pair] = st;
+  if (a.active) atomicAdd(a.active, 1);
+}
+
+__global__ void k_init_state(PairState* state, int n, float initial_error) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  PairState st;
+  pose_identity(st.pose);  // src/Tracker.cpp:385
+  st.last_error = initial_error;
+  st.error = 0.f;
+  st.level_done = 0;
+  st.status = 0;
+  st.iters = 0;
+  st.n_valid = 0;
+  state[i] = st;
+}
+
+// end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
+__global__ void k_level_end(PairState* state, int n, int lvl, int scale_t, float initial_error) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  PairState st = state[i];
+  if (st.status == 0 && lvl != 0) {
+    if (!se3_handoff(st.pose, scale_t != 0)) st.status = 1;  // SOPHUS_ENSURE would abort
+  }
+  st.level_done = 0;
+  st.last_error = initial_error;
+  state[i] = st;
+}
+
+struct StatsOut { int status, iterations, n_valid; float error; };
+
+__global__ void k_write_out(const PairState* state, int n, float* poses, StatsOut* stats) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const PairState st = state[i];
+  for (int k = 0; k < 4; k++) poses[7 * i + k] = st.pose.q[k];
+  for (int k = 0; k < 3; k++) poses[7 * i + 4 + k] = st.pose.t[k];
+  if (stats) {
+    StatsOut o;
+    o.status = st.status; o.iterations = st.iters; o.n_valid = st.n_valid; o.error = st.error;
+    stats[i] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// per-stage helpers (parity entry points)
+// ------------------------------------------------------------------------------------------------------------
+
+// Tracker::WarpFunction on an explicit N x 4 point table (src/Tracker.cpp:1417-1471)
+__global__ void k_warp_table(const float4* __restrict__ pts, float4* __restrict__ out, int n, Pose pose, LevelK L) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float T[12];
+  pose_to_T12(pose, T);
+  const float4 p = pts[i];
+  float X = (p.x - L.cx) * L.invfx; X = X * p.z;
+  float Y = (p.y - L.cy) * L.invfy; Y = Y * p.z;
+  float o[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    float s = T[4 * k] * X;
+    s = __builtin_fmaf(T[4 * k + 1], Y, s);
+    s = __builtin_fmaf(T[4 * k + 2], p.z, s);
+    s = __builtin_fmaf(T[4 * k + 3], p.w, s);
+    o[k] = s;
+  }
+  float wq = 0.f * X;  // fourth row of the rigid matrix is (0 0 0 1)
+  wq = __builtin_fmaf(0.f, Y, wq);
+  wq = __builtin_fmaf(0.f, p.z, wq);
+  wq = __builtin_fmaf(1.f, p.w, wq);
+  float u = o[0] * L.fx; u = u / o[2]; u = u + L.cx;
+  float v = o[1] * L.fy; v = v / o[2]; v = v + L.cy;
+  u = u * wq;
+  v = v * wq;
+  out[i] = make_float4(u, v, o[2], wq);
+}
+
+// LS::update over n rows (src/LeastSquares.cpp:204-209) as a grid reduction: thread-sequential over a strided
+// subset, then the same deterministic block fold; weights enter as (J_i·J_j)·w, (r·w)·J_i, (r·r)·w.
+__global__ __launch_bounds__(kBlock) void k_ls_accumulate(const float* __restrict__ J, const float* __restrict__ r,
+                                                          const float* __restrict__ w, int n, float* partials) {
+  float acc[28];
+#pragma unroll
+  for (int i = 0; i < 28; i++) acc[i] = 0.f;
+  for (int p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
+    float Jr[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) Jr[k] = J[(size_t)p * 6 + k];
+    const float wi = w ? w[p] : 1.0f, ri = r[p];
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = i; j < 6; j++, s++) acc[s] += (Jr[i] * Jr[j]) * wi;
+    const float rw = ri * wi;
+#pragma unroll
+    for (int i = 0; i < 6; i++) acc[21 + i] += Jr[i] * rw;
+    acc[27] += ri * ri * wi;
+  }
+  __shared__ float red[28][kBlock];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int v = 0; v < 28; v++) red[v][tid] = acc[v];
+  __syncthreads();
+  if (tid < 28) {
+    double s = 0.0;
+    for (int j = 0; j < kBlock; j++) s += (double)red[tid][j];
+    partials[blockIdx.x * 28 + tid] = (float)s;
+  }
+}
+
+__global__ void k_se3_ops(int op, const float* in_a, const float* in_b, float* out, int* flag) {
+  if (threadIdx.x || blockIdx.x) return;
+  Pose a, b, o;
+  if (op == 0) {  // exp
+    se3_exp(in_a, o);
+    for (int k = 0; k < 4; k++) out[k] = o.q[k];
+    for (int k = 0; k < 3; k++) out[4 + k] = o.t[k];
+  } else if (op == 1) {  // mul
+    for (int k = 0; k < 4; k++) { a.q[k] = in_a[k]; b.q[k] = in_b[k]; }
+    for (int k = 0; k < 3; k++) { a.t[k] = in_a[4 + k]; b.t[k] = in_b[4 + k]; }
+    se3_mul(a, b, o);
+    for (int k = 0; k < 4; k++) out[k] = o.q[k];
+    for (int k = 0; k < 3; k++) out[4 + k] = o.t[k];
+  } else if (op == 2) {  // matrix
+    for (int k = 0; k < 4; k++) a.q[k] = in_a[k];
+    for (int k = 0; k < 3; k++) a.t[k] = in_a[4 + k];
+    float T[12];
+    pose_to_T12(a, T);
+    for (int k = 0; k < 12; k++) out[k] = T[k];
+    out[12] = 0.f; out[13] = 0.f; out[14] = 0.f; out[15] = 1.f;
+  } else if (op == 3 || op == 4) {  // handoff (4: also scale t)
+    for (int k = 0; k < 4; k++) a.q[k] = in_a[k];
+    for (int k = 0; k < 3; k++) a.t[k] = in_a[4 + k];
+    *flag = se3_handoff(a, op == 4) ? 1 : 0;
+    for (int k = 0; k < 4; k++) out[k] = a.q[k];
+    for (int k = 0; k < 3; k++) out[4 + k] = a.t[k];
+  } else if (op == 5) {  // solve: in_a = A(36), in_b = b(6); out = delta(6) + Ainv(36)
+    float d[6], Ai[36];
+    *flag = solve_delta(in_a, in_b, d, Ai) ? 1 : 0;
+    for (int k = 0; k < 6; k++) out[k] = d[k];
+    for (int k = 0; k < 36; k++) out[6 + k] = Ai[k];
+  }
+}
+
+}  // namespace uwt

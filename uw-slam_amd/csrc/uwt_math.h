@@ -1,0 +1,191 @@
+// uwt_math.h — device-side SE(3) / 6x6 solve used by the Gauss-Newton update kernel.
+//
+// Restates, for gfx950, the arithmetic the reference obtains from Sophus::SE3f / Eigen::Quaternionf and
+// cv::Mat::inv(): thirdparty/sophus/se3.hpp:253-268, 317-321, 723-744; so3.hpp:270-288, 338-354, 534-566;
+// src/Tracker.cpp:564, 574, 580-590.  All f32, no FMA contraction (build with -ffp-contract=off); sin/cos are
+// evaluated in f64 and rounded once so the result does not depend on a libm's f32 kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace uwt {
+
+struct Pose {  // unit quaternion (x y z w) + translation, the storage of Sophus::SE3f
+  float q[4];
+  float t[3];
+};
+
+__device__ inline float sin_r(float x) { return (float)sin((double)x); }
+__device__ inline float cos_r(float x) { return (float)cos((double)x); }
+
+__device__ inline void pose_identity(Pose& p) {
+  p.q[0] = 0.f; p.q[1] = 0.f; p.q[2] = 0.f; p.q[3] = 1.f;
+  p.t[0] = 0.f; p.t[1] = 0.f; p.t[2] = 0.f;
+}
+
+// Eigen Quaternion::toRotationMatrix, row-major 3x3 (so3.hpp:286-288)
+__device__ inline void quat_to_rot(const float q[4], float R[9]) {
+  const float x = q[0], y = q[1], z = q[2], w = q[3];
+  const float tx = 2.f * x, ty = 2.f * y, tz = 2.f * z;
+  const float twx = tx * w, twy = ty * w, twz = tz * w;
+  const float txx = tx * x, txy = ty * x, txz = tz * x;
+  const float tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  R[0] = 1.f - (tyy + tzz); R[1] = txy - twz;         R[2] = txz + twy;
+  R[3] = txy + twz;         R[4] = 1.f - (txx + tzz); R[5] = tyz - twx;
+  R[6] = txz - twy;         R[7] = tyz + twx;         R[8] = 1.f - (txx + tyy);
+}
+
+// SE3f::matrix3x4 (se3.hpp:263-268): rows of [R | t]
+__device__ inline void pose_to_T12(const Pose& p, float T[12]) {
+  float R[9];
+  quat_to_rot(p.q, R);
+  T[0] = R[0]; T[1] = R[1]; T[2] = R[2];  T[3] = p.t[0];
+  T[4] = R[3]; T[5] = R[4]; T[6] = R[5];  T[7] = p.t[1];
+  T[8] = R[6]; T[9] = R[7]; T[10] = R[8]; T[11] = p.t[2];
+}
+
+// Hamilton product, coefficient order x y z w (Eigen generic quat_product)
+__device__ inline void quat_mul(const float a[4], const float b[4], float o[4]) {
+  const float ax = a[0], ay = a[1], az = a[2], aw = a[3];
+  const float bx = b[0], by = b[1], bz = b[2], bw = b[3];
+  o[3] = aw * bw - ax * bx - ay * by - az * bz;
+  o[0] = aw * bx + ax * bw + ay * bz - az * by;
+  o[1] = aw * by + ay * bw + az * bx - ax * bz;
+  o[2] = aw * bz + az * bw + ax * by - ay * bx;
+}
+
+// QuaternionBase::_transformVector (so3.hpp:320-322)
+__device__ inline void quat_rotate(const float q[4], const float v[3], float o[3]) {
+  float ux = q[1] * v[2] - q[2] * v[1];
+  float uy = q[2] * v[0] - q[0] * v[2];
+  float uz = q[0] * v[1] - q[1] * v[0];
+  ux = ux + ux; uy = uy + uy; uz = uz + uz;
+  const float cx = q[1] * uz - q[2] * uy;
+  const float cy = q[2] * ux - q[0] * uz;
+  const float cz = q[0] * uy - q[1] * ux;
+  o[0] = (v[0] + q[3] * ux) + cx;
+  o[1] = (v[1] + q[3] * uy) + cy;
+  o[2] = (v[2] + q[3] * uz) + cz;
+}
+
+constexpr float kSophusEps = 1e-5f;  // Constants<float>::epsilon, common.hpp:154-158
+
+// SE3f::exp (se3.hpp:723-744) with SO3f::expAndTheta (so3.hpp:534-566); xi = [upsilon, omega]
+__device__ inline void se3_exp(const float xi[6], Pose& out) {
+  const float o0 = xi[3], o1 = xi[4], o2 = xi[5];
+  const float theta_sq = o0 * o0 + o1 * o1 + o2 * o2;
+  const float theta = sqrtf(theta_sq);
+  const float half_theta = 0.5f * theta;
+  float imag, real;
+  if (theta < kSophusEps) {
+    const float theta_po4 = theta_sq * theta_sq;
+    imag = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * theta_po4;
+    real = 1.f - (float)(1.0 / 8.0) * theta_sq + (float)(1.0 / 384.0) * theta_po4;
+  } else {
+    imag = sin_r(half_theta) / theta;
+    real = cos_r(half_theta);
+  }
+  out.q[0] = imag * o0; out.q[1] = imag * o1; out.q[2] = imag * o2; out.q[3] = real;
+
+  const float Om[9] = {0.f, -o2, o1, o2, 0.f, -o0, -o1, o0, 0.f};  // SO3::hat, so3.hpp:618-627
+  float V[9];
+  if (theta < kSophusEps) {
+    quat_to_rot(out.q, V);  // se3.hpp:734
+  } else {
+    float Om2[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = 0; j < 3; j++)
+        Om2[3 * i + j] = (Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j]) + Om[3 * i + 2] * Om[6 + j];
+    const float tsq = theta * theta;
+    const float c1 = (1.f - cos_r(theta)) / tsq;
+    const float c2 = (theta - sin_r(theta)) / (tsq * theta);
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const float id = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+      V[i] = (id + c1 * Om[i]) + c2 * Om2[i];
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) out.t[i] = (V[3 * i] * xi[0] + V[3 * i + 1] * xi[1]) + V[3 * i + 2] * xi[2];
+}
+
+// SE3f::operator*= (se3.hpp:317-321) and SO3f::operator*= with the 2/(1+|q|²) renormalisation (so3.hpp:338-354)
+__device__ inline void se3_mul(const Pose& a, const Pose& b, Pose& out) {
+  float rt[3];
+  quat_rotate(a.q, b.t, rt);
+  const float t0 = a.t[0] + rt[0], t1 = a.t[1] + rt[1], t2 = a.t[2] + rt[2];
+  float q[4];
+  quat_mul(a.q, b.q, q);
+  const float sn = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  if (sn != 1.f) {
+    const float s = 2.f / (1.f + sn);
+    q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
+  }
+  out.q[0] = q[0]; out.q[1] = q[1]; out.q[2] = q[2]; out.q[3] = q[3];
+  out.t[0] = t0; out.t[1] = t1; out.t[2] = t2;
+}
+
+// src/Tracker.cpp:580-590: q.xyz *= 2; SE3(q, t) re-normalises (so3.hpp:270-276). Returns false where
+// SOPHUS_ENSURE would abort (|q| < eps).
+__device__ inline bool se3_handoff(Pose& p, bool scale_t) {
+  const float x = p.q[0] * 2.f, y = p.q[1] * 2.f, z = p.q[2] * 2.f, w = p.q[3];
+  const float len = sqrtf(x * x + y * y + z * z + w * w);
+  if (!(len >= kSophusEps)) return false;
+  p.q[0] = x / len; p.q[1] = y / len; p.q[2] = z / len; p.q[3] = w / len;
+  if (scale_t) { p.t[0] *= 2.f; p.t[1] *= 2.f; p.t[2] *= 2.f; }
+  return true;
+}
+
+// cv::Mat::inv() (DECOMP_LU, CV_32F) as used at src/Tracker.cpp:564: Gaussian elimination with partial
+// pivoting, pivot threshold 10·FLT_EPSILON, singular ⇒ zero matrix.  Returns false when singular.
+__device__ inline bool inv6_lu(const float Ain[36], float X[36]) {
+  float A[36];
+  for (int i = 0; i < 36; i++) { A[i] = Ain[i]; X[i] = 0.f; }
+  for (int i = 0; i < 6; i++) X[7 * i] = 1.f;
+  const float eps = 1.1920929e-07f * 10;
+  for (int i = 0; i < 6; i++) {
+    int k = i;
+    for (int j = i + 1; j < 6; j++)
+      if (fabsf(A[j * 6 + i]) > fabsf(A[k * 6 + i])) k = j;
+    if (fabsf(A[k * 6 + i]) < eps) {
+      for (int q = 0; q < 36; q++) X[q] = 0.f;
+      return false;
+    }
+    if (k != i) {
+      for (int j = i; j < 6; j++) { const float t = A[i * 6 + j]; A[i * 6 + j] = A[k * 6 + j]; A[k * 6 + j] = t; }
+      for (int j = 0; j < 6; j++) { const float t = X[i * 6 + j]; X[i * 6 + j] = X[k * 6 + j]; X[k * 6 + j] = t; }
+    }
+    const float d = -1.f / A[i * 6 + i];
+    for (int j = i + 1; j < 6; j++) {
+      const float alpha = A[j * 6 + i] * d;
+      for (int q = i + 1; q < 6; q++) A[j * 6 + q] = A[j * 6 + q] + alpha * A[i * 6 + q];
+      for (int q = 0; q < 6; q++) X[j * 6 + q] = X[j * 6 + q] + alpha * X[i * 6 + q];
+    }
+    A[i * 6 + i] = -d;
+  }
+  for (int i = 5; i >= 0; i--)
+    for (int j = 0; j < 6; j++) {
+      float s = X[i * 6 + j];
+      for (int q = i + 1; q < 6; q++) s = s - A[i * 6 + q] * X[q * 6 + j];
+      X[i * 6 + j] = s * A[i * 6 + i];
+    }
+  return true;
+}
+
+// deltaMat = A.inv() * b (src/Tracker.cpp:564): the 6x6·6x1 product accumulates in f64 and rounds once.
+__device__ inline bool solve_delta(const float A[36], const float b[6], float delta[6], float* Ainv_out) {
+  float Ai[36];
+  const bool ok = inv6_lu(A, Ai);
+  for (int i = 0; i < 6; i++) {
+    double s = 0.0;
+    for (int j = 0; j < 6; j++) s += (double)Ai[6 * i + j] * (double)b[j];
+    delta[i] = (float)s;
+  }
+  if (Ainv_out)
+    for (int i = 0; i < 36; i++) Ainv_out[i] = Ai[i];
+  return ok;
+}
+
+}  // namespace uwt

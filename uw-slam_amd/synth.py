@@ -1,5 +1,5 @@
 """Deterministic synthetic frame pairs: band-limited noise textures re-rendered under a small
-random SE(3) for a fronto-parallel plane at depth z.  Host-side test/bench input only; no dependency on oracle/.
+random SE(3) for a fronto-parallel plane at depth z.  Host-side test/bench input only.
 """
 import numpy as np
 from scipy import ndimage

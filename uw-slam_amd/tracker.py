@@ -1,0 +1,131 @@
+"""Host-side mirror of the reference's Tracker / LS / Frame surface for the direct-tracking path, over the C ABI.
+
+Same method names, argument meaning and call order as include/Tracker.h:97-170, include/LeastSquares.h:31-45 and
+the Frame fields of include/System.h:85-100 that the path touches, so that System::Tracking()'s sequence
+(src/System.cpp:193-223) reads the same here:
+
+    tracker = Tracker(depth_available); tracker.InitializePyramid(w, h, K)
+    tracker.ApplyGradient(prev); tracker.ApplyGradient(cur)
+    tracker.ObtainAllPoints(prev)
+    tracker.EstimatePose(prev, cur)     # -> prev.rigid_transformation_
+
+Everything numeric happens in libuwt_hip.so; this file only moves buffers.  (The compiled-language mirror for C++
+callers is include/uw_tracker.hpp.)
+"""
+import numpy as np
+
+from . import capi
+
+PYRAMID_LEVELS = 5  # src/Options.cpp:26
+
+
+class Frame:
+    """include/System.h:63-103 — only the members the tracker reads or writes."""
+
+    def __init__(self, image, depth=None, id_frame=0):
+        self.idFrame_ = id_frame
+        self.images_ = [np.ascontiguousarray(image, np.uint8)]
+        self.depths_ = [np.ascontiguousarray(depth, np.uint16)] if depth is not None else []
+        self.depth_available_ = depth is not None
+        self.obtained_gradients_ = False
+        self.obtained_candidatePoints_ = False
+        self.rigid_transformation_ = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)  # qx qy qz qw tx ty tz
+        self._slot = None
+
+
+class Tracker:
+    """include/Tracker.h:90-170.  Solver constants are the locals of Tracker::EstimatePose (src/Tracker.cpp:364-372)
+    unless overridden through **params (the uwt_params fields)."""
+
+    def __init__(self, _depth_available=False, max_frames=16, device=0, **params):
+        self.depth_available_ = bool(_depth_available)
+        self._max_frames = max_frames
+        self._device = device
+        self._over = params
+        self._ctx = None
+        self._next_slot = 0
+
+    def InitializePyramid(self, _width, _height, _K):
+        K = np.asarray(_K, np.float32)
+        over = dict(n_levels=PYRAMID_LEVELS, max_frames=self._max_frames, max_pairs=max(1, self._max_frames // 2),
+                    has_depth=int(self.depth_available_), device=self._device)
+        over.update(self._over)
+        p = capi.default_params(int(_width), int(_height), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), **over)
+        self._ctx = capi.Context(p)
+        lv = [self._ctx.level_info(l) for l in range(p.n_levels)]
+        self.w_ = [L.w for L in lv]
+        self.h_ = [L.h for L in lv]
+        self.fx_ = [L.fx for L in lv]
+        self.fy_ = [L.fy for L in lv]
+        self.cx_ = [L.cx for L in lv]
+        self.cy_ = [L.cy for L in lv]
+        self.invfx_ = [L.invfx for L in lv]
+        self.invfy_ = [L.invfy for L in lv]
+
+    def InitializeMasks(self):
+        """src/Tracker.cpp:342-359 builds masks nothing reads; kept as a no-op for call-order compatibility."""
+
+    def _bind(self, frame):
+        """System::AddFrame's pyramid loop (src/System.cpp:246-251): upload level 0, build levels 1.. on the GPU."""
+        if frame._slot is None:
+            frame._slot = self._next_slot % self._max_frames
+            self._next_slot += 1
+            self._ctx.set_frame(frame._slot, frame.images_[0], frame.depths_[0] if self.depth_available_ else None)
+            self._ctx.build_pyramids(frame._slot, 1)
+        return frame._slot
+
+    def ApplyGradient(self, _frame):
+        slot = self._bind(_frame)
+        self._ctx.apply_gradient(slot, 1)
+        _frame.obtained_gradients_ = True
+
+    def ObtainAllPoints(self, _frame):
+        """src/Tracker.cpp:1259-1310.  The dense table is the pixel grid; the kernels derive (x, y, z, w) in
+        registers instead of materialising N x 4 floats."""
+        self._bind(_frame)
+        _frame.obtained_candidatePoints_ = True
+
+    def WarpFunction(self, _points2warp, _rigid_transformation, _lvl):
+        return self._ctx.warp(int(_lvl), _points2warp, _rigid_transformation)
+
+    def EstimatePose(self, _previous_frame, _current_frame):
+        if not _previous_frame.obtained_gradients_:
+            raise RuntimeError("ApplyGradient(previous_frame) must run before EstimatePose")  # reference: empty cv::Mat
+        a, b = self._bind(_previous_frame), self._bind(_current_frame)
+        poses, stats = self._ctx.estimate_pose_batch([a], [b], raise_on_pair_failure=True)
+        _previous_frame.rigid_transformation_ = poses[0]
+        return stats[0]
+
+    def GetFrameData(self, _frame, lvl, plane):
+        return self._ctx.get_plane(self._bind(_frame), lvl, plane)
+
+
+class LS:
+    """include/LeastSquares.h:26-50 over the GPU reduction: rows are buffered by update() and folded by finish()."""
+
+    def __init__(self, ctx):
+        self._ctx = ctx
+        self.initialize(0)
+
+    def initialize(self, max_num_constraints):
+        self._J, self._r, self._w = [], [], []
+        self.A = np.zeros((6, 6), np.float32)
+        self.b = np.zeros(6, np.float32)
+        self.error = 0.0
+        self.num_constraints = 0
+
+    def update(self, J, res, weight):
+        self._J.append(np.asarray(J, np.float32).reshape(6))
+        self._r.append(res)
+        self._w.append(weight)
+
+    def _fold(self, divide):
+        J = np.stack(self._J) if self._J else np.zeros((0, 6), np.float32)
+        self.A, self.b, self.error, self.num_constraints = self._ctx.ls_accumulate(
+            J, np.array(self._r, np.float32), np.array(self._w, np.float32), divide)
+
+    def finishNoDivide(self):
+        self._fold(False)
+
+    def finish(self):
+        self._fold(True)
