@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py — frame-pair alignments/s of the MI355X direct SE(3) tracking path (BASELINE.json metric).
+
+One "step" = one pass of the whole hot path over one resident batch: pyramids of every frame of the batch +
+gradients + the full coarse-to-fine Gauss-Newton alignment of every pair (levels 3..0 of a 4-level pyramid,
+10 iterations per level, no early exit), poses written to HBM.  N > 1: one process per GPU (torchrun), pairs sharded
+round-robin (pair i -> rank i mod N), one RCCL all_gather of the solved poses per step; weak scaling.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29500 \
+        bench.py --gpus 8 --steps 10 --warmup 3
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_PIXEL_ITER = 10          # I_ref 1 + gx 2 + gy 2 + z 4 + I_tgt 1
+HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=512, help="resident frame pairs per GPU")
+    ap.add_argument("--unique", type=int, default=16, help="distinct synthetic pairs generated per rank (tiled to --pairs)")
+    ap.add_argument("--width", type=int, default=640)
+    ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--levels", type=int, default=4)
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--acc", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--no-depth", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs timed on the CPU oracle (rank 0, N=1 only; 0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not bracket the residual kernel with HIP events")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    capi = importlib.import_module("uw-slam_amd.capi")
+    synth = importlib.import_module("uw-slam_amd.synth")
+    distm = importlib.import_module("uw-slam_amd.dist")
+
+    w, h, P = args.width, args.height, args.pairs
+    f = 525.0 * w / 640.0                                  # TUM-like intrinsics (calibrationTUM.xml:18-22), scaled
+    intr = (f, f, w / 2 - 0.5, h / 2 - 0.5)
+    has_depth = 0 if args.no_depth else 1
+    over = dict(n_levels=args.levels, first_level=args.levels - 1, last_level=0, max_iters=args.iters, early_exit=0,
+                has_depth=has_depth, accumulate_f64=1 if args.acc == "f64" else 0)
+    params = capi.default_params(w, h, *intr, max_frames=2 * P, max_pairs=P, device=local_rank, **over)
+    ctx = capi.Context(params)
+
+    # global pair ids owned by this rank: i mod N == rank (round-robin, BASELINE config 4)
+    my_pairs = distm.shard_round_robin(P * world, world, rank)
+    U = min(args.unique, P)
+    refs, tgts, deps = [], [], []
+    for u in range(U):
+        gid = int(my_pairs[u])
+        ref, tgt, dep, _, _ = synth.render_pair(w, h, *intr, seed=gid, z=0.8 + 0.4 * ((gid * 7) % 11) / 10.0,
+                                                with_depth=bool(has_depth))
+        refs.append(ref); tgts.append(tgt); deps.append(dep)
+    idx = np.arange(P) % U
+    frames = np.empty((2 * P, h, w), np.uint8)
+    frames[0::2] = np.stack(refs)[idx]
+    frames[1::2] = np.stack(tgts)[idx]
+    depth = None
+    if has_depth:
+        depth = np.empty((2 * P, h, w), np.uint16)
+        depth[0::2] = np.stack(deps)[idx]
+        depth[1::2] = depth[0::2]
+    ctx.upload_frames(0, frames, depth)                    # inputs resident in HBM before the timed region
+    del frames, depth
+    ref_slots = np.arange(P, dtype=np.int32) * 2
+    tgt_slots = ref_slots + 1
+
+    poses = torch.empty((P, 7), dtype=torch.float32, device=dev)
+    gathered = torch.empty((world * P, 7), dtype=torch.float32, device=dev) if world > 1 else None
+
+    def step():
+        ctx.track_batch_async(0, 2 * P, ref_slots, tgt_slots, poses.data_ptr())
+        if world > 1:
+            ctx.sync()                                     # the context stream is not torch's stream
+            dist.all_gather_into_tensor(gathered, poses)   # RCCL gather of the solved poses over xGMI
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile:
+        ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    res_ms, res_launches, res_pixels = ctx.profile_read() if not args.no_profile else (0.0, 0, 0)
+    ctx.profile_enable(False)
+
+    total_pairs = world * P * args.steps
+    value = total_pairs / dt
+    px_per_align = sum((w >> l) * (h >> l) for l in range(args.levels))
+    gpu_poses = poses.cpu().numpy()
+
+    out = {
+        "metric": "frame-pair alignments/sec (640x480, 4 pyr lvls)",
+        "value": round(value, 2),
+        "unit": "alignments/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32 (normal equations accumulated in %s)" % args.acc,
+        "data": "synthetic",
+        "config": {
+            "workload": "synthetic %dx%d pairs, %d pyramid levels (0..%d), %d GN iterations/level, no early exit, "
+                        "dense points%s, %d pairs resident per GPU (%d distinct), pyramids+gradients+alignment per step"
+                        % (w, h, args.levels, args.levels - 1, args.iters, ", u16 depth plane" if has_depth else ", z=1",
+                           P, U),
+            "pairs_per_gpu": P, "sharding": "round-robin pairs, RCCL all_gather of poses" if world > 1 else "single GPU",
+        },
+    }
+    if rank == 0:
+        if res_launches:
+            alg_bytes = ALG_BYTES_PER_PIXEL_ITER * res_pixels
+            achieved = alg_bytes / (res_ms * 1e-3) / 1e9
+            out["roofline"] = {
+                "bound": "hbm", "kernel": "k_residual (fused warp+residual+Jacobian+reduction)",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "launches": int(res_launches), "avg_launch_ms": round(res_ms / res_launches, 5),
+                "algorithmic_bytes_per_launch_avg": int(alg_bytes / res_launches),
+                "whole_job_effective_GBs": round(value / world * (ALG_BYTES_PER_PIXEL_ITER * px_per_align * args.iters
+                                                                  + 5 * px_per_align + 2.5 * px_per_align) / 1e9, 1),
+            }
+        if world == 1 and args.cpu_pairs > 0:
+            from oracle import oracle as O          # test infrastructure, used here only as the timed CPU baseline/checker
+            po = O.default_params(w, h, *intr, **{k: v for k, v in over.items() if k != "accumulate_f64"})
+            n_cpu = min(args.cpu_pairs, U)
+            t0 = time.perf_counter()
+            cpu_poses = []
+            for u in range(n_cpu):
+                st, pose, _ = O.align_pair(po, refs[u], tgts[u], deps[u] if has_depth else None)
+                cpu_poses.append(pose)
+            t_cpu = time.perf_counter() - t0
+            dr, dtr, bit = [], [], 0
+            for u in range(n_cpu):
+                a, b = gpu_poses[u].astype(np.float64), cpu_poses[u].astype(np.float64)
+                wv = abs(float(np.dot(a[:4], b[:4])))
+                v = b[3] * a[:3] - a[3] * b[:3] - np.cross(a[:3], b[:3])
+                dr.append(2.0 * np.arctan2(np.linalg.norm(v), wv))
+                dtr.append(float(np.linalg.norm(a[4:] - b[4:])))
+                bit += int(np.array_equal(gpu_poses[u].view(np.uint32), cpu_poses[u].view(np.uint32)))
+            out["cpu_baseline"] = {
+                "value": round(n_cpu / t_cpu, 4), "unit": "alignments/s", "cores": 1, "kind": "port",
+                "sample": "%d of the batch's distinct pairs through oracle/uwt_oracle.c (pyramid+gradients+EstimatePose), "
+                          "1 thread, %.1f s" % (n_cpu, t_cpu),
+            }
+            out["parity"] = {"pairs": n_cpu, "max_rot_rad": float(np.max(dr)), "max_trans_m": float(np.max(dtr)),
+                             "bit_identical_poses": bit, "tolerance": "1e-4 rad / 1e-4 m"}
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -28,7 +28,8 @@ enum uwt_status_code {
   UWT_ERR_NO_VALID_POINTS = 2, /* reference: cv::Exception from the empty Mat product, src/Tracker.cpp:501 */
   UWT_ERR_HIP = 3,
   UWT_ERR_NO_DEVICE = 4,
-  UWT_ERR_CAPACITY = 5
+  UWT_ERR_CAPACITY = 5,
+  UWT_ERR_PAIR_FAILED = 6      /* batch ran; at least one pair has a non-zero status in its uwt_stats */
 };
 
 enum uwt_plane { UWT_PLANE_IMAGE = 0, UWT_PLANE_DEPTH = 1, UWT_PLANE_GRADX = 2, UWT_PLANE_GRADY = 3 };
@@ -51,6 +52,8 @@ typedef struct uwt_params {
   int32_t early_exit;        /* 1: reference exit test src/Tracker.cpp:508; 0: exactly max_iters updates */
   int32_t has_depth;         /* Tracker(bool _depth_available)                                           */
   int32_t handoff_scale_t;   /* 0: EstimatePose (:580-590); 1: EstimatePoseFeatures (:856)               */
+  int32_t accumulate_f64;    /* 1 (default): JᵀJ/Jᵀr summed in f64 like cv::gemm on CV_32F (:560-561);  */
+                             /* 0: f32 per-thread partial sums (faster, not bit-reproducing the oracle)  */
   int32_t max_frames;        /* frame-slot capacity of the context                                       */
   int32_t max_pairs;         /* largest batch of pairs per call                                          */
   int32_t device;            /* HIP device ordinal                                                       */

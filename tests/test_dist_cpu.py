@@ -1,0 +1,62 @@
+"""world_size-2 gloo test of the pair sharding + pose gather used by the multi-GPU batched mode (no GPU needed:
+the per-rank 'solver' here is a stand-in that stamps each pose with its global pair id)."""
+import importlib
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_pairs, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = importlib.import_module("uw-slam_amd.dist")
+    ids = d.shard_round_robin(n_pairs, world, rank)
+    local = torch.zeros((len(ids), 7), dtype=torch.float32)
+    for k, gid in enumerate(ids):
+        local[k] = torch.arange(7, dtype=torch.float32) + 10.0 * gid
+    glob = d.gather_poses(local, n_pairs)
+    if rank == 0:
+        q.put(glob.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [8, 7, 1])
+def test_round_robin_shard_and_gather_world2(n_pairs):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_pairs, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    glob = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    expect = np.arange(7, dtype=np.float32)[None, :] + 10.0 * np.arange(n_pairs, dtype=np.float32)[:, None]
+    assert np.array_equal(glob, expect)
+
+
+def test_shard_partition_properties():
+    d = importlib.import_module("uw-slam_amd.dist")
+    for n, g in [(8192, 8), (10, 3), (5, 8)]:
+        ids = [d.shard_round_robin(n, g, r) for r in range(g)]
+        allid = np.sort(np.concatenate(ids))
+        assert np.array_equal(allid, np.arange(n))
+        assert d.shard_sizes(n, g) == [len(x) for x in ids]
+        assert all((x % g == r).all() for r, x in enumerate(ids))

@@ -1,0 +1,56 @@
+"""Pose-parity survey: GPU (C ABI) vs CPU oracle on N seeded synthetic pairs.  Prints the distribution of
+rotation / translation differences and the count of bit-identical poses."""
+import importlib, os, sys, time, argparse
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+capi = importlib.import_module("uw-slam_amd.capi")
+synth = importlib.import_module("uw-slam_amd.synth")
+from oracle import oracle as O
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=32)
+ap.add_argument("--w", type=int, default=160)
+ap.add_argument("--h", type=int, default=96)
+ap.add_argument("--mode", default="fixed")
+ap.add_argument("--depth", type=int, default=0)
+ap.add_argument("--seed0", type=int, default=1000)
+a = ap.parse_args()
+w, h = a.w, a.h
+f = 525.0 * w / 640.0
+intr = (f, f, w / 2 - 0.5, h / 2 - 0.5)
+if a.mode == "fixed":
+    over = dict(n_levels=4, first_level=3, last_level=0, max_iters=10, early_exit=0)
+else:
+    over = dict()
+if a.depth:
+    over["has_depth"] = 1
+n = a.n
+ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
+po = O.default_params(w, h, *intr, **over)
+frames, depths, cpu = [], [], []
+t0 = time.time()
+for s in range(n):
+    ref, tgt, dep, _, _ = synth.render_pair(w, h, *intr, seed=a.seed0 + s, z=1.0 + 0.2 * ((s % 5) - 2) / 2, with_depth=bool(a.depth))
+    frames += [ref, tgt]
+    if a.depth:
+        depths += [dep, dep]
+    st, pose, tr = O.align_pair(po, ref, tgt, dep if a.depth else None, want_trace=True)
+    cpu.append((st, pose, len(tr)))
+t_cpu = time.time() - t0
+ctx.upload_frames(0, np.stack(frames), np.stack(depths) if a.depth else None)
+ctx.build_pyramids(0, 2 * n); ctx.apply_gradient(0, 2 * n)
+poses, stats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1)
+def rot_angle(qa, qb):
+    qa, qb = qa.astype(np.float64), qb.astype(np.float64)
+    wv = abs(float(np.dot(qa, qb)))
+    v = qb[3] * qa[:3] - qa[3] * qb[:3] - np.cross(qa[:3], qb[:3])
+    return 2.0 * np.arctan2(np.linalg.norm(v), wv)
+dr = np.array([rot_angle(poses[i][:4], cpu[i][1][:4]) for i in range(n)])
+dt = np.array([np.linalg.norm(poses[i][4:].astype(np.float64) - cpu[i][1][4:]) for i in range(n)])
+bit = sum(np.array_equal(poses[i].view(np.uint32), cpu[i][1].view(np.uint32)) for i in range(n))
+it_eq = sum(stats[i]["iterations"] == cpu[i][2] for i in range(n))
+print("mode %s %dx%d depth=%d n=%d: bit-identical %d, iterations equal %d, status!=0 %d" % (a.mode, w, h, a.depth, n, bit, it_eq, sum(s["status"] != 0 for s in stats)))
+print("  rot  diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dr), np.percentile(dr, 90), dr.max(), (dr > 1e-4).sum()))
+print("  trans diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dt), np.percentile(dt, 90), dt.max(), (dt > 1e-4).sum()))
+print("  |t| median %.2e ; cpu time/pair %.3fs" % (np.median([np.linalg.norm(c[1][4:]) for c in cpu]), t_cpu / n))

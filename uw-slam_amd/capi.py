@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libuwt_hip.so")
 
-OK, ERR_INVALID_ARG, ERR_NO_VALID_POINTS, ERR_HIP, ERR_NO_DEVICE, ERR_CAPACITY = range(6)
+OK, ERR_INVALID_ARG, ERR_NO_VALID_POINTS, ERR_HIP, ERR_NO_DEVICE, ERR_CAPACITY, ERR_PAIR_FAILED = range(7)
 PLANE_IMAGE, PLANE_DEPTH, PLANE_GRADX, PLANE_GRADY = range(4)
 MAX_LEVELS = 8
 
@@ -23,7 +23,7 @@ class Params(C.Structure):
         ("epsilon", C.c_float), ("gain", C.c_float), ("z_factor", C.c_float), ("angle_factor", C.c_float),
         ("depth_scale", C.c_float), ("initial_error", C.c_float),
         ("early_exit", C.c_int32), ("has_depth", C.c_int32), ("handoff_scale_t", C.c_int32),
-        ("max_frames", C.c_int32), ("max_pairs", C.c_int32), ("device", C.c_int32),
+        ("accumulate_f64", C.c_int32), ("max_frames", C.c_int32), ("max_pairs", C.c_int32), ("device", C.c_int32),
     ]
 
 
@@ -169,7 +169,7 @@ class Context:
         poses = np.empty((n, 7), np.float32)
         stats = (Stats * n)()
         st = lib().uwt_estimate_pose_batch(self._h, n, _p(ref, C.c_int32), _p(tgt, C.c_int32), _p(poses, C.c_float), stats)
-        self._chk(st, allow=() if raise_on_pair_failure else (ERR_NO_VALID_POINTS, ERR_INVALID_ARG))
+        self._chk(st, allow=() if raise_on_pair_failure else (ERR_PAIR_FAILED,))
         return poses, [dict(status=s.status, iterations=s.iterations, n_valid=s.n_valid, error=s.error) for s in stats]
 
     def track_batch_async(self, first_slot, n_frames, ref_slots, tgt_slots, d_poses_ptr, d_stats_ptr=None):

@@ -50,7 +50,7 @@ struct uwt_ctx {
 
 namespace {
 
-constexpr int kGroupsPerThread = 4;  // x VEC pixels per thread per launch (fixed ⇒ results independent of batch size)
+constexpr int kGroupsPerThread = 8;  // x VEC pixels per thread per launch (fixed ⇒ results independent of batch size)
 
 int fail(uwt_ctx* c, int code, const std::string& msg) {
   if (c) c->last_error = msg;
@@ -128,8 +128,11 @@ int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int 
 }
 
 template <int VEC, bool DEPTH, bool UNIT, bool DUMP>
-void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs) {
-  hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64) {
+  if (acc64)
+    hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, double>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+  else
+    hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, float>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
 }
 
 int launch_residual(uwt_ctx* c, const ResidualArgs& a, int n_pairs, bool dump) {
@@ -137,23 +140,24 @@ int launch_residual(uwt_ctx* c, const ResidualArgs& a, int n_pairs, bool dump) {
   const bool unit = (a.zf == 1.0f && a.af == 1.0f);
   const int key = (c->vec == 4 ? 8 : 0) | (depth ? 4 : 0) | (unit ? 2 : 0) | (dump ? 1 : 0);
   hipStream_t s = c->stream;
+  const bool acc64 = c->p.accumulate_f64 != 0;
   switch (key) {
-    case 0: launch_residual_t<1, false, false, false>(s, a, n_pairs); break;
-    case 1: launch_residual_t<1, false, false, true>(s, a, n_pairs); break;
-    case 2: launch_residual_t<1, false, true, false>(s, a, n_pairs); break;
-    case 3: launch_residual_t<1, false, true, true>(s, a, n_pairs); break;
-    case 4: launch_residual_t<1, true, false, false>(s, a, n_pairs); break;
-    case 5: launch_residual_t<1, true, false, true>(s, a, n_pairs); break;
-    case 6: launch_residual_t<1, true, true, false>(s, a, n_pairs); break;
-    case 7: launch_residual_t<1, true, true, true>(s, a, n_pairs); break;
-    case 8: launch_residual_t<4, false, false, false>(s, a, n_pairs); break;
-    case 9: launch_residual_t<4, false, false, true>(s, a, n_pairs); break;
-    case 10: launch_residual_t<4, false, true, false>(s, a, n_pairs); break;
-    case 11: launch_residual_t<4, false, true, true>(s, a, n_pairs); break;
-    case 12: launch_residual_t<4, true, false, false>(s, a, n_pairs); break;
-    case 13: launch_residual_t<4, true, false, true>(s, a, n_pairs); break;
-    case 14: launch_residual_t<4, true, true, false>(s, a, n_pairs); break;
-    default: launch_residual_t<4, true, true, true>(s, a, n_pairs); break;
+    case 0: launch_residual_t<1, false, false, false>(s, a, n_pairs, acc64); break;
+    case 1: launch_residual_t<1, false, false, true>(s, a, n_pairs, acc64); break;
+    case 2: launch_residual_t<1, false, true, false>(s, a, n_pairs, acc64); break;
+    case 3: launch_residual_t<1, false, true, true>(s, a, n_pairs, acc64); break;
+    case 4: launch_residual_t<1, true, false, false>(s, a, n_pairs, acc64); break;
+    case 5: launch_residual_t<1, true, false, true>(s, a, n_pairs, acc64); break;
+    case 6: launch_residual_t<1, true, true, false>(s, a, n_pairs, acc64); break;
+    case 7: launch_residual_t<1, true, true, true>(s, a, n_pairs, acc64); break;
+    case 8: launch_residual_t<4, false, false, false>(s, a, n_pairs, acc64); break;
+    case 9: launch_residual_t<4, false, false, true>(s, a, n_pairs, acc64); break;
+    case 10: launch_residual_t<4, false, true, false>(s, a, n_pairs, acc64); break;
+    case 11: launch_residual_t<4, false, true, true>(s, a, n_pairs, acc64); break;
+    case 12: launch_residual_t<4, true, false, false>(s, a, n_pairs, acc64); break;
+    case 13: launch_residual_t<4, true, false, true>(s, a, n_pairs, acc64); break;
+    case 14: launch_residual_t<4, true, true, false>(s, a, n_pairs, acc64); break;
+    default: launch_residual_t<4, true, true, true>(s, a, n_pairs, acc64); break;
   }
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
@@ -299,6 +303,7 @@ const char* uwt_status_string(int status) {
     case UWT_ERR_HIP: return "HIP error";
     case UWT_ERR_NO_DEVICE: return "no gfx950 device";
     case UWT_ERR_CAPACITY: return "capacity exceeded";
+    case UWT_ERR_PAIR_FAILED: return "at least one pair failed";
     default: return "unknown status";
   }
 }
@@ -323,6 +328,7 @@ int uwt_default_params(uwt_params* p, int32_t width, int32_t height, float fx, f
   p->early_exit = 1;
   p->has_depth = 0;
   p->handoff_scale_t = 0;
+  p->accumulate_f64 = 1;
   p->max_frames = 2;
   p->max_pairs = 1;
   p->device = 0;
@@ -539,7 +545,9 @@ int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slot
     if (stats_out) stats_out[i] = tmp[i];
     if (tmp[i].status != UWT_OK && worst == UWT_OK) worst = tmp[i].status;
   }
-  if (worst) return fail(c, worst, "uwt_estimate_pose_batch: at least one pair failed (see stats)");
+  if (worst)
+    return fail(c, UWT_ERR_PAIR_FAILED, std::string("uwt_estimate_pose_batch: at least one pair failed, first status: ") +
+                                            uwt_status_string(worst));
   return UWT_OK;
 }
 
@@ -687,10 +695,14 @@ int uwt_residual_jacobian(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, int32_
   std::memset(acc_out, 0, sizeof(*acc_out));
   for (int s = 0; s < a.slices; s++) {  // same slice-ordered f64 fold as k_gn_update
     const uint32_t* r = recs.data() + (size_t)s * kRecWords;
-    for (int k = 0; k < 21; k++) { float f; std::memcpy(&f, r + k, 4); acc_out->A[k] += (double)f; }
-    for (int k = 0; k < 6; k++) { float f; std::memcpy(&f, r + 21 + k, 4); acc_out->jtr[k] += (double)f; }
-    acc_out->n_valid += (int32_t)r[27];
-    acc_out->sum_r2 += (int64_t)(((uint64_t)r[29] << 32) | r[28]);
+    double d[27];
+    std::memcpy(d, r, sizeof(d));
+    for (int k = 0; k < 21; k++) acc_out->A[k] += d[k];
+    for (int k = 0; k < 6; k++) acc_out->jtr[k] += d[21 + k];
+    acc_out->n_valid += (int32_t)r[54];
+    int64_t sr2;
+    std::memcpy(&sr2, r + 56, 8);
+    acc_out->sum_r2 += sr2;
   }
   return UWT_OK;
 }

@@ -20,7 +20,7 @@ namespace uwt {
 
 constexpr int kBlock = 256;
 constexpr int kAccFloats = 27;   // 21 upper-triangle JᵀJ + 6 Jᵀr
-constexpr int kRecWords = 32;    // one partial record: 27 f32, n_valid u32, Σr² u64, 2 pad words (128 B)
+constexpr int kRecWords = 64;    // one partial record (256 B): 27 f64 | n_valid u32 @ word 54 | Σr² u64 @ words 56-57
 
 struct LevelK {
   int w, h, n;
@@ -203,6 +203,8 @@ __device__ __forceinline__ bool pixel_terms(const LevelK& L, const WarpK& K, flo
   return true;
 }
 
+// Accumulator type: double reproduces the reference's double-accumulating gemm (src/Tracker.cpp:560-561) to the
+// last bit of the f32 result in practice (products of two f32 are exact in f64); float is the cheaper variant.
 __device__ __forceinline__ void accumulate(float acc[kAccFloats], const float J[6], float r) {
   int s = 0;
 #pragma unroll
@@ -213,49 +215,72 @@ __device__ __forceinline__ void accumulate(float acc[kAccFloats], const float J[
   for (int i = 0; i < 6; i++) acc[21 + i] = __builtin_fmaf(J[i], r, acc[21 + i]);
 }
 
-// Deterministic block reduction of the per-thread accumulators through LDS (fixed order, no atomics):
-// stage 1 transposes 29 rows x 256 threads into LDS; stage 2: 232 threads each fold 32 columns, 29 threads
-// fold the 8 segment sums.  Writes one 128-B record.
-__device__ __forceinline__ void block_reduce_store(const float acc[kAccFloats], uint32_t sum_r2, uint32_t n_valid,
+__device__ __forceinline__ void accumulate(double acc[kAccFloats], const float J[6], float r) {
+  double Jd[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) Jd[i] = (double)J[i];
+  const double rd = (double)r;
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++, s++) acc[s] = __builtin_fma(Jd[i], Jd[j], acc[s]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) acc[21 + i] = __builtin_fma(Jd[i], rd, acc[21 + i]);
+}
+
+// Deterministic block reduction of the per-thread accumulators through LDS (fixed order, no atomics).
+// Threads accumulate a handful of pixels in f32; from here on every sum is f64 so that the totals are, to ~1e-9,
+// the exact sums the reference's double-accumulating gemm produces (src/Tracker.cpp:560-561).
+// Stage 1 transposes 29 rows x 256 threads into LDS; stage 2: 232 threads each fold 32 columns; stage 3: 29
+// threads fold the 8 segment sums and write the 256-B record.
+template <typename AccT>
+__device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], uint32_t sum_r2, uint32_t n_valid,
                                                    uint32_t* __restrict__ rec) {
-  __shared__ uint32_t red[29][kBlock];
-  __shared__ float seg_f[kAccFloats][8];
+  constexpr int kPass = 14;  // accumulators per LDS pass (2 passes; keeps the f64 image under 29 KB per block)
+  __shared__ AccT red[kPass][kBlock];
+  __shared__ uint32_t redi[2][kBlock];
+  __shared__ double seg_f[kAccFloats][8];
   __shared__ unsigned long long seg_u[2][8];
   const int tid = threadIdx.x;
+  const int v = tid >> 3, seg = tid & 7;
+  redi[0][tid] = n_valid;
+  redi[1][tid] = sum_r2;
 #pragma unroll
-  for (int v = 0; v < kAccFloats; v++) red[v][tid] = __float_as_uint(acc[v]);
-  red[27][tid] = n_valid;
-  red[28][tid] = sum_r2;
-  __syncthreads();
-  if (tid < 29 * 8) {
-    const int v = tid >> 3, seg = tid & 7;
-    if (v < kAccFloats) {
-      float s = 0.f;
+  for (int pass = 0; pass < 2; pass++) {
+    const int base = pass * kPass;
+    const int cnt = pass == 0 ? kPass : kAccFloats - kPass;
+    if (pass) __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPass; i++)
+      if (i < cnt) red[i][tid] = acc[base + i];
+    __syncthreads();
+    if (v < cnt) {
+      double s = 0.0;
 #pragma unroll 8
-      for (int j = 0; j < 32; j++) s += __uint_as_float(red[v][seg * 32 + ((j + tid) & 31)]);
-      seg_f[v][seg] = s;
-    } else {
+      for (int j = 0; j < 32; j++) s += (double)red[v][seg * 32 + ((j + tid) & 31)];
+      seg_f[base + v][seg] = s;
+    } else if (pass == 0 && v >= kPass && v < kPass + 2) {
       unsigned long long s = 0;
 #pragma unroll 8
-      for (int j = 0; j < 32; j++) s += red[v][seg * 32 + ((j + tid) & 31)];
-      seg_u[v - kAccFloats][seg] = s;
+      for (int j = 0; j < 32; j++) s += redi[v - kPass][seg * 32 + ((j + tid) & 31)];
+      seg_u[v - kPass][seg] = s;
     }
   }
   __syncthreads();
   if (tid < kAccFloats) {
-    float s = seg_f[tid][0];
+    double s = seg_f[tid][0];
 #pragma unroll
     for (int k = 1; k < 8; k++) s += seg_f[tid][k];
-    rec[tid] = __float_as_uint(s);
+    reinterpret_cast<double*>(rec)[tid] = s;
   } else if (tid == 27) {
     unsigned long long s = 0;
     for (int k = 0; k < 8; k++) s += seg_u[0][k];
-    rec[27] = (uint32_t)s;
+    rec[54] = (uint32_t)s;
   } else if (tid == 28) {
     unsigned long long s = 0;
     for (int k = 0; k < 8; k++) s += seg_u[1][k];
-    rec[28] = (uint32_t)(s & 0xffffffffu);
-    rec[29] = (uint32_t)(s >> 32);
+    reinterpret_cast<unsigned long long*>(rec)[28] = s;
   }
 }
 
@@ -284,7 +309,7 @@ struct ResidualArgs {
   uint8_t* dumpV;
 };
 
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP>
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT>
 __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
   const int pair = blockIdx.y;
   Pose pose;
@@ -305,9 +330,9 @@ __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
   const int16_t* __restrict__ GY = a.gy + ref_off;
   const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
 
-  float acc[kAccFloats];
+  AccT acc[kAccFloats];
 #pragma unroll
-  for (int i = 0; i < kAccFloats; i++) acc[i] = 0.f;
+  for (int i = 0; i < kAccFloats; i++) acc[i] = (AccT)0;
   uint32_t sum_r2 = 0, n_valid = 0;
 
   const int n_groups = L.n / VEC;
@@ -359,7 +384,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
       }
     }
   }
-  block_reduce_store(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + blockIdx.x) * kRecWords);
+  block_reduce_store<AccT>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + blockIdx.x) * kRecWords);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -384,12 +409,11 @@ __device__ inline void fold_partials(const uint32_t* __restrict__ recs, int slic
   colsum = 0.0;
   isum = 0;
   if (lane < kAccFloats) {
-    for (int s = 0; s < slices; s++) colsum += (double)__uint_as_float(recs[(size_t)s * kRecWords + lane]);
+    for (int s = 0; s < slices; s++) colsum += reinterpret_cast<const double*>(recs + (size_t)s * kRecWords)[lane];
   } else if (lane == 27) {
-    for (int s = 0; s < slices; s++) isum += recs[(size_t)s * kRecWords + 27];
+    for (int s = 0; s < slices; s++) isum += recs[(size_t)s * kRecWords + 54];
   } else if (lane == 28) {
-    for (int s = 0; s < slices; s++)
-      isum += (long long)(((unsigned long long)recs[(size_t)s * kRecWords + 29] << 32) | recs[(size_t)s * kRecWords + 28]);
+    for (int s = 0; s < slices; s++) isum += reinterpret_cast<const long long*>(recs + (size_t)s * kRecWords)[28];
   }
 }
 
