@@ -132,8 +132,25 @@ struct WarpK {
   float T[12];
 };
 
+// Correctly rounded f32 quotients sharing one refined reciprocal of the common denominator: the same
+// rcp / Newton / two-residual-correction sequence hipcc emits for an IEEE `a / b`, minus the div_scale / div_fixup
+// range handling.  Bit-identical to `a / b` for normal-range operands and quotients; a zero, infinite or NaN
+// denominator yields NaN or infinity here as there, and such a pixel fails the bounds test either way.
+__device__ __forceinline__ float refined_rcp(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  const float e = __builtin_fmaf(-d, r, 1.0f);
+  return __builtin_fmaf(e, r, r);
+}
+__device__ __forceinline__ float div_by(float n, float d, float r) {
+  float q = n * r;
+  float e = __builtin_fmaf(-d, q, n);
+  q = __builtin_fmaf(e, r, q);
+  e = __builtin_fmaf(-d, q, n);
+  return __builtin_fmaf(e, r, q);
+}
+
 __device__ __forceinline__ void warp_point(const LevelK& L, const WarpK& K, float xf, float yf, float z, float& u,
-                                           float& v, float& zp) {
+                                           float& v, float& zp, float& iz) {
   float X = (xf - L.cx) * L.invfx;
   X = X * z;
   float Y = (yf - L.cy) * L.invfy;
@@ -150,12 +167,14 @@ __device__ __forceinline__ void warp_point(const LevelK& L, const WarpK& K, floa
   zp = __builtin_fmaf(K.T[9], Y, zp);
   zp = __builtin_fmaf(K.T[10], z, zp);
   zp = zp + K.T[11];
+  const float r = refined_rcp(zp);
   u = xp * L.fx;
-  u = u / zp;
+  u = div_by(u, zp, r);
   u = u + L.cx;
   v = yp * L.fy;
-  v = v / zp;
+  v = div_by(v, zp, r);
   v = v + L.cy;
+  iz = div_by(1.0f, zp, r);  // inv_z2 = 1 / z2 (src/Tracker.cpp:447)
 }
 
 __device__ __forceinline__ int round_pos(float x) {  // C round() for x > 0
@@ -167,9 +186,8 @@ template <bool UNIT_FACTORS>
 __device__ __forceinline__ bool pixel_terms(const LevelK& L, const WarpK& K, float zf, float af, float xf, float yf,
                                             float z, const uint8_t* __restrict__ I2, int i1, int gxi, int gyi,
                                             float J[6], int& ri) {
-  float x2, y2, z2;
-  warp_point(L, K, xf, yf, z, x2, y2, z2);
-  float iz = 1.0f / z2;
+  float x2, y2, z2, iz;
+  warp_point(L, K, xf, yf, z, x2, y2, z2, iz);
   const bool valid = (y2 > 0.f) && (y2 < (float)L.h) && (x2 > 0.f) && (x2 < (float)L.w) && (z2 != 0.f);
   if (!valid) return false;
   if (iz < 0.f) iz = 0.f;
