@@ -27,6 +27,11 @@ if ROOT not in sys.path:
 
 ALG_BYTES_PER_PIXEL_ITER = 10          # I_ref 1 + gx 2 + gy 2 + z 4 + I_tgt 1
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+# HBM traffic of k_residual from rocprofv3 PMC passes (profiles/r01/pmc_summary_bench_p512.csv): per launch, averaged over
+# the four levels, (2 x FETCH_SIZE + WRITE_SIZE) KiB = 2 x 204560.5 + 1664 KiB at 512 pairs (the x2 is the gfx950
+# FETCH_SIZE correction of MI355X_MICROARCH.md §HBM) -> bytes per pair per average launch.  Only valid for the default
+# workload (640x480, 4 levels, u16 depth plane); other configurations report null.
+TRAFFIC_BYTES_PER_PAIR_LAUNCH = (2 * 204560.5 + 1664.0) * 1024.0 / 512.0
 
 
 def main():
@@ -164,7 +169,9 @@ def main():
             out["roofline"] = {
                 "bound": "hbm", "kernel": "k_residual (fused warp+residual+Jacobian+reduction)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": (int(TRAFFIC_BYTES_PER_PAIR_LAUNCH * P) if (w, h, args.levels, has_depth) == (640, 480, 4, 1)
+                            else None),
                 "launches": int(res_launches), "avg_launch_ms": round(res_ms / res_launches, 5),
                 "algorithmic_bytes_per_launch_avg": int(alg_bytes / res_launches),
                 "whole_job_effective_GBs": round(value / world * (ALG_BYTES_PER_PIXEL_ITER * px_per_align * args.iters

@@ -1,0 +1,194 @@
+// uw_tracker.hpp — header-only C++ mirror of the reference's direct-tracking class surface over the C ABI (uwt.h).
+//
+// Same class / method names, argument meaning and call order as the reference's include/Tracker.h:90-170,
+// include/LeastSquares.h:26-50 and the Frame members of include/System.h:63-103 that the path touches, so that
+// System::InitializeSystem / System::Tracking (src/System.cpp:121-123, 193-223) read the same against this header:
+//
+//     tracker_ = new uw::Tracker(depth_available_);
+//     tracker_->InitializePyramid(w_, h_, K_);
+//     ...
+//     tracker_->ApplyGradient(previous_frame_);  tracker_->ApplyGradient(current_frame_);
+//     tracker_->ObtainAllPoints(previous_frame_);
+//     tracker_->EstimatePose(previous_frame_, current_frame_);   // -> previous_frame_->rigid_transformation_
+//
+// OpenCV / Eigen / Sophus are not required: images are passed as uw::ImageView (data, rows, cols, step — the four
+// cv::Mat fields the path reads); define UW_WITH_OPENCV before including to get the cv::Mat overloads.
+// Every numeric step runs in libuwt_hip.so on the GPU; a non-zero status becomes a std::runtime_error (the reference
+// surfaces misuse as cv::Exception / SOPHUS_ENSURE aborts).
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "uwt.h"
+
+#ifdef UW_WITH_OPENCV
+#include <opencv2/core.hpp>
+#endif
+
+namespace uw {
+
+constexpr int PYRAMID_LEVELS = 5;  // src/Options.cpp:26
+
+// Storage of Sophus::SE3f: unit quaternion (x y z w) + translation.
+struct SE3 {
+  float q[4] = {0.f, 0.f, 0.f, 1.f};
+  float t[3] = {0.f, 0.f, 0.f};
+  const float* data() const { return q; }  // 7 contiguous floats
+  float* data() { return q; }
+};
+static_assert(sizeof(SE3) == 7 * sizeof(float), "SE3 must be 7 packed floats");
+
+struct ImageView {
+  const void* data = nullptr;
+  int rows = 0, cols = 0;
+  size_t step = 0;  // bytes per row (cv::Mat::step)
+  ImageView() = default;
+  ImageView(const void* d, int r, int c, size_t s) : data(d), rows(r), cols(c), step(s) {}
+#ifdef UW_WITH_OPENCV
+  ImageView(const cv::Mat& m) : data(m.data), rows(m.rows), cols(m.cols), step(m.step) {}
+#endif
+};
+
+// include/System.h:63-103 — the members the tracker reads or writes.
+class Frame {
+ public:
+  int idFrame_ = 0;
+  ImageView image0_;   // images_[0], CV_8UC1
+  ImageView depth0_;   // depths_[0], CV_16UC1 (optional)
+  bool depth_available_ = false;
+  bool obtained_gradients_ = false;
+  bool obtained_candidatePoints_ = false;
+  SE3 rigid_transformation_;
+  int slot_ = -1;      // device frame slot once bound
+};
+
+class Tracker {
+ public:
+  // include/Tracker.h:97.  `overrides` lets a caller change the constants the reference hard-codes as locals of
+  // EstimatePose (src/Tracker.cpp:364-372); by default they are exactly those.
+  explicit Tracker(bool _depth_available, int max_frames = 16, int device = 0)
+      : depth_available_(_depth_available), max_frames_(max_frames), device_(device) {}
+  ~Tracker() {
+    if (ctx_) uwt_destroy(ctx_);
+  }
+  Tracker(const Tracker&) = delete;
+  Tracker& operator=(const Tracker&) = delete;
+
+  uwt_params& params() { return params_; }  // valid after InitializePyramid's defaults; edit before first use
+
+  // include/Tracker.h:112; K row-major 3x3 (fx 0 cx; 0 fy cy; 0 0 1)
+  void InitializePyramid(int _width, int _height, const float K[9]) {
+    check(uwt_default_params(&params_, _width, _height, K[0], K[4], K[2], K[5]), "uwt_default_params");
+    params_.n_levels = PYRAMID_LEVELS;
+    params_.has_depth = depth_available_ ? 1 : 0;
+    params_.max_frames = max_frames_;
+    params_.max_pairs = max_frames_ > 1 ? max_frames_ / 2 : 1;
+    params_.device = device_;
+  }
+#ifdef UW_WITH_OPENCV
+  void InitializePyramid(int _width, int _height, const cv::Mat& _K) {
+    const float K[9] = {_K.at<float>(0, 0), 0, _K.at<float>(0, 2), 0, _K.at<float>(1, 1), _K.at<float>(1, 2), 0, 0, 1};
+    InitializePyramid(_width, _height, K);
+  }
+#endif
+  void InitializeMasks() {}  // src/Tracker.cpp:342-359 builds masks nothing reads
+
+  void ApplyGradient(Frame* _frame) {  // include/Tracker.h:137
+    const int slot = bind(_frame);
+    check(uwt_apply_gradient(ctx(), slot, 1), "uwt_apply_gradient");
+    _frame->obtained_gradients_ = true;
+  }
+  void ObtainAllPoints(Frame* _frame) {  // include/Tracker.h:153 — the dense table is implicit on the GPU
+    bind(_frame);
+    _frame->obtained_candidatePoints_ = true;
+  }
+  // include/Tracker.h:170: N x 4 points in, N x 4 out
+  std::vector<float> WarpFunction(const std::vector<float>& _points2warp, const SE3& _rigid_transformation, int _lvl) {
+    std::vector<float> out(_points2warp.size());
+    check(uwt_warp(ctx(), _lvl, _points2warp.data(), (int)(_points2warp.size() / 4), _rigid_transformation.data(), out.data()),
+          "uwt_warp");
+    return out;
+  }
+  // include/Tracker.h:122
+  void EstimatePose(Frame* _previous_frame, Frame* _current_frame) {
+    if (!_previous_frame->obtained_gradients_) throw std::runtime_error("EstimatePose: ApplyGradient(previous) not called");
+    const int32_t a = bind(_previous_frame), b = bind(_current_frame);
+    check(uwt_estimate_pose_batch(ctx(), 1, &a, &b, _previous_frame->rigid_transformation_.data(), &last_stats_),
+          "uwt_estimate_pose_batch");
+  }
+  const uwt_stats& last_stats() const { return last_stats_; }
+  uwt_level level(int lvl) {  // w_/h_/fx_/fy_/cx_/cy_/invfx_/invfy_[lvl], include/Tracker.h:516-526
+    uwt_level L;
+    check(uwt_level_info(ctx(), lvl, &L), "uwt_level_info");
+    return L;
+  }
+  uwt_ctx* ctx() {
+    if (!ctx_) check(uwt_create(&params_, &ctx_), "uwt_create");
+    return ctx_;
+  }
+
+ private:
+  void check(int st, const char* what) {
+    if (st != UWT_OK)
+      throw std::runtime_error(std::string(what) + ": " + uwt_status_string(st) + (ctx_ ? std::string(" — ") + uwt_last_error(ctx_) : ""));
+  }
+  // System::AddFrame's pyramid loop (src/System.cpp:246-251): upload level 0, build the other levels on the GPU
+  int bind(Frame* f) {
+    if (f->slot_ < 0) {
+      f->slot_ = next_slot_++ % max_frames_;
+      check(uwt_set_frame(ctx(), f->slot_, (const uint8_t*)f->image0_.data, f->image0_.step,
+                          depth_available_ ? (const uint16_t*)f->depth0_.data : nullptr, f->depth0_.step),
+            "uwt_set_frame");
+      check(uwt_build_pyramids(ctx(), f->slot_, 1), "uwt_build_pyramids");
+    }
+    return f->slot_;
+  }
+  bool depth_available_;
+  int max_frames_, device_;
+  int next_slot_ = 0;
+  uwt_params params_{};
+  uwt_ctx* ctx_ = nullptr;
+  uwt_stats last_stats_{};
+};
+
+// include/LeastSquares.h:26-50.  update() buffers rows; finish*/() folds them on the GPU (uwt_ls_accumulate).
+// b keeps the reference's stored sign: b = -Σ w r J (src/LeastSquares.cpp:206).
+class LS {
+ public:
+  explicit LS(uwt_ctx* ctx) : ctx_(ctx) { initialize(0); }
+  float A[36];
+  float b[6];
+  float error;
+  int num_constraints;
+
+  void initialize(const int /*max_num_constraints*/) {
+    J_.clear(); r_.clear(); w_.clear();
+    std::memset(A, 0, sizeof(A));
+    std::memset(b, 0, sizeof(b));
+    error = 0.f;
+    num_constraints = 0;
+  }
+  void update(const float J[6], const float& res, const float& weight) {
+    J_.insert(J_.end(), J, J + 6);
+    r_.push_back(res);
+    w_.push_back(weight);
+  }
+  void finishNoDivide() { fold(0); }
+  void finish() { fold(1); }
+
+ private:
+  void fold(int divide) {
+    int32_t n = 0;
+    const int st = uwt_ls_accumulate(ctx_, J_.data(), r_.data(), w_.data(), (int)r_.size(), divide, A, b, &error, &n);
+    if (st != UWT_OK) throw std::runtime_error(std::string("uwt_ls_accumulate: ") + uwt_status_string(st));
+    num_constraints = n;
+  }
+  uwt_ctx* ctx_;
+  std::vector<float> J_, r_, w_;
+};
+
+}  // namespace uw

@@ -1,0 +1,47 @@
+"""The header-only C++ mirror (include/uw_tracker.hpp): compiles and links against libuwt_hip.so on CPU; on the GPU
+it runs System::Tracking()'s call sequence and must reproduce the oracle's pose."""
+import importlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "cpp", "shim_sequence")
+
+
+def build_exe():
+    importlib.import_module("uw-slam_amd").build_native()
+    libdir = os.path.join(ROOT, "uw-slam_amd")
+    src = os.path.join(ROOT, "tests", "cpp", "shim_sequence.cpp")
+    if os.path.exists(EXE) and os.path.getmtime(EXE) >= max(os.path.getmtime(src), os.path.getmtime(os.path.join(libdir, "libuwt_hip.so")),
+                                                          os.path.getmtime(os.path.join(ROOT, "include", "uw_tracker.hpp"))):
+        return EXE
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(ROOT, "include"), src, "-o", EXE,
+                           "-L", libdir, "-luwt_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    return EXE
+
+
+def test_shim_compiles_and_links():
+    assert os.path.exists(build_exe())
+
+
+@pytest.mark.gpu
+def test_shim_sequence_matches_oracle(O, synth, tmp_path):
+    exe = EXE if os.path.exists(EXE) else build_exe()
+    w, h = 160, 96
+    f = 525.0 * w / 640.0
+    ref, tgt, _, _, _ = synth.render_pair(w, h, f, f, w / 2 - 0.5, h / 2 - 0.5, seed=77)
+    raw = tmp_path / "pair.raw"
+    raw.write_bytes(ref.tobytes() + tgt.tobytes())
+    out = subprocess.run([exe, str(raw), str(w), str(h)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    vals = lines[0].split()
+    pose = np.array([float(v) for v in vals[:7]], np.float32)
+    st, pose_cpu, tr = O.align_pair(O.default_params(w, h, f, f, w / 2 - 0.5, h / 2 - 0.5), ref, tgt, want_trace=True)
+    assert st == 0 and int(vals[7]) == len(tr)
+    assert np.array_equal(pose, pose_cpu)
+    ls = lines[1].split()
+    assert ls[0] == "LS" and float(ls[1]) == 1.0 and float(ls[2]) == -3.0 and float(ls[3]) == 2.0 and int(ls[4]) == 1
