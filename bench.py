@@ -152,14 +152,14 @@ def main():
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
-        "dtype": "f32 (normal equations accumulated in %s)" % args.acc,
+        "dtype": "f32",
         "data": "synthetic",
         "config": {
             "workload": "synthetic %dx%d pairs, %d pyramid levels (0..%d), %d GN iterations/level, no early exit, "
                         "dense points%s, %d pairs resident per GPU (%d distinct), pyramids+gradients+alignment per step"
                         % (w, h, args.levels, args.levels - 1, args.iters, ", u16 depth plane" if has_depth else ", z=1",
                            P, U),
-            "pairs_per_gpu": P, "sharding": "round-robin pairs, RCCL all_gather of poses" if world > 1 else "single GPU",
+            "normal_equation_accumulation": args.acc, "pairs_per_gpu": P, "sharding": "round-robin pairs, RCCL all_gather of poses" if world > 1 else "single GPU",
         },
     }
     if rank == 0:

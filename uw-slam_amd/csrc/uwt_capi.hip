@@ -6,7 +6,9 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <new>
 #include <string>
 #include <vector>
@@ -360,7 +362,9 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   size_t max_slices = 1;
   for (int l = 0; l < p->n_levels; l++) {
     const int n_groups = c->lv[l].n / c->vec;
-    c->groups_per_block[l] = kBlock * kGroupsPerThread;
+    int gpt = kGroupsPerThread;
+    if (const char* e = std::getenv("UWT_GROUPS_PER_THREAD")) gpt = std::max(1, std::atoi(e));  // tuning experiments only
+    c->groups_per_block[l] = kBlock * gpt;
     c->slices[l] = (n_groups + c->groups_per_block[l] - 1) / c->groups_per_block[l];
     if ((size_t)c->slices[l] > max_slices) max_slices = c->slices[l];
   }

@@ -182,15 +182,27 @@ __device__ __forceinline__ int round_pos(float x) {  // C round() for x > 0
   return (int)t + ((x - t) >= 0.5f ? 1 : 0);
 }
 
-template <bool UNIT_FACTORS>
-__device__ __forceinline__ bool pixel_terms(const LevelK& L, const WarpK& K, float zf, float af, float xf, float yf,
-                                            float z, const uint8_t* __restrict__ I2, int i1, int gxi, int gyi,
-                                            float J[6], int& ri) {
-  float x2, y2, z2, iz;
+// Phase 1 of a pixel: warp, validity (src/Tracker.cpp:450-453) and the gather index of the nearest-neighbour sample
+// (:472).  Branch-free: an invalid pixel is sanitised (x2 = y2 = iz = 0) so that every later term is finite and its
+// Jacobian row comes out as exact zeros, which leave the accumulators unchanged.
+__device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, float xf, float yf, float z, bool ok_in,
+                                           float& x2, float& y2, float& iz, bool& ok, uint32_t& gidx) {
+  float z2;
   warp_point(L, K, xf, yf, z, x2, y2, z2, iz);
-  const bool valid = (y2 > 0.f) && (y2 < (float)L.h) && (x2 > 0.f) && (x2 < (float)L.w) && (z2 != 0.f);
-  if (!valid) return false;
-  if (iz < 0.f) iz = 0.f;
+  ok = ok_in && (y2 > 0.f) && (y2 < (float)L.h) && (x2 > 0.f) && (x2 < (float)L.w) && (z2 != 0.f);
+  x2 = ok ? x2 : 0.f;
+  y2 = ok ? y2 : 0.f;
+  iz = (ok && !(iz < 0.f)) ? iz : 0.f;  // "if (inv_z2 < 0) inv_z2 = 0" (:452-453)
+  int ix2 = round_pos(x2), iy2 = round_pos(y2);
+  ix2 = min(ix2, L.w - 1);  // the reference reads one past the edge here (:450, :472); clamp
+  iy2 = min(iy2, L.h - 1);
+  gidx = (uint32_t)(iy2 * L.w + ix2);
+}
+
+// Phase 2: Jw (src/Tracker.cpp:455-467) and Jacobian_row = Jl * Jw (:476-479), reference operation order.
+template <bool UNIT_FACTORS>
+__device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf, float af, float x2, float y2, float iz, float g0,
+                                               float g1, float J[6]) {
   const float fx = L.fx, fy = L.fy;
   float a0 = fx * iz;
   float a2 = -(((fx * x2) * iz) * iz);
@@ -206,19 +218,12 @@ __device__ __forceinline__ bool pixel_terms(const LevelK& L, const WarpK& K, flo
     a2 = a2 * zf; a3 = a3 * af; a4 = a4 * af; a5 = a5 * af;
     b2 = b2 * zf; b3 = b3 * af; b4 = b4 * af; b5 = b5 * af;
   }
-  int ix2 = round_pos(x2), iy2 = round_pos(y2);
-  ix2 = min(ix2, L.w - 1);  // reference reads one past the edge here (src/Tracker.cpp:450,472); clamp
-  iy2 = min(iy2, L.h - 1);
-  const int i2 = I2[iy2 * L.w + ix2];
-  ri = i2 - i1;
-  const float g0 = (float)gxi, g1 = (float)gyi;
   J[0] = g0 * a0;                                   // fma(g1, 0, g0*a0)
   J[1] = g1 * b1;                                   // fma(g1, b1, g0*0)
   J[2] = __builtin_fmaf(g1, b2, g0 * a2);
   J[3] = __builtin_fmaf(g1, b3, g0 * a3);
   J[4] = __builtin_fmaf(g1, b4, g0 * a4);
   J[5] = __builtin_fmaf(g1, b5, g0 * a5);
-  return true;
 }
 
 // Accumulator type: double reproduces the reference's double-accumulating gemm (src/Tracker.cpp:560-561) to the
@@ -327,6 +332,31 @@ struct ResidualArgs {
   uint8_t* dumpV;
 };
 
+// reference planes of one group of VEC pixels, as loaded (one vector load per plane)
+template <int VEC>
+struct RefGroup {
+  uint8_t i1[VEC];
+  int16_t gx[VEC], gy[VEC];
+  uint16_t dp[VEC];
+};
+
+template <int VEC, bool DEPTH>
+__device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __restrict__ I1, const int16_t* __restrict__ GX,
+                                           const int16_t* __restrict__ GY, const uint16_t* __restrict__ DP, uint32_t idx) {
+  if constexpr (VEC == 4) {
+    *reinterpret_cast<uint32_t*>(r.i1) = *reinterpret_cast<const uint32_t*>(I1 + idx);
+    *reinterpret_cast<uint2*>(r.gx) = *reinterpret_cast<const uint2*>(GX + idx);
+    *reinterpret_cast<uint2*>(r.gy) = *reinterpret_cast<const uint2*>(GY + idx);
+    if constexpr (DEPTH) *reinterpret_cast<uint2*>(r.dp) = *reinterpret_cast<const uint2*>(DP + idx);
+  } else {
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      r.i1[j] = I1[idx + j]; r.gx[j] = GX[idx + j]; r.gy[j] = GY[idx + j];
+      if constexpr (DEPTH) r.dp[j] = DP[idx + j];
+    }
+  }
+}
+
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT>
 __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
   const int pair = blockIdx.y;
@@ -356,49 +386,65 @@ __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
   const int n_groups = L.n / VEC;
   const int g_begin = blockIdx.x * a.groups_per_block;
   const int g_end = min(g_begin + a.groups_per_block, n_groups);
-  for (int g = g_begin + threadIdx.x; g < g_end; g += kBlock) {
-    const uint32_t idx = (uint32_t)g * VEC;
+  const int iters = (g_end - g_begin + kBlock - 1) / kBlock;  // block-uniform trip count
+
+  // software pipeline: the reference planes of group it+1 are in flight while group it is processed
+  RefGroup<VEC> nxt;
+  int g = g_begin + (int)threadIdx.x;
+  load_group<VEC, DEPTH>(nxt, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
+  for (int it = 0; it < iters; it++, g += kBlock) {
+    const RefGroup<VEC> cur = nxt;
+    const bool active = g < g_end;
+    const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
+    if (it + 1 < iters) load_group<VEC, DEPTH>(nxt, I1, GX, GY, DP, (uint32_t)min(g + kBlock, n_groups - 1) * VEC);
     const uint32_t y = __umulhi(idx, L.magic);
     const uint32_t x = idx - y * L.w;
-    uint8_t i1[VEC];
-    int16_t gxv[VEC], gyv[VEC];
-    uint16_t dv[VEC];
-    if constexpr (VEC == 4) {
-      *reinterpret_cast<uint32_t*>(i1) = *reinterpret_cast<const uint32_t*>(I1 + idx);
-      *reinterpret_cast<uint2*>(gxv) = *reinterpret_cast<const uint2*>(GX + idx);
-      *reinterpret_cast<uint2*>(gyv) = *reinterpret_cast<const uint2*>(GY + idx);
-      if constexpr (DEPTH) *reinterpret_cast<uint2*>(dv) = *reinterpret_cast<const uint2*>(DP + idx);
-    } else {
-#pragma unroll
-      for (int j = 0; j < VEC; j++) {
-        i1[j] = I1[idx + j]; gxv[j] = GX[idx + j]; gyv[j] = GY[idx + j];
-        if constexpr (DEPTH) dv[j] = DP[idx + j];
-      }
-    }
-    const float yf = (float)y;
+    const float yf = (float)y, xf0 = (float)x;
+
+    float x2[VEC], y2[VEC], iz[VEC];
+    bool ok[VEC];
+    uint32_t gidx[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       float z = 1.0f;
-      bool ok = true;
+      bool okin = active;
       if constexpr (DEPTH) {
-        const int d = (int)(int16_t)dv[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
-        ok = d > 0;
+        const int d = (int)(int16_t)cur.dp[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
+        okin = okin && d > 0;
         z = (float)d * L.zscale;
       }
-      float J[6];
-      int ri = 0;
-      if (ok) ok = pixel_terms<UNIT_FACTORS>(L, K, a.zf, a.af, (float)(x + j), yf, z, I2, (int)i1[j], (int)gxv[j], (int)gyv[j], J, ri);
-      if (ok) {
-        accumulate(acc, J, (float)ri);
-        sum_r2 += (uint32_t)(ri * ri);
-        n_valid += 1;
-      }
+      pixel_warp(L, K, xf0 + (float)j, yf, z, okin, x2[j], y2[j], iz[j], ok[j], gidx[j]);
+    }
+    int i2[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+#ifdef UWT_EXP_NOGATHER
+      i2[j] = (int)cur.i1[j] + (int)(gidx[j] & 1);
+#else
+      i2[j] = I2[gidx[j]];                        // nearest-neighbour gather of the target level (:472)
+#endif
+    }
+    float J[VEC][6];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const float g0 = ok[j] ? (float)cur.gx[j] : 0.f;
+      const float g1 = ok[j] ? (float)cur.gy[j] : 0.f;
+      pixel_jacobian<UNIT_FACTORS>(L, a.zf, a.af, x2[j], y2[j], iz[j], g0, g1, J[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      const int ri = ok[j] ? i2[j] - (int)cur.i1[j] : 0;
+      accumulate(acc, J[j], (float)ri);
+      sum_r2 += (uint32_t)(ri * ri);
+      n_valid += ok[j] ? 1u : 0u;
       if constexpr (DUMP) {
-        const size_t p = (size_t)pair * L.n + idx + j;
-        if (a.dumpV) a.dumpV[p] = ok ? 1 : 0;
-        if (a.dumpR) a.dumpR[p] = ok ? (float)ri : 0.f;
-        if (a.dumpJ)
-          for (int k = 0; k < 6; k++) a.dumpJ[p * 6 + k] = ok ? J[k] : 0.f;
+        if (active) {
+          const size_t p = (size_t)pair * L.n + idx + j;
+          if (a.dumpV) a.dumpV[p] = ok[j] ? 1 : 0;
+          if (a.dumpR) a.dumpR[p] = (float)ri;
+          if (a.dumpJ)
+            for (int k = 0; k < 6; k++) a.dumpJ[p * 6 + k] = J[j][k];
+        }
       }
     }
   }
