@@ -396,3 +396,40 @@ def test_full_size_1280x960_5_levels(capi, O, synth):
     st, pose_cpu, _ = O.align_pair(O.default_params(w, h, *intr, **over), ref, tgt)
     assert st == 0
     assert_pose_close(poses[0], pose_cpu)
+
+
+def test_track_batch_async_device_outputs_match_sync_path(capi, O, synth):
+    """uwt_track_batch_async (pyramids + reference-only gradients + alignment, poses/stats to device memory, sub-batches
+    on two streams) gives bit-identical poses to the step-by-step synchronous entry points and to the oracle."""
+    import torch
+    w, h, n = 160, 96, 80   # n >= 64 so that the two-stream sub-batching is exercised
+    over = dict(n_levels=4, first_level=3, last_level=0, max_iters=5, early_exit=0)
+    ctx = make_ctx(capi, w, h, MID, max_frames=2 * n, max_pairs=n, **over)
+    frames = []
+    for s in range(n):
+        ref, tgt, _, _, _ = synth.render_pair(w, h, *MID, seed=3000 + s)
+        frames += [ref, tgt]
+    frames = np.stack(frames)
+    ref_s, tgt_s = np.arange(n) * 2, np.arange(n) * 2 + 1
+    ctx.upload_frames(0, frames)
+    d_poses = torch.zeros((n, 7), dtype=torch.float32, device="cuda")
+    d_stats = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()  # torch's fill kernels run on torch's stream, not on the context's streams
+    ctx.track_batch_async(0, 2 * n, ref_s, tgt_s, d_poses.data_ptr(), d_stats.data_ptr(), grad_refs_only=True)
+    ctx.sync()
+    a = d_poses.cpu().numpy()
+    st = d_stats.cpu().numpy()
+    assert (st[:, 0] == 0).all() and (st[:, 1] == 20).all()
+    # target slots never had gradients computed in this mode; reference slots did
+    gx, _ = O.scharr3(frames[0])
+    assert np.array_equal(ctx.get_plane(0, 0, capi.PLANE_GRADX), gx)
+    ctx2 = make_ctx(capi, w, h, MID, max_frames=2 * n, max_pairs=n, **over)
+    ctx2.upload_frames(0, frames)
+    ctx2.build_pyramids(0, 2 * n)
+    ctx2.apply_gradient(0, 2 * n)
+    b, _ = ctx2.estimate_pose_batch(ref_s, tgt_s, raise_on_pair_failure=True)
+    p = O.default_params(w, h, *MID, **over)
+    cpu = np.stack([O.align_pair(p, frames[2 * i], frames[2 * i + 1])[1] for i in range(n)])
+    bad_a = [i for i in range(n) if not np.array_equal(a[i], cpu[i])]
+    bad_b = [i for i in range(n) if not np.array_equal(b[i], cpu[i])]
+    assert bad_a == [] and bad_b == [], "async!=cpu %s ; sync!=cpu %s ; a==b %s" % (bad_a, bad_b, np.array_equal(a, b))

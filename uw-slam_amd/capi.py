@@ -60,12 +60,29 @@ class UwtError(RuntimeError):
         self.status = status
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so (same SONAME as /opt/rocm's).  If libuwt_hip.so pulled in the
+    system copy first, a later `import torch` would load a second HIP runtime into the process (two device states,
+    "No HIP GPUs are available", unordered streams).  Loading torch's copy first makes both use one runtime; without
+    torch installed the system runtime is used."""
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec and spec.origin:
+            cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+            if os.path.exists(cand):
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Loads libuwt_hip.so; raises if it is missing (no fallback)."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("libuwt_hip.so not built at %s — run __graft_entry__.build()" % LIB_PATH)
+        _share_torch_hip_runtime()
         _lib = C.CDLL(LIB_PATH)
         _lib.uwt_status_string.restype = C.c_char_p
         _lib.uwt_last_error.restype = C.c_char_p
@@ -172,10 +189,10 @@ class Context:
         self._chk(st, allow=() if raise_on_pair_failure else (ERR_PAIR_FAILED,))
         return poses, [dict(status=s.status, iterations=s.iterations, n_valid=s.n_valid, error=s.error) for s in stats]
 
-    def track_batch_async(self, first_slot, n_frames, ref_slots, tgt_slots, d_poses_ptr, d_stats_ptr=None):
+    def track_batch_async(self, first_slot, n_frames, ref_slots, tgt_slots, d_poses_ptr, d_stats_ptr=None, grad_refs_only=True):
         ref = np.ascontiguousarray(ref_slots, np.int32)
         tgt = np.ascontiguousarray(tgt_slots, np.int32)
-        self._chk(lib().uwt_track_batch_async(self._h, first_slot, n_frames, 0, ref.size, _p(ref, C.c_int32),
+        self._chk(lib().uwt_track_batch_async(self._h, first_slot, n_frames, int(grad_refs_only), ref.size, _p(ref, C.c_int32),
                                               _p(tgt, C.c_int32), C.c_void_p(d_poses_ptr),
                                               C.c_void_p(d_stats_ptr) if d_stats_ptr else None))
 

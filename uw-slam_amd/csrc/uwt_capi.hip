@@ -27,6 +27,7 @@ struct uwt_ctx {
   int slices[UWT_MAX_LEVELS];
   int groups_per_block[UWT_MAX_LEVELS];
   hipStream_t stream = nullptr;
+  int pipeline = 1;                     // 1: two half-batches pipelined through k_step (fixed-iteration mode)
   uint8_t* img[UWT_MAX_LEVELS] = {};
   uint16_t* depth[UWT_MAX_LEVELS] = {};
   int16_t* gx[UWT_MAX_LEVELS] = {};
@@ -34,6 +35,8 @@ struct uwt_ctx {
   PairState* state = nullptr;
   int* d_ref = nullptr;
   int* d_tgt = nullptr;
+  int* h_pairs = nullptr;               // pinned staging: [ref(max_pairs) | tgt(max_pairs)], also the cache of what is on the device
+  int n_pairs_cached = 0;
   uint32_t* partials = nullptr;
   size_t partial_records = 0;
   float* d_poses = nullptr;
@@ -121,10 +124,20 @@ int launch_halve(uwt_ctx* c, const T* src, T* dst, int w_out, int h_out, size_t 
   return UWT_OK;
 }
 
-int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int w, int h, size_t fs, int n_frames) {
+// src/gx/gy point at slot 0 of the level planes; the frames processed are slots[0..n) if given, else first_slot..+n
+int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int w, int h, size_t fs, int n_frames,
+                  const int* d_slots = nullptr, int first_slot = 0) {
   if (n_frames == 0) return UWT_OK;
-  const int tiles = ((w + kGradTW - 1) / kGradTW) * ((h + kGradTH - 1) / kGradTH);
-  hipLaunchKernelGGL(k_scharr3, dim3(tiles, n_frames), dim3(kBlock), 0, c->stream, src, gx, gy, w, h, fs);
+  if (w % 4 == 0) {
+    const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + kGradVH - 1) / kGradVH);
+    hipLaunchKernelGGL(k_scharr3_v4, dim3(tiles, n_frames), dim3(kBlock), 0, c->stream, src, gx, gy, w, h, fs, d_slots,
+                       first_slot);
+  } else {
+    if (d_slots) return fail(c, UWT_ERR_INVALID_ARG, "slot lists need level widths that are multiples of 4");
+    const int tiles = ((w + kGradTW - 1) / kGradTW) * ((h + kGradTH - 1) / kGradTH);
+    hipLaunchKernelGGL(k_scharr3, dim3(tiles, n_frames), dim3(kBlock), 0, c->stream, src + first_slot * fs,
+                       gx + first_slot * fs, gy + first_slot * fs, w, h, fs);
+  }
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
 }
@@ -208,54 +221,150 @@ int prof_collect(uwt_ctx* c) {  // after a stream sync
   return UWT_OK;
 }
 
-// Tracker::EstimatePose for a batch, enqueued on the stream (src/Tracker.cpp:362-597)
+template <int VEC, bool DEPTH, bool UNIT>
+void launch_step_t(hipStream_t s, const ResidualArgs& ra, const UpdateArgs& ua, int n_upd, int n_res, bool acc64) {
+  const int blocks = n_upd + n_res * ra.slices;
+  if (blocks == 0) return;
+  if (acc64)
+    hipLaunchKernelGGL((k_step<VEC, DEPTH, UNIT, double>), dim3(blocks), dim3(kBlock), 0, s, ra, ua, n_upd);
+  else
+    hipLaunchKernelGGL((k_step<VEC, DEPTH, UNIT, float>), dim3(blocks), dim3(kBlock), 0, s, ra, ua, n_upd);
+}
+
+int launch_step(uwt_ctx* c, const ResidualArgs& ra, const UpdateArgs& ua, int n_upd, int n_res) {
+  const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f), acc64 = c->p.accumulate_f64 != 0;
+  const int key = (c->vec == 4 ? 4 : 0) | (depth ? 2 : 0) | (unit ? 1 : 0);
+  hipStream_t s = c->stream;
+  switch (key) {
+    case 0: launch_step_t<1, false, false>(s, ra, ua, n_upd, n_res, acc64); break;
+    case 1: launch_step_t<1, false, true>(s, ra, ua, n_upd, n_res, acc64); break;
+    case 2: launch_step_t<1, true, false>(s, ra, ua, n_upd, n_res, acc64); break;
+    case 3: launch_step_t<1, true, true>(s, ra, ua, n_upd, n_res, acc64); break;
+    case 4: launch_step_t<4, false, false>(s, ra, ua, n_upd, n_res, acc64); break;
+    case 5: launch_step_t<4, false, true>(s, ra, ua, n_upd, n_res, acc64); break;
+    case 6: launch_step_t<4, true, false>(s, ra, ua, n_upd, n_res, acc64); break;
+    default: launch_step_t<4, true, true>(s, ra, ua, n_upd, n_res, acc64); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
+UpdateArgs update_args(uwt_ctx* c, int lvl) {
+  UpdateArgs ua;
+  std::memset(&ua, 0, sizeof(ua));
+  ua.partials = c->partials;
+  ua.state = c->state;
+  ua.slices = c->slices[lvl];
+  ua.max_iters = c->p.max_iters;
+  ua.early_exit = c->p.early_exit;
+  ua.epsilon = c->p.epsilon;
+  ua.gain = c->p.gain;
+  ua.level = lvl;
+  ua.scale_t = c->p.handoff_scale_t;
+  ua.initial_error = c->p.initial_error;
+  return ua;
+}
+
+// Fixed-iteration schedule (early_exit == 0): the batch is cut into halves A and B whose (residual, update) chains are
+// interleaved on ONE stream — launch i carries the update of one half and the residual of the other:
+//   res(A,0) | upd(A,0)+res(B,0) | upd(B,0)+res(A,1) | ... | upd(A,last)+res(B,last) | upd(B,last)
+// The level hand-off rides on the last update of each level, so the chain runs across levels without a bubble.
+int enqueue_estimate_pipelined(uwt_ctx* c, int n_pairs) {
+  const uwt_params& p = c->p;
+  const int nA = (n_pairs + 1) / 2, nB = n_pairs - nA;
+  const int base[2] = {0, nA}, cnt[2] = {nA, nB};
+  struct Item { int lvl, k; };
+  std::vector<Item> seq;
+  for (int lvl = p.first_level; lvl >= p.last_level; lvl--)
+    for (int k = 0; k < p.max_iters; k++) seq.push_back({lvl, k});
+  const int T = (int)seq.size();
+  // launch t (0..2T): residual of chain step t (half t&1, item t>>1) and update of chain step t-1
+  for (int t = 0; t <= 2 * T; t++) {
+    const bool has_res = t < 2 * T, has_upd = t >= 1;
+    ResidualArgs ra;
+    std::memset(&ra, 0, sizeof(ra));
+    ra.slices = 1;
+    int n_res = 0, n_upd = 0;
+    if (has_res) {
+      const int h = t & 1;
+      ra = residual_args(c, seq[t >> 1].lvl);
+      ra.pair_base = base[h];
+      n_res = cnt[h];
+    }
+    UpdateArgs ua;
+    std::memset(&ua, 0, sizeof(ua));
+    if (has_upd) {
+      const int u = t - 1, h = u & 1;
+      const Item it = seq[u >> 1];
+      ua = update_args(c, it.lvl);
+      ua.k = it.k;
+      ua.pair_base = base[h];
+      ua.level_end = (it.k == p.max_iters - 1) ? 1 : 0;
+      n_upd = cnt[h];
+    }
+    if (n_res == 0 && n_upd == 0) continue;
+    size_t ev = 0;
+    const bool prof = c->profiling && n_res > 0;
+    if (prof) {
+      int st = prof_begin(c, &ev);
+      if (st) return st;
+    }
+    int st = launch_step(c, ra, ua, n_upd, n_res);
+    if (st) return st;
+    if (prof) {
+      HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
+      c->prof_launches += 1;
+      c->prof_pixels += (long long)n_res * c->lv[seq[t >> 1].lvl].n;
+    }
+  }
+  return UWT_OK;
+}
+
+// Tracker::EstimatePose for a batch, enqueued on the context's stream (src/Tracker.cpp:362-597)
 int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats) {
   const uwt_params& p = c->p;
   const int tb = 128;
   hipLaunchKernelGGL(k_init_state, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs,
                      p.initial_error);
   HIPCHK(c, hipGetLastError());
-  for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
-    ResidualArgs ra = residual_args(c, lvl);
-    UpdateArgs ua;
-    ua.partials = c->partials;
-    ua.state = c->state;
-    ua.slices = c->slices[lvl];
-    ua.max_iters = p.max_iters;
-    ua.early_exit = p.early_exit;
-    ua.epsilon = p.epsilon;
-    ua.gain = p.gain;
-    ua.active = nullptr;
-    int next_poll = 2;
-    for (int k = 0; k < p.max_iters; k++) {
-      size_t ev = 0;
-      if (c->profiling) {
-        int st = prof_begin(c, &ev);
+  if (!p.early_exit && c->pipeline && n_pairs >= 2) {
+    int st = enqueue_estimate_pipelined(c, n_pairs);
+    if (st) return st;
+  } else {
+    for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
+      ResidualArgs ra = residual_args(c, lvl);
+      UpdateArgs ua = update_args(c, lvl);
+      int next_poll = 2;
+      for (int k = 0; k < p.max_iters; k++) {
+        size_t ev = 0;
+        if (c->profiling) {
+          int st = prof_begin(c, &ev);
+          if (st) return st;
+        }
+        int st = launch_residual(c, ra, n_pairs, false);
         if (st) return st;
+        if (c->profiling) {
+          HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
+          c->prof_launches += 1;
+          c->prof_pixels += (long long)n_pairs * c->lv[lvl].n;
+        }
+        ua.k = k;
+        const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
+        ua.active = poll ? c->d_active : nullptr;
+        if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
+        hipLaunchKernelGGL(k_gn_update, dim3(n_pairs), dim3(64), 0, c->stream, ua);
+        HIPCHK(c, hipGetLastError());
+        if (poll) {  // reference-mode early exit: stop launching once every pair has left this level
+          HIPCHK(c, hipMemcpyAsync(c->h_active, c->d_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipStreamSynchronize(c->stream));
+          if (*c->h_active == 0) break;
+          next_poll *= 2;
+        }
       }
-      int st = launch_residual(c, ra, n_pairs, false);
-      if (st) return st;
-      if (c->profiling) {
-        HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
-        c->prof_launches += 1;
-        c->prof_pixels += (long long)n_pairs * c->lv[lvl].n;
-      }
-      ua.k = k;
-      const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
-      ua.active = poll ? c->d_active : nullptr;
-      if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
-      hipLaunchKernelGGL(k_gn_update, dim3(n_pairs), dim3(64), 0, c->stream, ua);
+      hipLaunchKernelGGL(k_level_end, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs, lvl,
+                         p.handoff_scale_t, p.initial_error);
       HIPCHK(c, hipGetLastError());
-      if (poll) {  // reference-mode early exit: stop launching once every pair has left this level
-        HIPCHK(c, hipMemcpyAsync(c->h_active, c->d_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        if (*c->h_active == 0) break;
-        next_poll *= 2;
-      }
     }
-    hipLaunchKernelGGL(k_level_end, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs, lvl,
-                       p.handoff_scale_t, p.initial_error);
-    HIPCHK(c, hipGetLastError());
   }
   hipLaunchKernelGGL(k_write_out, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs, d_poses,
                      d_stats);
@@ -263,14 +372,25 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats)
   return UWT_OK;
 }
 
+// The caller's lists are copied before this returns (they may be temporaries): into a pinned staging buffer, then
+// asynchronously to the device.  Unchanged lists (the steady state of a resident batch) are not re-sent.
 int upload_pairs(uwt_ctx* c, int n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots) {
   if (!ref_slots || !tgt_slots || n_pairs < 1) return fail(c, UWT_ERR_INVALID_ARG, "null pair lists or n_pairs < 1");
   if (n_pairs > c->p.max_pairs) return fail(c, UWT_ERR_CAPACITY, "n_pairs exceeds max_pairs");
   for (int i = 0; i < n_pairs; i++)
     if (ref_slots[i] < 0 || ref_slots[i] >= c->p.max_frames || tgt_slots[i] < 0 || tgt_slots[i] >= c->p.max_frames)
       return fail(c, UWT_ERR_INVALID_ARG, "pair slot out of range");
-  HIPCHK(c, hipMemcpyAsync(c->d_ref, ref_slots, sizeof(int) * n_pairs, hipMemcpyHostToDevice, c->stream));
-  HIPCHK(c, hipMemcpyAsync(c->d_tgt, tgt_slots, sizeof(int) * n_pairs, hipMemcpyHostToDevice, c->stream));
+  int* h_ref = c->h_pairs;
+  int* h_tgt = c->h_pairs + c->p.max_pairs;
+  if (n_pairs == c->n_pairs_cached && !std::memcmp(h_ref, ref_slots, sizeof(int) * n_pairs) &&
+      !std::memcmp(h_tgt, tgt_slots, sizeof(int) * n_pairs))
+    return UWT_OK;
+  HIPCHK(c, hipStreamSynchronize(c->stream));  // an earlier async copy may still be reading the staging buffer
+  std::memcpy(h_ref, ref_slots, sizeof(int) * n_pairs);
+  std::memcpy(h_tgt, tgt_slots, sizeof(int) * n_pairs);
+  c->n_pairs_cached = n_pairs;
+  HIPCHK(c, hipMemcpyAsync(c->d_ref, h_ref, sizeof(int) * n_pairs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipMemcpyAsync(c->d_tgt, h_tgt, sizeof(int) * n_pairs, hipMemcpyHostToDevice, c->stream));
   return UWT_OK;
 }
 
@@ -381,6 +501,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   } while (0)
   CREATE_CHK(hipSetDevice(p->device));
   CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  if (const char* e = std::getenv("UWT_PIPELINE")) c->pipeline = std::atoi(e) != 0;  // tuning experiments only
   for (int l = 0; l < p->n_levels; l++) {
     const size_t n = (size_t)c->lv[l].n * p->max_frames;
     CREATE_CHK(hipMalloc((void**)&c->img[l], n));
@@ -396,6 +517,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_stats, sizeof(StatsOut) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_active, sizeof(int)));
   CREATE_CHK(hipHostMalloc((void**)&c->h_active, sizeof(int)));
+  CREATE_CHK(hipHostMalloc((void**)&c->h_pairs, sizeof(int) * 2 * p->max_pairs));
 #undef CREATE_CHK
   *out = c;
   return UWT_OK;
@@ -419,6 +541,7 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->d_stats) (void)hipFree(c->d_stats);
   if (c->d_active) (void)hipFree(c->d_active);
   if (c->h_active) (void)hipHostFree(c->h_active);
+  if (c->h_pairs) (void)hipHostFree(c->h_pairs);
   if (c->scratch) (void)hipFree(c->scratch);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -503,11 +626,9 @@ static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n) {
   return UWT_OK;
 }
 
-static int enqueue_gradients(uwt_ctx* c, int first_slot, int n) {
+static int enqueue_gradients(uwt_ctx* c, int first_slot, int n, const int* d_slots = nullptr) {
   for (int l = 0; l < c->p.n_levels; l++) {
-    const size_t nl = c->lv[l].n;
-    int st = launch_scharr(c, c->img[l] + first_slot * nl, c->gx[l] + first_slot * nl, c->gy[l] + first_slot * nl, c->lv[l].w,
-                           c->lv[l].h, nl, n);
+    int st = launch_scharr(c, c->img[l], c->gx[l], c->gy[l], c->lv[l].w, c->lv[l].h, c->lv[l].n, n, d_slots, first_slot);
     if (st) return st;
   }
   return UWT_OK;
@@ -559,12 +680,17 @@ int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int3
                           const int32_t* ref_slots, const int32_t* tgt_slots, float* d_poses_out, uwt_stats* d_stats_out) {
   if (!c || !d_poses_out || !slot_range_ok(c, first_slot, n_frames))
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_track_batch_async: bad argument");
-  (void)grad_refs_only;  // gradients are cheap next to the GN loop; all prepared frames get them (ApplyGradient on both frames, src/System.cpp:197-213)
   int st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
   if (st) return st;
   st = enqueue_pyramids(c, first_slot, n_frames);
   if (st) return st;
-  st = enqueue_gradients(c, first_slot, n_frames);
+  // The tracker only reads the previous frame's gradients (src/Tracker.cpp:407-408).  grad_refs_only computes them for
+  // the pairs' reference slots alone; otherwise every prepared frame gets them, as System::Tracking calls
+  // ApplyGradient on both frames (src/System.cpp:197-213).
+  if (grad_refs_only && c->vec == 4)
+    st = enqueue_gradients(c, 0, n_pairs, c->d_ref);
+  else
+    st = enqueue_gradients(c, first_slot, n_frames);
   if (st) return st;
   return enqueue_estimate(c, n_pairs, d_poses_out, reinterpret_cast<StatsOut*>(d_stats_out));
 }

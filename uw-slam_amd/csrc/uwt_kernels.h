@@ -123,6 +123,61 @@ __global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ 
   }
 }
 
+// Vector variant for level widths that are multiples of 4: a 128x8 output tile per block, the 130x10 source patch
+// staged in LDS with 4-byte loads, each thread produces 4 adjacent outputs from nine aligned LDS words and stores two
+// 8-byte vectors.  HBM-bound: 1 B read + 4 B written per pixel.  `slots` (optional) lists the frame slots to process.
+constexpr int kGradVW = 128, kGradVH = 8;
+
+__global__ __launch_bounds__(kBlock) void k_scharr3_v4(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
+                                                       int16_t* __restrict__ gy, int w, int h, size_t frame_stride,
+                                                       const int* __restrict__ slots, int first_slot) {
+  __shared__ uint32_t tile[kGradVH + 2][kGradVW / 4 + 2];  // word 0: left halo in its top byte; word 33: right halo in its low byte
+  const int slot = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;
+  const int tiles_x = (w + kGradVW - 1) / kGradVW;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int x0 = tx * kGradVW, y0 = ty * kGradVH;
+  const uint8_t* img = src + (size_t)slot * frame_stride;
+  const int tw = min(kGradVW, w - x0);  // valid width of this tile (multiple of 4)
+  for (int i = threadIdx.x; i < (kGradVH + 2) * (kGradVW / 4); i += kBlock) {
+    const int r = i / (kGradVW / 4), c = i - r * (kGradVW / 4);
+    if (4 * c < tw) {
+      const int sy = reflect101(min(y0 + r - 1, h), h);
+      tile[r][1 + c] = *reinterpret_cast<const uint32_t*>(img + (size_t)sy * w + x0 + 4 * c);
+    }
+  }
+  if (threadIdx.x < 2 * (kGradVH + 2)) {
+    const int r = threadIdx.x >> 1, side = threadIdx.x & 1;
+    const int sy = reflect101(min(y0 + r - 1, h), h);
+    const int xs = reflect101(side ? x0 + tw : x0 - 1, w);
+    const uint32_t v = img[(size_t)sy * w + xs];
+    if (side) tile[r][1 + tw / 4] = v; else tile[r][0] = v << 24;
+  }
+  __syncthreads();
+  const int ly = threadIdx.x / (kGradVW / 4), c = threadIdx.x - ly * (kGradVW / 4);
+  const int x = x0 + 4 * c, y = y0 + ly;
+  if (4 * c < tw && y < h) {
+    int p[3][6];  // p[row][0..5] = pixels x-1 .. x+4
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+      const uint32_t wl = tile[ly + r][c], wc = tile[ly + r][c + 1], wr = tile[ly + r][c + 2];
+      p[r][0] = wl >> 24;
+      p[r][1] = wc & 0xff; p[r][2] = (wc >> 8) & 0xff; p[r][3] = (wc >> 16) & 0xff; p[r][4] = wc >> 24;
+      p[r][5] = wr & 0xff;
+    }
+    int16_t ox[4], oy[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int sx = 3 * (3 * (p[0][j + 2] - p[0][j]) + 10 * (p[1][j + 2] - p[1][j]) + 3 * (p[2][j + 2] - p[2][j]));
+      const int sy = 3 * (3 * (p[2][j] - p[0][j]) + 10 * (p[2][j + 1] - p[0][j + 1]) + 3 * (p[2][j + 2] - p[0][j + 2]));
+      ox[j] = (int16_t)sx;
+      oy[j] = (int16_t)sy;
+    }
+    const size_t o = (size_t)slot * frame_stride + (size_t)y * w + x;
+    *reinterpret_cast<uint2*>(gx + o) = *reinterpret_cast<uint2*>(ox);
+    *reinterpret_cast<uint2*>(gy + o) = *reinterpret_cast<uint2*>(oy);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // per-pixel terms: WarpFunction (src/Tracker.cpp:1439-1467) + validity / Jw / residual / Jl·Jw (:447-479).
 // Float op order is the contract (mirrors oracle S1): small products are k-sequential FMA chains, everything
@@ -331,6 +386,7 @@ struct ResidualArgs {
   float zf, af;
   int groups_per_block;
   int slices;
+  int pair_base;            // first pair of this launch (sub-batches run on separate streams)
   uint32_t* partials;       // [pair][slice][kRecWords]
   float* dumpJ;             // optional per-pixel dumps (DUMP only)
   float* dumpR;
@@ -363,8 +419,7 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
 }
 
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT>
-__global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
-  const int pair = blockIdx.y;
+__device__ __forceinline__ void residual_block(const ResidualArgs& a, const int pair, const int slice) {
   Pose pose;
   if (a.state) {
     const PairState st = a.state[pair];
@@ -389,7 +444,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
   uint32_t sum_r2 = 0, n_valid = 0;
 
   const int n_groups = L.n / VEC;
-  const int g_begin = blockIdx.x * a.groups_per_block;
+  const int g_begin = slice * a.groups_per_block;
   const int g_end = min(g_begin + a.groups_per_block, n_groups);
   const int iters = (g_end - g_begin + kBlock - 1) / kBlock;  // block-uniform trip count
 
@@ -460,8 +515,13 @@ __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
     if (s == 1.2345 && sum_r2 == 77 && n_valid == 3) a.partials[threadIdx.x] = 1;
   }
 #else
-  block_reduce_store<AccT>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + blockIdx.x) * kRecWords);
+  block_reduce_store<AccT>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + slice) * kRecWords);
 #endif
+}
+
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT>
+__global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
+  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -478,6 +538,11 @@ struct UpdateArgs {
   int early_exit;
   float epsilon;
   float gain;
+  int pair_base;
+  int level_end;     // 1: also run the level hand-off after this update (pipelined schedule)
+  int level;
+  int scale_t;
+  float initial_error;
   int* active;       // optional: counts the pairs still iterating after this update (early-exit polling)
 };
 
@@ -494,56 +559,91 @@ __device__ inline void fold_partials(const uint32_t* __restrict__ recs, int slic
   }
 }
 
-__global__ __launch_bounds__(64) void k_gn_update(const UpdateArgs a) {
-  const int pair = blockIdx.x, lane = threadIdx.x;
-  PairState st = a.state[pair];
-  if (st.level_done || st.status) return;
+// The scalar tail of one GN iteration for one pair; executed by the first wave of the calling block (any block size:
+// lanes >= 64 only take part in the barrier).
+__device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair) {
+  const int lane = threadIdx.x;
   __shared__ double sums[kAccFloats];
   __shared__ long long isums[2];
-  double cs;
-  long long is;
-  fold_partials(a.partials + (size_t)pair * a.slices * kRecWords, a.slices, lane, cs, is);
-  if (lane < kAccFloats) sums[lane] = cs;
-  else if (lane < 29) isums[lane - 27] = is;
+  PairState st = a.state[pair];
+  const bool live = !(st.level_done || st.status);  // block-uniform
+  if (live && lane < 64) {
+    double cs;
+    long long is;
+    fold_partials(a.partials + (size_t)pair * a.slices * kRecWords, a.slices, lane, cs, is);
+    if (lane < kAccFloats) sums[lane] = cs;
+    else if (lane < 29) isums[lane - 27] = is;
+  }
   __syncthreads();
   if (lane != 0) return;
-
-  const int n = (int)isums[0];
-  const long long sr2 = isums[1];
-  st.iters += 1;
-  st.n_valid = n;
-  if (n == 0) {
-    st.status = 2;  // UWT_ERR_NO_VALID_POINTS
-    st.level_done = 1;
-    a.state[pair] = st;
-    return;
-  }
-  const float inv_n = (float)(1.0 / (double)n);                 // src/Tracker.cpp:499
-  const float error = (float)((double)inv_n * (double)sr2);     // :501, scaled-gemm form
-  st.error = error;
-  if (a.early_exit &&
-      (error >= st.last_error || a.k == a.max_iters - 1 || fabsf(error - st.last_error) < a.epsilon)) {  // :508
-    st.level_done = 1;
-    a.state[pair] = st;
-    return;
-  }
-  st.last_error = error;  // :529
-  float A[36], b[6], delta[6];
-  int s = 0;
-  for (int i = 0; i < 6; i++)
-    for (int j = i; j < 6; j++, s++) {
-      const float v = (float)sums[s];
-      A[6 * i + j] = v;
-      A[6 * j + i] = v;
+  if (live) {
+    const int n = (int)isums[0];
+    const long long sr2 = isums[1];
+    st.iters += 1;
+    st.n_valid = n;
+    bool update = true;
+    if (n == 0) {
+      st.status = 2;  // UWT_ERR_NO_VALID_POINTS
+      st.level_done = 1;
+      update = false;
+    } else {
+      const float inv_n = (float)(1.0 / (double)n);                 // src/Tracker.cpp:499
+      const float error = (float)((double)inv_n * (double)sr2);     // :501, scaled-gemm form
+      st.error = error;
+      if (a.early_exit &&
+          (error >= st.last_error || a.k == a.max_iters - 1 || fabsf(error - st.last_error) < a.epsilon)) {  // :508
+        st.level_done = 1;
+        update = false;
+      } else {
+        st.last_error = error;  // :529
+      }
     }
-  for (int i = 0; i < 6; i++) b[i] = (float)(-((double)a.gain * sums[21 + i]));  // :559-561
-  solve_delta(A, b, delta, nullptr);                                              // :564
-  Pose d, np;
-  se3_exp(delta, d);                                                              // :574
-  se3_mul(st.pose, d, np);
-  st.pose = np;
+    if (update) {
+      float A[36], b[6], delta[6];
+      int s = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++, s++) {
+          const float v = (float)sums[s];
+          A[6 * i + j] = v;
+          A[6 * j + i] = v;
+        }
+#pragma unroll
+      for (int i = 0; i < 6; i++) b[i] = (float)(-((double)a.gain * sums[21 + i]));  // :559-561
+      solve_delta(A, b, delta, nullptr);                                              // :564
+      Pose d, np;
+      se3_exp(delta, d);                                                              // :574
+      se3_mul(st.pose, d, np);
+      st.pose = np;
+      if (a.active) atomicAdd(a.active, 1);
+    }
+  }
+  if (a.level_end) {  // last iteration of the level in the pipelined schedule: hand-off + re-arm (:580-590, :392-393)
+    if (st.status == 0 && a.level != 0) {
+      if (!se3_handoff(st.pose, a.scale_t != 0)) st.status = 1;  // SOPHUS_ENSURE would abort
+    }
+    st.level_done = 0;
+    st.last_error = a.initial_error;
+  }
   a.state[pair] = st;
-  if (a.active) atomicAdd(a.active, 1);
+}
+
+__global__ __launch_bounds__(64) void k_gn_update(const UpdateArgs a) { update_block(a, (int)blockIdx.x + a.pair_base); }
+
+// k_step: one launch of the pipelined schedule — the GN update of one half of the batch (blocks [0, n_upd), first
+// wave only) next to the residual evaluation of the other half (remaining blocks, pair-major).  The two halves are
+// independent, so the latency-bound updates hide behind the residual blocks, on a single stream.
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, typename AccT>
+__global__ __launch_bounds__(kBlock) void k_step(const ResidualArgs ra, const UpdateArgs ua, const int n_upd) {
+  const int b = blockIdx.x;
+  if (b < n_upd) {
+    update_block(ua, b + ua.pair_base);
+  } else {
+    const int r = b - n_upd;
+    const int pair = r / ra.slices;
+    residual_block<VEC, DEPTH, UNIT_FACTORS, false, AccT>(ra, pair + ra.pair_base, r - pair * ra.slices);
+  }
 }
 
 __global__ void k_init_state(PairState* state, int n, float initial_error) {
@@ -562,7 +662,7 @@ __global__ void k_init_state(PairState* state, int n, float initial_error) {
 
 // end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
 __global__ void k_level_end(PairState* state, int n, int lvl, int scale_t, float initial_error) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // `state` is already offset to the sub-batch
   if (i >= n) return;
   PairState st = state[i];
   if (st.status == 0 && lvl != 0) {

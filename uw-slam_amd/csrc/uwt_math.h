@@ -141,33 +141,57 @@ __device__ inline bool se3_handoff(Pose& p, bool scale_t) {
 // cv::Mat::inv() (DECOMP_LU, CV_32F) as used at src/Tracker.cpp:564: Gaussian elimination with partial
 // pivoting, pivot threshold 10·FLT_EPSILON, singular ⇒ zero matrix.  Returns false when singular.
 __device__ inline bool inv6_lu(const float Ain[36], float X[36]) {
+  // Fully unrolled with compile-time indices (the pivot row is applied through predicated row swaps), so that the
+  // two 6x6 matrices live in registers instead of scratch memory.
   float A[36];
+#pragma unroll
   for (int i = 0; i < 36; i++) { A[i] = Ain[i]; X[i] = 0.f; }
+#pragma unroll
   for (int i = 0; i < 6; i++) X[7 * i] = 1.f;
   const float eps = 1.1920929e-07f * 10;
+  bool singular = false;
+#pragma unroll
   for (int i = 0; i < 6; i++) {
     int k = i;
-    for (int j = i + 1; j < 6; j++)
-      if (fabsf(A[j * 6 + i]) > fabsf(A[k * 6 + i])) k = j;
-    if (fabsf(A[k * 6 + i]) < eps) {
-      for (int q = 0; q < 36; q++) X[q] = 0.f;
-      return false;
+    float best = fabsf(A[i * 6 + i]);
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) {
+      const float v = fabsf(A[j * 6 + i]);
+      if (v > best) { best = v; k = j; }  // "abs(A[j][i]) > abs(A[k][i])": the first maximum wins
     }
-    if (k != i) {
-      for (int j = i; j < 6; j++) { const float t = A[i * 6 + j]; A[i * 6 + j] = A[k * 6 + j]; A[k * 6 + j] = t; }
-      for (int j = 0; j < 6; j++) { const float t = X[i * 6 + j]; X[i * 6 + j] = X[k * 6 + j]; X[k * 6 + j] = t; }
+    if (best < eps) singular = true;
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) {
+      if (k == j) {
+#pragma unroll
+        for (int q = i; q < 6; q++) { const float t = A[i * 6 + q]; A[i * 6 + q] = A[j * 6 + q]; A[j * 6 + q] = t; }
+#pragma unroll
+        for (int q = 0; q < 6; q++) { const float t = X[i * 6 + q]; X[i * 6 + q] = X[j * 6 + q]; X[j * 6 + q] = t; }
+      }
     }
     const float d = -1.f / A[i * 6 + i];
+#pragma unroll
     for (int j = i + 1; j < 6; j++) {
       const float alpha = A[j * 6 + i] * d;
+#pragma unroll
       for (int q = i + 1; q < 6; q++) A[j * 6 + q] = A[j * 6 + q] + alpha * A[i * 6 + q];
+#pragma unroll
       for (int q = 0; q < 6; q++) X[j * 6 + q] = X[j * 6 + q] + alpha * X[i * 6 + q];
     }
     A[i * 6 + i] = -d;
+    if (singular) break;  // the reference returns at the first tiny pivot
   }
+  if (singular) {
+#pragma unroll
+    for (int q = 0; q < 36; q++) X[q] = 0.f;
+    return false;
+  }
+#pragma unroll
   for (int i = 5; i >= 0; i--)
+#pragma unroll
     for (int j = 0; j < 6; j++) {
       float s = X[i * 6 + j];
+#pragma unroll
       for (int q = i + 1; q < 6; q++) s = s - A[i * 6 + q] * X[q * 6 + j];
       X[i * 6 + j] = s * A[i * 6 + i];
     }
@@ -178,13 +202,17 @@ __device__ inline bool inv6_lu(const float Ain[36], float X[36]) {
 __device__ inline bool solve_delta(const float A[36], const float b[6], float delta[6], float* Ainv_out) {
   float Ai[36];
   const bool ok = inv6_lu(A, Ai);
+#pragma unroll
   for (int i = 0; i < 6; i++) {
     double s = 0.0;
+#pragma unroll
     for (int j = 0; j < 6; j++) s += (double)Ai[6 * i + j] * (double)b[j];
     delta[i] = (float)s;
   }
-  if (Ainv_out)
+  if (Ainv_out) {
+#pragma unroll
     for (int i = 0; i < 36; i++) Ainv_out[i] = Ai[i];
+  }
   return ok;
 }
 
