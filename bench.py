@@ -63,8 +63,12 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ          # under torchrun the RCCL path runs even with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
 
     capi = importlib.import_module("uw-slam_amd.capi")
@@ -104,18 +108,18 @@ def main():
     tgt_slots = ref_slots + 1
 
     poses = torch.empty((P, 7), dtype=torch.float32, device=dev)
-    gathered = torch.empty((world * P, 7), dtype=torch.float32, device=dev) if world > 1 else None
+    gathered = torch.empty((world * P, 7), dtype=torch.float32, device=dev) if use_dist else None
 
     def step():
         ctx.track_batch_async(0, 2 * P, ref_slots, tgt_slots, poses.data_ptr())
-        if world > 1:
+        if use_dist:
             ctx.sync()                                     # the context stream is not torch's stream
             dist.all_gather_into_tensor(gathered, poses)   # RCCL gather of the solved poses over xGMI
 
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -132,7 +136,7 @@ def main():
         step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -162,7 +166,7 @@ def main():
                         "dense points%s, %d pairs resident per GPU (%d distinct), pyramids+gradients+alignment per step"
                         % (w, h, args.levels, args.levels - 1, args.iters, ", u16 depth plane" if has_depth else ", z=1",
                            P, U),
-            "normal_equation_accumulation": args.acc, "pairs_per_gpu": P, "sharding": "round-robin pairs, RCCL all_gather of poses" if world > 1 else "single GPU",
+            "normal_equation_accumulation": args.acc, "pairs_per_gpu": P, "sharding": "round-robin pairs, RCCL all_gather of poses" if use_dist else "single GPU",
         },
     }
     if rank == 0:
@@ -206,8 +210,11 @@ def main():
             out["parity"] = {"pairs": n_cpu, "max_rot_rad": float(np.max(dr)), "max_trans_m": float(np.max(dtr)),
                              "bit_identical_poses": bit, "tolerance": "1e-4 rad / 1e-4 m"}
         print(json.dumps(out), flush=True)
+    if use_dist and rank == 0:
+        # the gathered block of this rank must equal its own poses (rank-major layout; pair i of rank r is global r + i*N)
+        assert torch.equal(gathered[rank * P:(rank + 1) * P], poses)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
