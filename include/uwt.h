@@ -168,6 +168,34 @@ int uwt_se3_handoff(uwt_ctx* ctx, float pose_inout[7], int32_t scale_t);
 int uwt_solve_delta(uwt_ctx* ctx, const float A[36], const float b[6], float delta_out[6], float* Ainv_out_or_null,
                     int32_t* nonsingular_out_or_null);
 
+/* ---- sparse point tables (Frame::candidatePoints_[lvl]) -------------------------------------------- */
+
+/* Tracker::EstimatePose / EstimatePoseFeatures over explicit per-level point tables (src/Tracker.cpp:401, 669): tables[l]
+ * is an n_points[l] x 4 host array [x y z w] for every level l in [last_level, first_level] (other entries ignored).
+ * With the EstimatePoseFeatures constants (first = last = 0, max_iters 10, gain 1, z_factor 0.002, handoff_scale_t 1;
+ * src/Tracker.cpp:634-640, 834, 856) this is the reference's live tracking call. */
+int uwt_estimate_pose_points(uwt_ctx* ctx, int32_t ref_slot, int32_t tgt_slot, const float* const* tables,
+                             const int32_t* n_points, float pose_out[7], uwt_stats* stats_out_or_null);
+/* frame->gradient_[lvl] (src/Tracker.cpp:1136-1142): u8 plane copied to the host */
+int uwt_gradient_magnitude(uwt_ctx* ctx, int32_t slot, int32_t lvl, uint8_t* mag_out);
+/* Tracker::ObtainCandidatePoints for one level (src/Tracker.cpp:1314-1362): gradient_ > mean + threshold
+ * (GRADIENT_THRESHOLD = 20, src/Options.cpp:27), x-major order; needs uwt_apply_gradient on the slot first.
+ * Writes min(count, cap) points; *count_out is the full count. */
+int uwt_obtain_candidate_points(uwt_ctx* ctx, int32_t slot, int32_t lvl, double threshold, float* pts_out, int32_t cap,
+                                int32_t* count_out);
+/* Tracker::ObtainPatchesPoints (src/Tracker.cpp:1178-1257): 11x11 level-0 patches around <= 200 key points (x, y). */
+int uwt_obtain_patch_points(uwt_ctx* ctx, int32_t slot, const float* keypoints_xy, int32_t n_keypoints, float* pts_out,
+                            int32_t cap, int32_t* count_out);
+
+/* ---- next to the path: trajectory accumulation (Visualizer::UpdateMessages, src/Visualizer.cpp:304-325) --------- */
+
+/* final_i = final_{i-1} * SE3(q_i, t_scale * t_i), start = previous_pose_ (identity or the ground-truth start,
+ * src/Visualizer.cpp:240-258).  reference_axes != 0 additionally publishes position as (-z, -x, -y) (:318-320).
+ * The reference uses t_scale = 40, reference_axes = 1; (1, 0) is the plain SE(3) prefix product.
+ * poses: n x 7 host floats (per-pair poses from uwt_estimate_pose_batch); traj_out: n x 7 host floats. */
+int uwt_accumulate_trajectory(uwt_ctx* ctx, const float* poses, int32_t n, const float start_pose[7], float t_scale,
+                              int32_t reference_axes, float* traj_out);
+
 #ifdef __cplusplus
 }
 #endif

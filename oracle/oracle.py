@@ -294,3 +294,60 @@ def ls_finish(ls, divide=True):
     (lib().uwo_ls_finish if divide else lib().uwo_ls_finish_no_divide)(C.byref(ls))
     return (np.array(ls.A, np.float32).reshape(6, 6), np.array(ls.b, np.float32), float(ls.error),
             int(ls.num_constraints))
+
+
+def accumulate_trajectory(poses, start=None, t_scale=1.0, reference_axes=False):
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+    start = np.array([0, 0, 0, 1, 0, 0, 0], np.float32) if start is None else np.ascontiguousarray(start, np.float32)
+    out = np.empty_like(poses)
+    lib().uwo_accumulate_trajectory(_p(poses, C.c_float), poses.shape[0], _p(start, C.c_float), C.c_float(t_scale),
+                                    int(bool(reference_axes)), _p(out, C.c_float))
+    return out
+
+
+def align_pair_points(p, ref_gray, tgt_gray, tables, ref_depth=None, want_trace=False):
+    """tables: {level: n x 4 float32 array} for every iterated level."""
+    ref_gray = np.ascontiguousarray(ref_gray, np.uint8)
+    tgt_gray = np.ascontiguousarray(tgt_gray, np.uint8)
+    arrs = {}
+    ptrs = (C.POINTER(C.c_float) * MAX_LEVELS)()
+    counts = (C.c_int32 * MAX_LEVELS)()
+    for l, t in tables.items():
+        arrs[l] = np.ascontiguousarray(t, np.float32).reshape(-1, 4)
+        counts[l] = arrs[l].shape[0]
+        if arrs[l].shape[0]:
+            ptrs[l] = _p(arrs[l], C.c_float)
+    pose = np.empty(7, np.float32)
+    dp = None
+    if ref_depth is not None:
+        ref_depth = np.ascontiguousarray(ref_depth, np.uint16)
+        dp = _p(ref_depth, C.c_uint16)
+    cap = (p.first_level - p.last_level + 1) * p.max_iters if want_trace else 0
+    tr = (Trace * max(cap, 1))()
+    n = C.c_int32(cap)
+    st = lib().uwo_align_pair_points(C.byref(p), _p(ref_gray, C.c_uint8), _p(tgt_gray, C.c_uint8), dp, ptrs, counts,
+                                     _p(pose, C.c_float), tr if want_trace else None, C.byref(n) if want_trace else None)
+    return st, pose, [trace_to_dict(tr[i]) for i in range(n.value)] if want_trace else []
+
+
+def patch_points(kp, depth0, w, h, cap=200 * 144):
+    kp = np.ascontiguousarray(kp, np.float32).reshape(-1, 2)
+    pts = np.empty((cap, 4), np.float32)
+    dp = None
+    if depth0 is not None:
+        depth0 = np.ascontiguousarray(depth0, np.uint16)
+        dp = _p(depth0, C.c_uint16)
+    n = lib().uwo_patch_points(_p(kp, C.c_float), kp.shape[0], dp, w, h, _p(pts, C.c_float), cap)
+    return pts[:min(n, cap)].copy(), n
+
+
+def candidate_points(mag, depth=None, threshold=20.0):
+    mag = np.ascontiguousarray(mag, np.uint8)
+    h, w = mag.shape
+    pts = np.empty((w * h, 4), np.float32)
+    dp = None
+    if depth is not None:
+        depth = np.ascontiguousarray(depth, np.uint16)
+        dp = _p(depth, C.c_uint16)
+    n = lib().uwo_candidate_points(_p(mag, C.c_uint8), dp, w, h, C.c_double(threshold), _p(pts, C.c_float), w * h)
+    return pts[:n].copy(), n

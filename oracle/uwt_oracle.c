@@ -524,6 +524,15 @@ void uwo_solve_delta(const float A[36], const float b[6], float delta[6]) {
 
 int uwo_estimate_pose(const uwo_params* p, const uwo_frame* prev, const uwo_frame* cur,
                       float pose_out[7], uwo_trace* trace, int32_t* n_trace) {
+  return uwo_estimate_pose_points(p, prev, cur, NULL, NULL, pose_out, trace, n_trace);
+}
+
+/* Same loop over explicit per-level point tables (Frame::candidatePoints_[lvl], N x 4): what EstimatePose /
+ * EstimatePoseFeatures consume whichever producer filled them (ObtainAllPoints, ObtainCandidatePoints,
+ * ObtainPatchesPoints).  tables == NULL: dense tables (ObtainAllPoints). */
+int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const uwo_frame* cur,
+                             const float* const* tables, const int32_t* n_points,
+                             float pose_out[7], uwo_trace* trace, int32_t* n_trace) {
   if (p->first_level >= p->n_levels || p->last_level < 0 || p->last_level > p->first_level) return UWO_ERR_INVALID_ARG;
   int cap = (trace && n_trace) ? *n_trace : 0;
   int nt = 0;
@@ -534,6 +543,10 @@ int uwo_estimate_pose(const uwo_params* p, const uwo_frame* prev, const uwo_fram
   uwo_level L0;
   uwo_level_intrinsics(p, p->last_level, &L0);
   size_t nmax = (size_t)L0.w * L0.h;
+  if (tables)
+    for (int l = p->last_level; l <= p->first_level; l++)
+      if ((size_t)n_points[l] > nmax) nmax = (size_t)n_points[l];
+  if (nmax == 0) nmax = 1;
   float* pts = (float*)malloc(sizeof(float) * 4 * nmax);
   float* warped = (float*)malloc(sizeof(float) * 4 * nmax);
   float* J = (float*)malloc(sizeof(float) * 6 * nmax);
@@ -545,7 +558,12 @@ int uwo_estimate_pose(const uwo_params* p, const uwo_frame* prev, const uwo_fram
     uwo_level_intrinsics(p, lvl, &L);
     int n = L.w * L.h;
     float last_error = p->initial_error; /* :393 */
-    uwo_dense_points(p->has_depth ? prev->depth[lvl] : NULL, L.w, L.h, lvl, p->depth_scale, pts); /* :401 */
+    if (tables) {
+      n = n_points[lvl];
+      if (n > 0) memcpy(pts, tables[lvl], sizeof(float) * 4 * (size_t)n); /* :401 candidatePoints_[lvl].clone() */
+    } else {
+      uwo_dense_points(p->has_depth ? prev->depth[lvl] : NULL, L.w, L.h, lvl, p->depth_scale, pts); /* :401 */
+    }
 
     for (int k = 0; k < p->max_iters; k++) { /* :414 */
       uwo_warp(pts, n, pose, &L, warped); /* :422 */
@@ -602,6 +620,12 @@ int uwo_align_pair(const uwo_params* p, const uint8_t* ref_gray, const uint8_t* 
                    const uint16_t* ref_depth, const uint16_t* tgt_depth,
                    float pose_out[7], uwo_trace* trace, int32_t* n_trace) {
   (void)tgt_depth; /* the tracker reads only the previous frame's depth (Tracker.cpp:401) */
+  return uwo_align_pair_points(p, ref_gray, tgt_gray, ref_depth, NULL, NULL, pose_out, trace, n_trace);
+}
+
+int uwo_align_pair_points(const uwo_params* p, const uint8_t* ref_gray, const uint8_t* tgt_gray,
+                          const uint16_t* ref_depth, const float* const* tables, const int32_t* n_points,
+                          float pose_out[7], uwo_trace* trace, int32_t* n_trace) {
   if (p->n_levels < 1 || p->n_levels > UWO_MAX_LEVELS) return UWO_ERR_INVALID_ARG;
   if ((p->width % (1 << (p->n_levels - 1))) || (p->height % (1 << (p->n_levels - 1)))) return UWO_ERR_INVALID_ARG;
   uwo_frame fr[2];
@@ -634,11 +658,82 @@ int uwo_align_pair(const uwo_params* p, const uint8_t* ref_gray, const uint8_t* 
       }
     }
   }
-  int st = uwo_estimate_pose(p, &fr[0], &fr[1], pose_out, trace, n_trace);
+  int st = uwo_estimate_pose_points(p, &fr[0], &fr[1], tables, n_points, pose_out, trace, n_trace);
   for (int f = 0; f < 2; f++)
     for (int l = 0; l < UWO_MAX_LEVELS; l++)
       for (int k = 0; k < 4; k++) free(owned[f][l][k]);
   return st;
+}
+
+/* Tracker::ObtainPatchesPoints, Tracker.cpp:1178-1257 (level 0 only): 11x11 patches ("patch_size_ - 1 / 2" = 5, :1190)
+ * around at most 200 keypoints, x-major inside a patch; with depth the whole patch takes the key point's depth
+ * (at<short>, != 0 test, :1202-1204).  kp: n_kp x 2 (x, y).  Returns the number of points written (<= cap). */
+int uwo_patch_points(const float* kp, int n_kp, const uint16_t* depth0, int w, int h, float* pts, int cap) {
+  const float factor_depth = 0.0002f;
+  const float factor_lvl = (float)(1.0 / pow(2.0, 0.0));
+  const int start_point = 5 - 1 / 2;
+  int n = 0;
+  for (int q = 0; q < (n_kp < 200 ? n_kp : 200); q++) {
+    const float x = kp[2 * q], y = kp[2 * q + 1];
+    float z = 1.0f;
+    if (depth0) {
+      const int16_t d = (int16_t)depth0[(size_t)(int)y * w + (int)x];
+      if (d == 0) continue;
+      z = (float)d * factor_depth * factor_lvl; /* :1204 */
+    }
+    for (int i = (int)(x - (float)start_point); (float)i <= x + (float)start_point; i++)
+      for (int j = (int)(y - (float)start_point); (float)j <= y + (float)start_point; j++)
+        if (i > 0 && i < w && j > 0 && j < h) {
+          if (n < cap) { pts[4 * n] = (float)i; pts[4 * n + 1] = (float)j; pts[4 * n + 2] = z; pts[4 * n + 3] = 1.0f; }
+          n++;
+        }
+  }
+  return n;
+}
+
+/* Tracker::ObtainCandidatePoints, Tracker.cpp:1314-1398, one level: mask = gradient_ > mean(gradient_) + threshold
+ * (cuda::meanStdDev + cuda::threshold THRESH_BINARY, :1324-1329), points pushed x-major (x outer, y inner, :1334-1335),
+ * z = 1 without depth.  With depth the reference indexes the 16-bit image through at<uchar> (:1339, :1344): byte x of
+ * row y, scaled by 0.0002 with no level factor — reproduced as is.  Returns the count (<= cap written). */
+int uwo_candidate_points(const uint8_t* mag, const uint16_t* depth, int w, int h, double threshold, float* pts, int cap) {
+  double sum = 0.0;
+  for (int i = 0; i < w * h; i++) sum += mag[i];
+  const double thres = sum / (double)((size_t)w * h) + threshold;
+  int n = 0;
+  for (int x = 0; x < w; x++)
+    for (int y = 0; y < h; y++) {
+      if (!((double)mag[(size_t)y * w + x] > thres)) continue;
+      float z = 1.0f;
+      if (depth) {
+        const uint8_t b = ((const uint8_t*)(depth + (size_t)y * w))[x];
+        if (b == 0) continue;
+        z = (float)b * 0.0002f;
+      }
+      if (n < cap) { pts[4 * n] = (float)x; pts[4 * n + 1] = (float)y; pts[4 * n + 2] = z; pts[4 * n + 3] = 1.0f; }
+      n++;
+    }
+  return n;
+}
+
+/* Visualizer.cpp:304-325.  SE3(quaternion, t) normalises the quaternion (so3.hpp:431-439, 270-276). */
+void uwo_accumulate_trajectory(const float* poses, int n, const float start[7], float t_scale, int reference_axes,
+                               float* traj_out) {
+  float prev[7];
+  memcpy(prev, start, sizeof(prev));
+  for (int i = 0; i < n; i++) {
+    const float* p = poses + 7 * (size_t)i;
+    float cur[7];
+    float len = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);
+    cur[0] = p[0] / len; cur[1] = p[1] / len; cur[2] = p[2] / len; cur[3] = p[3] / len;
+    cur[4] = t_scale * p[4]; cur[5] = t_scale * p[5]; cur[6] = t_scale * p[6]; /* :307-309 */
+    float fin[7];
+    uwo_se3_mul(prev, cur, fin); /* :313 */
+    memcpy(prev, fin, sizeof(prev)); /* :325 */
+    float* o = traj_out + 7 * (size_t)i;
+    o[0] = fin[0]; o[1] = fin[1]; o[2] = fin[2]; o[3] = fin[3];
+    if (reference_axes) { o[4] = -fin[6]; o[5] = -fin[4]; o[6] = -fin[5]; } /* :318-320 */
+    else { o[4] = fin[4]; o[5] = fin[5]; o[6] = fin[6]; }
+  }
 }
 
 /* ------------------------------------------------------------------------------------------ */

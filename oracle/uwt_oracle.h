@@ -142,10 +142,28 @@ typedef struct uwo_frame {
 int uwo_estimate_pose(const uwo_params* p, const uwo_frame* prev, const uwo_frame* cur,
                       float pose_out[7], uwo_trace* trace, int32_t* n_trace);
 
+/* the same loop over explicit per-level point tables (candidatePoints_[lvl]); tables == NULL: dense */
+int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const uwo_frame* cur,
+                             const float* const* tables, const int32_t* n_points,
+                             float pose_out[7], uwo_trace* trace, int32_t* n_trace);
+/* Tracker::ObtainPatchesPoints (Tracker.cpp:1178-1257) and ObtainCandidatePoints (:1314-1398, one level) */
+int uwo_patch_points(const float* kp, int n_kp, const uint16_t* depth0_or_null, int w, int h, float* pts, int cap);
+int uwo_candidate_points(const uint8_t* mag, const uint16_t* depth_or_null, int w, int h, double threshold, float* pts, int cap);
+
 /* convenience: level-0 images in, pyramid + gradients + EstimatePose; (the CPU-baseline unit of work) */
 int uwo_align_pair(const uwo_params* p, const uint8_t* ref_gray, const uint8_t* tgt_gray,
                    const uint16_t* ref_depth, const uint16_t* tgt_depth,
                    float pose_out[7], uwo_trace* trace, int32_t* n_trace);
+/* same with explicit per-level point tables for the reference frame (NULL: dense) */
+int uwo_align_pair_points(const uwo_params* p, const uint8_t* ref_gray, const uint8_t* tgt_gray,
+                          const uint16_t* ref_depth, const float* const* tables, const int32_t* n_points,
+                          float pose_out[7], uwo_trace* trace, int32_t* n_trace);
+
+/* Visualizer::UpdateMessages pose accumulation, Visualizer.cpp:304-325: final = previous * SE3(q, t_scale * t);
+ * reference_axes != 0 also applies the published position permutation (-z, -x, -y).  traj_out: n x 7.
+ * The reference uses t_scale = 40 and the permutation; (1, 0) is the plain SE(3) prefix product. */
+void uwo_accumulate_trajectory(const float* poses, int n, const float start[7], float t_scale, int reference_axes,
+                               float* traj_out);
 
 /* LS, LeastSquares.cpp:30-209 */
 typedef struct uwo_ls {

@@ -1,0 +1,150 @@
+"""explicit point tables (candidatePoints_) and their producers
+(ObtainPatchesPoints, ObtainCandidatePoints), CPU oracle checks + GPU parity."""
+import importlib
+
+import numpy as np
+import pytest
+
+MID = (131.25, 131.25, 79.5, 47.5)
+FEATURES = dict(n_levels=5, first_level=0, last_level=0, max_iters=10, early_exit=1, gain=1.0, z_factor=0.002,
+                handoff_scale_t=1)   # EstimatePoseFeatures locals, src/Tracker.cpp:634-640, 834, 856
+
+
+def test_oracle_patch_points_semantics(O):
+    w, h = 64, 48
+    kp = np.array([[20.0, 20.0], [2.5, 3.0], [62.9, 46.2], [30.7, 10.2]], np.float32)
+    pts, n = O.patch_points(kp, None, w, h)
+    exp = []
+    for x, y in kp:
+        i = int(np.float32(x) - np.float32(5))
+        while np.float32(i) <= np.float32(x) + np.float32(5):
+            j = int(np.float32(y) - np.float32(5))
+            while np.float32(j) <= np.float32(y) + np.float32(5):
+                if 0 < i < w and 0 < j < h:
+                    exp.append([i, j, 1, 1])
+                j += 1
+            i += 1
+    assert n == len(exp) and np.array_equal(pts, np.array(exp, np.float32))
+    assert (pts[:121, 0] == np.repeat(np.arange(15, 26), 11)).all()       # 11x11, x-major (src/Tracker.cpp:1204-1206)
+    dep = np.zeros((h, w), np.uint16)
+    dep[20, 20] = 5000
+    dep[10, 30] = 40000                                                    # negative as short, still != 0
+    pts, n = O.patch_points(kp, dep, w, h)
+    assert n == 121 + 121 and pts[0, 2] == np.float32(5000) * np.float32(0.0002) * np.float32(1.0)
+    assert pts[121, 2] == np.float32(np.int16(40000 - 65536)) * np.float32(0.0002)
+    many = np.tile(np.array([[20.0, 20.0]], np.float32), (250, 1))
+    assert O.patch_points(many, None, w, h)[1] == 200 * 121               # min(num_max_keypoints, 200)
+
+
+def test_oracle_candidate_points_semantics(O, synth):
+    img = synth.texture(64, 48, seed=4)
+    gx, gy = O.scharr3(img)
+    mag = O.gradient_mag(gx, gy)
+    pts, n = O.candidate_points(mag, None, 20.0)
+    thres = mag.astype(np.float64).mean() + 20.0
+    ys, xs = np.nonzero(mag.T > thres)  # transposed => x-major order
+    assert n == len(xs) and np.array_equal(pts[:, 0], ys) and np.array_equal(pts[:, 1], xs)
+    assert (pts[:, 2] == 1).all() and (pts[:, 3] == 1).all() and 0 < n < mag.size
+    dep = np.full((48, 64), 0x0100, np.uint16)  # bytes: 00 01 00 01 ... => at<uchar>(y, x) is zero for even x
+    ptsd, nd = O.candidate_points(mag, dep, 20.0)
+    assert nd > 0 and (ptsd[:, 0] % 2 == 1).all() and (ptsd[:, 2] == np.float32(1) * np.float32(0.0002)).all()
+
+
+def test_oracle_dense_table_equals_dense_path(O, synth):
+    w, h = 160, 96
+    ref, tgt, _, _, _ = synth.render_pair(w, h, *MID, seed=61)
+    p = O.default_params(w, h, *MID)
+    st0, pose0, tr0 = O.align_pair(p, ref, tgt, want_trace=True)
+    tables = {l: O.dense_points(None, w >> l, h >> l, l) for l in range(1, 5)}
+    st1, pose1, tr1 = O.align_pair_points(p, ref, tgt, tables, want_trace=True)
+    assert st0 == st1 == 0 and np.array_equal(pose0, pose1) and len(tr0) == len(tr1)
+
+
+@pytest.fixture(scope="module")
+def capi():
+    m = importlib.import_module("uw-slam_amd.capi")
+    m.lib()
+    return m
+
+
+def _ctx_pair(capi, synth, w, h, seed, depth=False, **over):
+    ref, tgt, dep, _, _ = synth.render_pair(w, h, *MID, seed=seed, with_depth=depth, z=1.1)
+    if depth:
+        over["has_depth"] = 1
+    ctx = capi.Context(capi.default_params(w, h, *MID, max_frames=2, max_pairs=1, **over))
+    ctx.upload_frames(0, np.stack([ref, tgt]), np.stack([dep, dep]) if depth else None)
+    ctx.build_pyramids(0, 2)
+    ctx.apply_gradient(0, 2)
+    return ctx, ref, tgt, dep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [False, True])
+def test_gpu_producers_bit_exact(capi, O, synth, depth):
+    w, h = 160, 96
+    ctx, ref, tgt, dep = _ctx_pair(capi, synth, w, h, 62, depth)
+    img, dp = ref, dep
+    for lvl in range(5):
+        if lvl:
+            img = O.halve_u8(img)
+            dp = O.halve_u16(dp) if depth else None
+        gx, gy = O.scharr3(img)
+        mag = O.gradient_mag(gx, gy)
+        assert np.array_equal(ctx.gradient_magnitude(0, lvl), mag)
+        for thr in (20.0, 0.0, 300.0):
+            a, na = ctx.obtain_candidate_points(0, lvl, thr)
+            b, nb = O.candidate_points(mag, dp, thr)
+            assert na == nb and np.array_equal(a, b)
+    a, na = ctx.obtain_candidate_points(0, 0, 20.0, cap=10)
+    assert a.shape == (10, 4) and na > 10
+    rng = np.random.default_rng(5)
+    kp = np.concatenate([rng.uniform(0, [w - 0.01, h - 0.01], (230, 2)),
+                         [[0, 0], [w - 1, h - 1], [4.5, 4.5], [5, 5], [w - 5.5, h - 5.5]]]).astype(np.float32)
+    for k in (kp, kp[:7], kp[:0]):
+        a, na = ctx.obtain_patch_points(0, k)
+        b, nb = O.patch_points(k, dep if depth else None, w, h)
+        assert na == nb and np.array_equal(a, b)
+    with pytest.raises(capi.UwtError):
+        ctx.obtain_patch_points(0, np.array([[w + 1.0, 2.0]], np.float32))
+
+
+@pytest.mark.gpu
+def test_gpu_point_table_alignment_matches_dense_and_oracle(capi, O, synth):
+    w, h = 160, 96
+    ctx, ref, tgt, _ = _ctx_pair(capi, synth, w, h, 63)
+    dense, _ = ctx.estimate_pose_batch([0], [1], raise_on_pair_failure=True)
+    tables = {l: O.dense_points(None, w >> l, h >> l, l) for l in range(1, 5)}
+    pose, st = ctx.estimate_pose_points(0, 1, tables)
+    assert st["status"] == 0 and np.array_equal(pose, dense[0])
+    # semi-dense tables from ObtainCandidatePoints on every level, reference schedule
+    cand = {l: ctx.obtain_candidate_points(0, l, 20.0)[0] for l in range(1, 5)}
+    pose, st = ctx.estimate_pose_points(0, 1, cand)
+    p = O.default_params(w, h, *MID)
+    so, pose_cpu, tr = O.align_pair_points(p, ref, tgt, cand, want_trace=True)
+    assert so == 0 and st["status"] == 0 and st["iterations"] == len(tr)
+    assert np.array_equal(pose, pose_cpu)
+    # empty table ⇒ no valid points
+    empty = dict(cand)
+    empty[4] = np.zeros((0, 4), np.float32)
+    pose, st = ctx.estimate_pose_points(0, 1, empty)
+    assert st["status"] == capi.ERR_NO_VALID_POINTS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("depth", [False, True])
+def test_gpu_estimate_pose_features_flow(capi, O, synth, depth):
+    """The reference's live sequence (src/System.cpp:193-223): key points -> ObtainPatchesPoints -> EstimatePoseFeatures."""
+    w, h = 160, 96
+    ctx, ref, tgt, dep = _ctx_pair(capi, synth, w, h, 64, depth, **FEATURES)
+    rng = np.random.default_rng(9)
+    kp = rng.uniform([6, 6], [w - 7, h - 7], (150, 2)).astype(np.float32)   # stand-in for the SURF key points
+    pts, n = ctx.obtain_patch_points(0, kp)
+    assert n == (O.patch_points(kp, dep if depth else None, w, h)[1]) and (depth or n == 150 * 121)  # duplicates allowed
+    pose, st = ctx.estimate_pose_points(0, 1, {0: pts})
+    p = O.default_params(w, h, *MID, **FEATURES)
+    if depth:
+        p.has_depth = 1
+    pts_cpu, _ = O.patch_points(kp, dep if depth else None, w, h)
+    so, pose_cpu, tr = O.align_pair_points(p, ref, tgt, {0: pts_cpu}, ref_depth=dep if depth else None, want_trace=True)
+    assert so == 0 and st["status"] == 0 and st["iterations"] == len(tr) and 1 <= len(tr) <= 10
+    assert np.array_equal(pose, pose_cpu)

@@ -48,7 +48,8 @@ SYMBOLS = [
     "uwt_build_pyramids", "uwt_apply_gradient", "uwt_estimate_pose_batch", "uwt_track_batch_async", "uwt_sync",
     "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
     "uwt_warp", "uwt_residual_jacobian", "uwt_ls_accumulate", "uwt_se3_exp", "uwt_se3_mul", "uwt_se3_matrix",
-    "uwt_se3_handoff", "uwt_solve_delta",
+    "uwt_se3_handoff", "uwt_solve_delta", "uwt_accumulate_trajectory",
+    "uwt_estimate_pose_points", "uwt_gradient_magnitude", "uwt_obtain_candidate_points", "uwt_obtain_patch_points",
 ]
 
 _lib = None
@@ -308,3 +309,51 @@ class Context:
         self._chk(lib().uwt_solve_delta(self._h, _p(A, C.c_float), _p(b, C.c_float), _p(d, C.c_float), _p(Ai, C.c_float),
                                         C.byref(ok)))
         return d, Ai.reshape(6, 6), bool(ok.value)
+
+    def accumulate_trajectory(self, poses, start=None, t_scale=1.0, reference_axes=False):
+        poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
+        start = np.array([0, 0, 0, 1, 0, 0, 0], np.float32) if start is None else np.ascontiguousarray(start, np.float32)
+        out = np.empty_like(poses)
+        self._chk(lib().uwt_accumulate_trajectory(self._h, _p(poses, C.c_float), poses.shape[0], _p(start, C.c_float),
+                                                  C.c_float(t_scale), int(bool(reference_axes)), _p(out, C.c_float)))
+        return out
+
+    def estimate_pose_points(self, ref_slot, tgt_slot, tables):
+        """tables: {level: n x 4 float32 array}"""
+        nl = self.params.n_levels
+        arrs = [None] * nl
+        ptrs = (C.POINTER(C.c_float) * MAX_LEVELS)()
+        counts = (C.c_int32 * MAX_LEVELS)()
+        for l, t in tables.items():
+            arrs[l] = np.ascontiguousarray(t, np.float32).reshape(-1, 4)
+            counts[l] = arrs[l].shape[0]
+            if arrs[l].shape[0]:
+                ptrs[l] = _p(arrs[l], C.c_float)
+        pose = np.empty(7, np.float32)
+        st = Stats()
+        rc = lib().uwt_estimate_pose_points(self._h, ref_slot, tgt_slot, ptrs, counts, _p(pose, C.c_float), C.byref(st))
+        self._chk(rc, allow=(ERR_PAIR_FAILED,))
+        return pose, dict(status=st.status, iterations=st.iterations, n_valid=st.n_valid, error=st.error)
+
+    def gradient_magnitude(self, slot, lvl):
+        L = self.level_info(lvl)
+        out = np.empty((L.h, L.w), np.uint8)
+        self._chk(lib().uwt_gradient_magnitude(self._h, slot, lvl, _p(out, C.c_uint8)))
+        return out
+
+    def obtain_candidate_points(self, slot, lvl, threshold=20.0, cap=None):
+        L = self.level_info(lvl)
+        cap = L.w * L.h if cap is None else cap
+        pts = np.empty((max(cap, 1), 4), np.float32)
+        cnt = C.c_int32()
+        self._chk(lib().uwt_obtain_candidate_points(self._h, slot, lvl, C.c_double(threshold), _p(pts, C.c_float), cap,
+                                                    C.byref(cnt)))
+        return pts[:min(cnt.value, cap)].copy(), cnt.value
+
+    def obtain_patch_points(self, slot, keypoints, cap=200 * 144):
+        kp = np.ascontiguousarray(keypoints, np.float32).reshape(-1, 2)
+        pts = np.empty((max(cap, 1), 4), np.float32)
+        cnt = C.c_int32()
+        self._chk(lib().uwt_obtain_patch_points(self._h, slot, _p(kp, C.c_float), kp.shape[0], _p(pts, C.c_float), cap,
+                                                C.byref(cnt)))
+        return pts[:min(cnt.value, cap)].copy(), cnt.value

@@ -914,4 +914,185 @@ int uwt_solve_delta(uwt_ctx* c, const float A[36], const float b[6], float delta
   return UWT_OK;
 }
 
+int uwt_estimate_pose_points(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, const float* const* tables,
+                             const int32_t* n_points, float pose_out[7], uwt_stats* stats_out) {
+  if (!c || !tables || !n_points || !pose_out) return fail(c, UWT_ERR_INVALID_ARG, "uwt_estimate_pose_points: null argument");
+  const uwt_params& p = c->p;
+  size_t total = 0;
+  for (int l = p.last_level; l <= p.first_level; l++) {
+    // one partial record per 8192 points; the context owns max_slices x max_pairs records
+    if (n_points[l] < 0 || (size_t)n_points[l] > c->partial_records * (size_t)(kBlock * 32) || (n_points[l] > 0 && !tables[l]))
+      return fail(c, UWT_ERR_INVALID_ARG, "uwt_estimate_pose_points: bad table (null, negative or too many points)");
+    total += (size_t)n_points[l];
+  }
+  int st = upload_pairs(c, 1, &ref_slot, &tgt_slot);
+  if (st) return st;
+  st = ensure_scratch(c, std::max<size_t>(16, total * 16));
+  if (st) return st;
+  float4* d_tab[UWT_MAX_LEVELS] = {};
+  size_t off = 0;
+  for (int l = p.last_level; l <= p.first_level; l++) {
+    d_tab[l] = (float4*)c->scratch + off;
+    if (n_points[l]) HIPCHK(c, hipMemcpyAsync(d_tab[l], tables[l], (size_t)n_points[l] * 16, hipMemcpyHostToDevice, c->stream));
+    off += (size_t)n_points[l];
+  }
+  const int tb = 64;
+  hipLaunchKernelGGL(k_init_state, dim3(1), dim3(tb), 0, c->stream, c->state, 1, p.initial_error);
+  HIPCHK(c, hipGetLastError());
+  const bool unit = (p.z_factor == 1.0f && p.angle_factor == 1.0f), acc64 = p.accumulate_f64 != 0;
+  const int per_block = kBlock * 32;
+  for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
+    ResidualArgs ra = residual_args(c, lvl);
+    PointsArgs pa;
+    pa.pts = d_tab[lvl];
+    pa.n_pts = n_points[lvl];
+    pa.pts_per_block = per_block;
+    ra.slices = std::max(1, (pa.n_pts + per_block - 1) / per_block);
+    UpdateArgs ua = update_args(c, lvl);
+    ua.slices = ra.slices;
+    int next_poll = 2;
+    for (int k = 0; k < p.max_iters; k++) {
+      const dim3 grid(ra.slices), blk(kBlock);
+      if (unit && acc64) hipLaunchKernelGGL((k_residual_points<true, false, double>), grid, blk, 0, c->stream, ra, pa);
+      else if (unit) hipLaunchKernelGGL((k_residual_points<true, false, float>), grid, blk, 0, c->stream, ra, pa);
+      else if (acc64) hipLaunchKernelGGL((k_residual_points<false, false, double>), grid, blk, 0, c->stream, ra, pa);
+      else hipLaunchKernelGGL((k_residual_points<false, false, float>), grid, blk, 0, c->stream, ra, pa);
+      HIPCHK(c, hipGetLastError());
+      ua.k = k;
+      const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
+      ua.active = poll ? c->d_active : nullptr;
+      if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
+      hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(64), 0, c->stream, ua);
+      HIPCHK(c, hipGetLastError());
+      if (poll) {
+        HIPCHK(c, hipMemcpyAsync(c->h_active, c->d_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*c->h_active == 0) break;
+        next_poll *= 2;
+      }
+    }
+    hipLaunchKernelGGL(k_level_end, dim3(1), dim3(tb), 0, c->stream, c->state, 1, lvl, p.handoff_scale_t, p.initial_error);
+    HIPCHK(c, hipGetLastError());
+  }
+  hipLaunchKernelGGL(k_write_out, dim3(1), dim3(tb), 0, c->stream, c->state, 1, c->d_poses, c->d_stats);
+  HIPCHK(c, hipGetLastError());
+  uwt_stats tmp;
+  HIPCHK(c, hipMemcpyAsync(pose_out, c->d_poses, sizeof(float) * 7, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(&tmp, c->d_stats, sizeof(tmp), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (stats_out) *stats_out = tmp;
+  if (tmp.status != UWT_OK)
+    return fail(c, UWT_ERR_PAIR_FAILED, std::string("uwt_estimate_pose_points: ") + uwt_status_string(tmp.status));
+  return UWT_OK;
+}
+
+static int mag_to_scratch(uwt_ctx* c, int slot, int lvl, uint8_t** d_mag, unsigned long long** d_sum) {
+  const size_t n = c->lv[lvl].n;
+  int st = ensure_scratch(c, n + 64 + (size_t)c->lv[lvl].n * 16 + 64);
+  if (st) return st;
+  *d_sum = (unsigned long long*)c->scratch;
+  *d_mag = (uint8_t*)c->scratch + 64;
+  HIPCHK(c, hipMemsetAsync(*d_sum, 0, 8, c->stream));
+  const int blocks = (int)std::min<size_t>(1024, (n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_grad_mag, dim3(blocks), dim3(kBlock), 0, c->stream, c->gx[lvl] + slot * n, c->gy[lvl] + slot * n, (int)n,
+                     *d_mag, *d_sum);
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
+int uwt_gradient_magnitude(uwt_ctx* c, int32_t slot, int32_t lvl, uint8_t* mag_out) {
+  if (!c || !mag_out || !slot_range_ok(c, slot, 1) || lvl < 0 || lvl >= c->p.n_levels)
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_gradient_magnitude");
+  uint8_t* d_mag;
+  unsigned long long* d_sum;
+  int st = mag_to_scratch(c, slot, lvl, &d_mag, &d_sum);
+  if (st) return st;
+  HIPCHK(c, hipMemcpyAsync(mag_out, d_mag, c->lv[lvl].n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
+int uwt_obtain_candidate_points(uwt_ctx* c, int32_t slot, int32_t lvl, double threshold, float* pts_out, int32_t cap,
+                                int32_t* count_out) {
+  if (!c || !count_out || cap < 0 || (cap > 0 && !pts_out) || !slot_range_ok(c, slot, 1) || lvl < 0 || lvl >= c->p.n_levels)
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_obtain_candidate_points");
+  uint8_t* d_mag;
+  unsigned long long* d_sum;
+  int st = mag_to_scratch(c, slot, lvl, &d_mag, &d_sum);
+  if (st) return st;
+  unsigned long long sum = 0;
+  HIPCHK(c, hipMemcpyAsync(&sum, d_sum, 8, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const size_t n = c->lv[lvl].n;
+  const double thres = (double)sum / (double)n + threshold;  // cuda::meanStdDev mean + GRADIENT_THRESHOLD (src/Tracker.cpp:1325-1327)
+  const size_t off = (n + 64 + 63) & ~(size_t)63;
+  float4* d_out = (float4*)((uint8_t*)c->scratch + off);
+  int* d_cnt = (int*)c->scratch + 2;
+  const int kcap = (int)std::min<size_t>((size_t)cap, n);
+  hipLaunchKernelGGL(k_candidate_points, dim3(1), dim3(1024), 0, c->stream, d_mag,
+                     c->p.has_depth ? c->depth[lvl] + slot * n : nullptr, c->lv[lvl].w, c->lv[lvl].h, thres, d_out, kcap, d_cnt);
+  HIPCHK(c, hipGetLastError());
+  int cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *count_out = cnt;
+  const int m = std::min(cnt, kcap);
+  if (m > 0) {
+    HIPCHK(c, hipMemcpyAsync(pts_out, d_out, (size_t)m * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return UWT_OK;
+}
+
+int uwt_obtain_patch_points(uwt_ctx* c, int32_t slot, const float* kp, int32_t n_kp, float* pts_out, int32_t cap,
+                            int32_t* count_out) {
+  if (!c || !count_out || n_kp < 0 || (n_kp > 0 && !kp) || cap < 0 || (cap > 0 && !pts_out) || !slot_range_ok(c, slot, 1))
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_obtain_patch_points");
+  const int w = c->lv[0].w, h = c->lv[0].h;
+  for (int i = 0; i < std::min(n_kp, 200); i++)
+    if (!(kp[2 * i] >= 0.f && kp[2 * i] < (float)w && kp[2 * i + 1] >= 0.f && kp[2 * i + 1] < (float)h))
+      return fail(c, UWT_ERR_INVALID_ARG, "uwt_obtain_patch_points: key point outside the image");
+  const int nk = std::min(n_kp, 200);
+  const int kcap = std::min(cap, 200 * 144);
+  int st = ensure_scratch(c, 4096 + (size_t)kcap * 16 + 64);
+  if (st) return st;
+  float2* d_kp = (float2*)((uint8_t*)c->scratch + 64);
+  float4* d_out = (float4*)((uint8_t*)c->scratch + 4096);
+  int* d_cnt = (int*)c->scratch;
+  if (nk) HIPCHK(c, hipMemcpyAsync(d_kp, kp, (size_t)nk * 8, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_patch_points, dim3(1), dim3(256), 0, c->stream, d_kp, nk,
+                     c->p.has_depth ? c->depth[0] + (size_t)slot * c->lv[0].n : nullptr, w, h, d_out, kcap, d_cnt);
+  HIPCHK(c, hipGetLastError());
+  int cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *count_out = cnt;
+  const int m = std::min(cnt, kcap);
+  if (m > 0) {
+    HIPCHK(c, hipMemcpyAsync(pts_out, d_out, (size_t)m * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return UWT_OK;
+}
+
+int uwt_accumulate_trajectory(uwt_ctx* c, const float* poses, int32_t n, const float start_pose[7], float t_scale,
+                              int32_t reference_axes, float* traj_out) {
+  if (!c || !poses || !start_pose || !traj_out || n < 0) return fail(c, UWT_ERR_INVALID_ARG, "uwt_accumulate_trajectory");
+  if (n == 0) return UWT_OK;
+  const size_t bytes = sizeof(float) * 7 * (size_t)n;
+  int st = ensure_scratch(c, 2 * bytes);
+  if (st) return st;
+  float* din = (float*)c->scratch;
+  float* dout = din + 7 * (size_t)n;
+  HIPCHK(c, hipMemcpyAsync(din, poses, bytes, hipMemcpyHostToDevice, c->stream));
+  Pose P;
+  for (int k = 0; k < 4; k++) P.q[k] = start_pose[k];
+  for (int k = 0; k < 3; k++) P.t[k] = start_pose[4 + k];
+  hipLaunchKernelGGL(k_trajectory, dim3(1), dim3(64), 0, c->stream, din, n, P, t_scale, reference_axes, dout);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(traj_out, dout, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
 }  // extern "C"

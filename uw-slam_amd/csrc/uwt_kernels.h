@@ -755,6 +755,220 @@ __global__ __launch_bounds__(kBlock) void k_ls_accumulate(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// explicit point tables (Frame::candidatePoints_[lvl], N x 4 [x y z w]) — what EstimatePose / EstimatePoseFeatures
+// iterate over when a sparse producer filled them (src/Tracker.cpp:401, 669).  Same per-point terms and the same
+// deterministic reduction as the dense kernel; reference values are gathered at ((int)y1, (int)x1) (:471-477).
+// ------------------------------------------------------------------------------------------------------------
+struct PointsArgs {
+  const float4* pts;        // table of this launch's single pair
+  int n_pts;
+  int pts_per_block;
+};
+
+template <bool UNIT_FACTORS, bool DUMP, typename AccT>
+__global__ __launch_bounds__(kBlock) void k_residual_points(const ResidualArgs a, const PointsArgs pa) {
+  const int pair = a.pair_base;
+  Pose pose;
+  if (a.state) {
+    const PairState st = a.state[pair];
+    if (st.level_done || st.status) return;
+    pose = st.pose;
+  } else {
+    pose = a.pose;
+  }
+  WarpK K;
+  pose_to_T12(pose, K.T);
+  const LevelK L = a.L;
+  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
+  const uint8_t* __restrict__ I1 = a.img + ref_off;
+  const uint8_t* __restrict__ I2 = a.img + tgt_off;
+  const int16_t* __restrict__ GX = a.gx + ref_off;
+  const int16_t* __restrict__ GY = a.gy + ref_off;
+  AccT acc[kAccFloats];
+#pragma unroll
+  for (int i = 0; i < kAccFloats; i++) acc[i] = (AccT)0;
+  uint32_t sum_r2 = 0, n_valid = 0;
+  const int p_begin = blockIdx.x * pa.pts_per_block;
+  const int p_end = min(p_begin + pa.pts_per_block, pa.n_pts);
+  for (int q = p_begin + (int)threadIdx.x; q < p_end; q += kBlock) {
+    const float4 P = pa.pts[q];
+    // WarpFunction with the table's own w (src/Tracker.cpp:1439-1467)
+    float X = (P.x - L.cx) * L.invfx; X = X * P.z;
+    float Y = (P.y - L.cy) * L.invfy; Y = Y * P.z;
+    float o[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      float s = K.T[4 * k] * X;
+      s = __builtin_fmaf(K.T[4 * k + 1], Y, s);
+      s = __builtin_fmaf(K.T[4 * k + 2], P.z, s);
+      s = __builtin_fmaf(K.T[4 * k + 3], P.w, s);
+      o[k] = s;
+    }
+    float wq = 0.f * X;
+    wq = __builtin_fmaf(0.f, Y, wq);
+    wq = __builtin_fmaf(0.f, P.z, wq);
+    wq = __builtin_fmaf(1.f, P.w, wq);
+    float x2 = o[0] * L.fx; x2 = x2 / o[2]; x2 = x2 + L.cx; x2 = x2 * wq;
+    float y2 = o[1] * L.fy; y2 = y2 / o[2]; y2 = y2 + L.cy; y2 = y2 * wq;
+    const float z2 = o[2];
+    float iz = 1.0f / z2;
+    bool ok = (y2 > 0.f) && (y2 < (float)L.h) && (x2 > 0.f) && (x2 < (float)L.w) && (z2 != 0.f);
+    const int ix1 = (int)P.x, iy1 = (int)P.y;
+    ok = ok && ix1 >= 0 && ix1 < L.w && iy1 >= 0 && iy1 < L.h;  // the reference would read out of bounds
+    float J[6];
+    int ri = 0;
+    if (ok) {
+      if (iz < 0.f) iz = 0.f;
+      const uint32_t i1x = (uint32_t)(iy1 * L.w + ix1);
+      int ix2 = round_pos(x2), iy2 = round_pos(y2);
+      ix2 = min(ix2, L.w - 1);
+      iy2 = min(iy2, L.h - 1);
+      ri = (int)I2[iy2 * L.w + ix2] - (int)I1[i1x];
+      pixel_jacobian<UNIT_FACTORS>(L, a.zf, a.af, x2, y2, iz, (float)GX[i1x], (float)GY[i1x], J);
+      accumulate(acc, J, ri);
+      sum_r2 += (uint32_t)(ri * ri);
+      n_valid += 1;
+    }
+    if constexpr (DUMP) {
+      if (a.dumpV) a.dumpV[q] = ok ? 1 : 0;
+      if (a.dumpR) a.dumpR[q] = ok ? (float)ri : 0.f;
+      if (a.dumpJ)
+        for (int k = 0; k < 6; k++) a.dumpJ[(size_t)q * 6 + k] = ok ? J[k] : 0.f;
+    }
+  }
+  block_reduce_store<AccT>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + blockIdx.x) * kRecWords);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// sparse point producers
+// ------------------------------------------------------------------------------------------------------------
+
+// gradient_ = addWeighted(convertScaleAbs(gx), 0.5, convertScaleAbs(gy), 0.5) (src/Tracker.cpp:1139-1142), u8,
+// plus its integer sum for cuda::meanStdDev (:1325).  (a + b)/2 with cvRound's round-half-to-even.
+__global__ __launch_bounds__(kBlock) void k_grad_mag(const int16_t* __restrict__ gx, const int16_t* __restrict__ gy, int n,
+                                                     uint8_t* __restrict__ mag, unsigned long long* __restrict__ sum) {
+  unsigned int local = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int ax = min(abs((int)gx[i]), 255), ay = min(abs((int)gy[i]), 255);
+    const int s = ax + ay;
+    int m = s >> 1;
+    if (s & 1) m += (m & 1);
+    mag[i] = (uint8_t)m;
+    local += (unsigned int)m;
+  }
+  __shared__ unsigned int red[kBlock];
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int st = kBlock / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(sum, (unsigned long long)red[0]);  // integer: order-independent
+}
+
+// Ordered compaction, one block: cell c (0 <= c < n_cells) is kept iff keep(c); kept cells are written in cell order.
+// ObtainCandidatePoints order: x outer, y inner (src/Tracker.cpp:1334-1335) => c = x*h + y.
+__global__ __launch_bounds__(1024) void k_candidate_points(const uint8_t* __restrict__ mag, const uint16_t* __restrict__ depth,
+                                                           int w, int h, double thres, float4* __restrict__ out, int cap,
+                                                           int* __restrict__ count) {
+  __shared__ int cnt[1024];
+  const int n_cells = w * h, tid = threadIdx.x;
+  const int per = (n_cells + 1023) / 1024;
+  const int c0 = min(tid * per, n_cells), c1 = min(c0 + per, n_cells);
+  auto keep = [&](int c, float& z) -> bool {
+    const int x = c / h, y = c - x * h;
+    if (!((double)mag[(size_t)y * w + x] > thres)) return false;
+    z = 1.0f;
+    if (depth) {  // the reference indexes the 16-bit plane through at<uchar> (:1339, :1344): byte x of row y
+      const uint8_t b = reinterpret_cast<const uint8_t*>(depth + (size_t)y * w)[x];
+      if (b == 0) return false;
+      z = (float)b * 0.0002f;
+    }
+    return true;
+  };
+  int k = 0;
+  float z;
+  for (int c = c0; c < c1; c++) k += keep(c, z) ? 1 : 0;
+  cnt[tid] = k;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 1024; i++) { const int v = cnt[i]; cnt[i] = run; run += v; }
+    *count = run;
+  }
+  __syncthreads();
+  int o = cnt[tid];
+  for (int c = c0; c < c1; c++)
+    if (keep(c, z)) {
+      const int x = c / h, y = c - x * h;
+      if (o < cap) out[o] = make_float4((float)x, (float)y, z, 1.0f);
+      o++;
+    }
+}
+
+// Tracker::ObtainPatchesPoints (src/Tracker.cpp:1178-1257): level 0, <= 200 key points, 11x11 patches
+// ("patch_size_ - 1 / 2" = 5), x-major inside a patch, key points in order.  One thread per key point counts, a
+// serial prefix orders, the thread then writes its patch.
+__global__ __launch_bounds__(256) void k_patch_points(const float2* __restrict__ kp, int n_kp, const uint16_t* __restrict__ depth0,
+                                                      int w, int h, float4* __restrict__ out, int cap, int* __restrict__ count) {
+  __shared__ int cnt[256];
+  const int q = threadIdx.x;
+  const int start_point = 5;
+  float x = 0.f, y = 0.f, z = 1.0f;
+  bool live = q < n_kp && q < 200;
+  if (live) {
+    x = kp[q].x; y = kp[q].y;
+    if (depth0) {
+      const int d = (int)(int16_t)depth0[(size_t)(int)y * w + (int)x];  // at<short>(y, x) != 0 (:1202)
+      if (d == 0) live = false;
+      z = (float)d * 0.0002f * 1.0f;                                      // * factor_depth * factor_lvl (:1204)
+    }
+  }
+  int k = 0;
+  if (live)
+    for (int i = (int)(x - (float)start_point); (float)i <= x + (float)start_point; i++)
+      for (int j = (int)(y - (float)start_point); (float)j <= y + (float)start_point; j++)
+        if (i > 0 && i < w && j > 0 && j < h) k++;
+  cnt[q] = k;
+  __syncthreads();
+  if (q == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; i++) { const int v = cnt[i]; cnt[i] = run; run += v; }
+    *count = run;
+  }
+  __syncthreads();
+  int o = cnt[q];
+  if (live)
+    for (int i = (int)(x - (float)start_point); (float)i <= x + (float)start_point; i++)
+      for (int j = (int)(y - (float)start_point); (float)j <= y + (float)start_point; j++)
+        if (i > 0 && i < w && j > 0 && j < h) {
+          if (o < cap) out[o] = make_float4((float)i, (float)j, z, 1.0f);
+          o++;
+        }
+}
+
+// Visualizer::UpdateMessages pose accumulation (src/Visualizer.cpp:304-325): final_i = final_{i-1} * SE3(q_i, s·t_i).
+// Strictly sequential (float SE(3) products are not associative to the last bit), one lane; n is a trajectory
+// length, not a pixel count.
+__global__ void k_trajectory(const float* __restrict__ poses, int n, Pose prev, float t_scale, int reference_axes,
+                             float* __restrict__ out) {
+  if (threadIdx.x || blockIdx.x) return;
+  for (int i = 0; i < n; i++) {
+    const float* p = poses + 7 * (size_t)i;
+    Pose cur, fin;
+    const float len = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);  // SE3(q, t) normalises q
+    cur.q[0] = p[0] / len; cur.q[1] = p[1] / len; cur.q[2] = p[2] / len; cur.q[3] = p[3] / len;
+    cur.t[0] = t_scale * p[4]; cur.t[1] = t_scale * p[5]; cur.t[2] = t_scale * p[6];
+    se3_mul(prev, cur, fin);
+    prev = fin;
+    float* o = out + 7 * (size_t)i;
+    o[0] = fin.q[0]; o[1] = fin.q[1]; o[2] = fin.q[2]; o[3] = fin.q[3];
+    if (reference_axes) { o[4] = -fin.t[2]; o[5] = -fin.t[0]; o[6] = -fin.t[1]; }
+    else { o[4] = fin.t[0]; o[5] = fin.t[1]; o[6] = fin.t[2]; }
+  }
+}
+
 __global__ void k_se3_ops(int op, const float* in_a, const float* in_b, float* out, int* flag) {
   if (threadIdx.x || blockIdx.x) return;
   Pose a, b, o;
