@@ -54,6 +54,9 @@ typedef struct uwt_params {
   int32_t handoff_scale_t;   /* 0: EstimatePose (:580-590); 1: EstimatePoseFeatures (:856)               */
   int32_t accumulate_f64;    /* 1 (default): JᵀJ/Jᵀr summed in f64 like cv::gemm on CV_32F (:560-561);  */
                              /* 0: f32 per-thread partial sums (faster, not bit-reproducing the oracle)  */
+  int32_t sampler;           /* 0: nearest neighbour, round() (:472, reference); 1: bilinear (north-star extension)  */
+  int32_t weights;           /* 0: IdentityWeights (:495, :1621); 1: TukeyFunctionWeights with the reference's      */
+                             /* histogram medians (:496, :1571-1654); 2: Huber, k = 1.345 (extension)                */
   int32_t max_frames;        /* frame-slot capacity of the context                                       */
   int32_t max_pairs;         /* largest batch of pairs per call                                          */
   int32_t device;            /* HIP device ordinal                                                       */
@@ -152,6 +155,12 @@ int uwt_warp(uwt_ctx* ctx, int32_t lvl, const float* pts, int32_t n, const float
  * level under `pose`.  Optional per-pixel dumps (level w*h entries, row-major): J_out (x6), r_out, valid_out. */
 int uwt_residual_jacobian(uwt_ctx* ctx, int32_t ref_slot, int32_t tgt_slot, int32_t lvl, const float pose[7],
                           uwt_accum* acc_out, float* J_out_or_null, float* r_out_or_null, uint8_t* valid_out_or_null);
+/* Same under the context's sampler / weights (general path): additionally returns the per-pixel robust weights
+ * (Tracker::TukeyFunctionWeights, src/Tracker.cpp:1626-1654), the scale 1/MAD, the error numerator Σ r·(r·w) and the
+ * accumulators of the weighted system (J <- w·J, r <- gain·r; :554-561): acc_out->jtr then holds Σ(wJ)·(gain·r·w). */
+int uwt_residual_jacobian_weighted(uwt_ctx* ctx, int32_t ref_slot, int32_t tgt_slot, int32_t lvl, const float pose[7],
+                                   uwt_accum* acc_out, double* err_num_out, float* inv_mad_out, float* J_out_or_null,
+                                   float* r_out_or_null, uint8_t* valid_out_or_null, float* w_out_or_null);
 /* LS::initialize + n x LS::update(J, r, w) + LS::finishNoDivide / finish  (src/LeastSquares.cpp:30-37, 204-209,
  * 39-146) on the GPU reduction.  A: 36 row-major, b: 6 (stored sign: b = -Σ w r J), error, count. */
 int uwt_ls_accumulate(uwt_ctx* ctx, const float* J, const float* r, const float* w_or_null, int32_t n, int32_t divide,

@@ -25,7 +25,7 @@ class Params(C.Structure):
         ("epsilon", C.c_float), ("gain", C.c_float), ("z_factor", C.c_float), ("angle_factor", C.c_float),
         ("depth_scale", C.c_float), ("initial_error", C.c_float),
         ("early_exit", C.c_int32), ("has_depth", C.c_int32), ("handoff_scale_t", C.c_int32),
-        ("weights", C.c_int32),
+        ("weights", C.c_int32), ("sampler", C.c_int32),
     ]
 
 
@@ -351,3 +351,34 @@ def candidate_points(mag, depth=None, threshold=20.0):
         dp = _p(depth, C.c_uint16)
     n = lib().uwo_candidate_points(_p(mag, C.c_uint8), dp, w, h, C.c_double(threshold), _p(pts, C.c_float), w * h)
     return pts[:n].copy(), n
+
+
+def bilinear_u8(img, x, y):
+    img = np.ascontiguousarray(img, np.uint8)
+    lib().uwo_bilinear_u8.restype = C.c_float
+    return float(lib().uwo_bilinear_u8(_p(img, C.c_uint8), img.shape[1], img.shape[0], C.c_float(x), C.c_float(y)))
+
+
+def huber_weights(r):
+    r = np.ascontiguousarray(r, np.float32)
+    w = np.empty_like(r)
+    lib().uwo_huber_weights(_p(r, C.c_float), r.size, _p(w, C.c_float))
+    return w
+
+
+def residual_jacobian_ex(img1, img2, gx1, gy1, pts, warped, L, z_factor=1.0, angle_factor=1.0, sampler=0):
+    img1 = np.ascontiguousarray(img1, np.uint8)
+    img2 = np.ascontiguousarray(img2, np.uint8)
+    gx1 = np.ascontiguousarray(gx1, np.int16)
+    gy1 = np.ascontiguousarray(gy1, np.int16)
+    pts = np.ascontiguousarray(pts, np.float32)
+    warped = np.ascontiguousarray(warped, np.float32)
+    n = pts.shape[0]
+    J = np.empty((n, 6), np.float32)
+    r = np.empty(n, np.float32)
+    idx = np.empty(n, np.int32)
+    nv = lib().uwo_residual_jacobian_ex(_p(img1, C.c_uint8), _p(img2, C.c_uint8), _p(gx1, C.c_int16), _p(gy1, C.c_int16),
+                                        _p(pts, C.c_float), _p(warped, C.c_float), n, C.byref(L),
+                                        C.c_float(z_factor), C.c_float(angle_factor), int(sampler),
+                                        _p(J, C.c_float), _p(r, C.c_float), _p(idx, C.c_int32))
+    return J[:nv].copy(), r[:nv].copy(), idx[:nv].copy()

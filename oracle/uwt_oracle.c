@@ -35,6 +35,7 @@ void uwo_default_params(uwo_params* p, int width, int height, float fx, float fy
   p->has_depth = 0;
   p->handoff_scale_t = 0;
   p->weights = UWO_WEIGHTS_IDENTITY;
+  p->sampler = UWO_SAMPLER_NEAREST;
 }
 
 /* Tracker::InitializePyramid, Tracker.cpp:297-340.  fx halves in double then narrows
@@ -324,10 +325,32 @@ void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, 
   }
 }
 
-/* Tracker.cpp:432-490. Returns the number of valid rows written. */
+/* EXTENSION (north star; the reference samples nearest-neighbour only): bilinear interpolation, f32, fixed order. */
+float uwo_bilinear_u8(const uint8_t* img, int w, int h, float x, float y) {
+  float x0 = floorf(x), y0 = floorf(y);
+  float ax = x - x0, ay = y - y0;
+  int ix0 = (int)x0, iy0 = (int)y0;
+  if (ix0 > w - 1) ix0 = w - 1;
+  if (iy0 > h - 1) iy0 = h - 1;
+  int ix1 = ix0 + 1 > w - 1 ? w - 1 : ix0 + 1;
+  int iy1 = iy0 + 1 > h - 1 ? h - 1 : iy0 + 1;
+  float a = (float)img[(size_t)iy0 * w + ix0], b = (float)img[(size_t)iy0 * w + ix1];
+  float c = (float)img[(size_t)iy1 * w + ix0], d = (float)img[(size_t)iy1 * w + ix1];
+  float top = fmaf(ax, b - a, a);
+  float bot = fmaf(ax, d - c, c);
+  return fmaf(ay, bot - top, top);
+}
+
 int uwo_residual_jacobian(const uint8_t* img1, const uint8_t* img2, const int16_t* gx1, const int16_t* gy1,
                           const float* pts, const float* warped, int n, const uwo_level* L,
                           float zf, float af, float* J, float* r, int32_t* idx) {
+  return uwo_residual_jacobian_ex(img1, img2, gx1, gy1, pts, warped, n, L, zf, af, UWO_SAMPLER_NEAREST, J, r, idx);
+}
+
+/* Tracker.cpp:432-490. Returns the number of valid rows written. */
+int uwo_residual_jacobian_ex(const uint8_t* img1, const uint8_t* img2, const int16_t* gx1, const int16_t* gy1,
+                             const float* pts, const float* warped, int n, const uwo_level* L,
+                             float zf, float af, int sampler, float* J, float* r, int32_t* idx) {
   int w = L->w, h = L->h;
   float fx = L->fx, fy = L->fy;
   int nv = 0;
@@ -359,6 +382,7 @@ int uwo_residual_jacobian(const uint8_t* img1, const uint8_t* img2, const int16_
         int i1 = img1[(size_t)iy1 * w + ix1];
         int i2 = img2[(size_t)iy2 * w + ix2];
         float res = (float)(i2 - i1); /* :474 */
+        if (sampler == UWO_SAMPLER_BILINEAR) res = uwo_bilinear_u8(img2, w, h, x2, y2) - (float)i1; /* extension */
         float jl0 = (float)gx1[(size_t)iy1 * w + ix1]; /* :476 */
         float jl1 = (float)gy1[(size_t)iy1 * w + ix1]; /* :477 */
         float* Jr = J + 6 * (size_t)nv;
@@ -429,6 +453,41 @@ void uwo_tukey_weights(const float* r, int n, float* w) {
   }
 }
 
+/* EXTENSION: Huber weights (see header). */
+static float signed_hist_median(const int* q, int n, int lo, int hi) { /* first bin whose cumulative count > n/2 */
+  int nb = hi - lo + 1;
+  int* hist = (int*)calloc((size_t)nb, sizeof(int));
+  for (int i = 0; i < n; i++) {
+    int v = q[i] < lo ? lo : (q[i] > hi ? hi : q[i]);
+    hist[v - lo]++;
+  }
+  float m = (float)(n / 2);
+  int bin = 0;
+  float med = (float)hi;
+  for (int i = 0; i < nb; i++) {
+    bin += hist[i];
+    if ((float)bin > m) { med = (float)(lo + i); break; }
+  }
+  free(hist);
+  return med;
+}
+
+void uwo_huber_weights(const float* r, int n, float* w) {
+  const float k = 1.345f;
+  int* q = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  for (int i = 0; i < n; i++) q[i] = (int)lrintf(r[i]);
+  float med = signed_hist_median(q, n, -255, 255);
+  for (int i = 0; i < n; i++) q[i] = abs(q[i] - (int)med);
+  float MAD = 1.4826f * signed_hist_median(q, n, 0, 510);
+  free(q);
+  if (MAD == 0.0f) MAD = 1.0f;
+  float inv_MAD = (float)(1.0 / (double)MAD);
+  for (int i = 0; i < n; i++) {
+    float ax = fabsf(r[i] * inv_MAD);
+    w[i] = ax <= k ? 1.0f : k / ax;
+  }
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* error, normal equations, solve                                                               */
 /* ------------------------------------------------------------------------------------------ */
@@ -440,7 +499,7 @@ float uwo_error(const float* r, const float* w, int n, int64_t* sum_r2_out) {
   for (int i = 0; i < n; i++) {
     float rw = w ? r[i] * w[i] : r[i];
     s += (double)r[i] * (double)rw;
-    si += (int64_t)r[i] * (int64_t)r[i];
+    si += (int64_t)lrintf(r[i]) * (int64_t)lrintf(r[i]);
   }
   if (sum_r2_out) *sum_r2_out = si;
   float inv_n = (float)(1.0 / (double)n); /* :499 */
@@ -567,11 +626,12 @@ int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const u
 
     for (int k = 0; k < p->max_iters; k++) { /* :414 */
       uwo_warp(pts, n, pose, &L, warped); /* :422 */
-      int nv = uwo_residual_jacobian(prev->img[lvl], cur->img[lvl], prev->gx[lvl], prev->gy[lvl], pts, warped, n, &L,
-                                     p->z_factor, p->angle_factor, J, r, NULL);
+      int nv = uwo_residual_jacobian_ex(prev->img[lvl], cur->img[lvl], prev->gx[lvl], prev->gy[lvl], pts, warped, n, &L,
+                                        p->z_factor, p->angle_factor, p->sampler, J, r, NULL);
       if (nv == 0) { status = UWO_ERR_NO_VALID_POINTS; break; } /* reference: cv::Exception on empty Mat product */
       const float* W = NULL;
       if (p->weights == UWO_WEIGHTS_TUKEY_REFERENCE) { uwo_tukey_weights(r, nv, wts); W = wts; } /* :495-496 */
+      else if (p->weights == UWO_WEIGHTS_HUBER) { uwo_huber_weights(r, nv, wts); W = wts; }        /* extension */
       int64_t sr2 = 0;
       float error = uwo_error(r, W, nv, &sr2); /* :499-502 */
 

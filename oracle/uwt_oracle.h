@@ -49,7 +49,8 @@ enum {
   UWO_ERR_NO_VALID_POINTS = 2
 };
 
-enum { UWO_WEIGHTS_IDENTITY = 0, UWO_WEIGHTS_TUKEY_REFERENCE = 1 };
+enum { UWO_WEIGHTS_IDENTITY = 0, UWO_WEIGHTS_TUKEY_REFERENCE = 1, UWO_WEIGHTS_HUBER = 2 };
+enum { UWO_SAMPLER_NEAREST = 0, UWO_SAMPLER_BILINEAR = 1 };
 
 typedef struct uwo_params {
   int32_t width, height;     /* level-0 size */
@@ -68,6 +69,7 @@ typedef struct uwo_params {
   int32_t has_depth;
   int32_t handoff_scale_t;   /* 0: EstimatePose (:580-590); 1: EstimatePoseFeatures (:856) */
   int32_t weights;           /* UWO_WEIGHTS_* */
+  int32_t sampler;           /* UWO_SAMPLER_* (bilinear is a north-star extension, not in the reference) */
 } uwo_params;
 
 typedef struct uwo_level {
@@ -118,6 +120,15 @@ void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, 
 int uwo_residual_jacobian(const uint8_t* img1, const uint8_t* img2, const int16_t* gx1, const int16_t* gy1,
                           const float* pts, const float* warped, int n, const uwo_level* L,
                           float z_factor, float angle_factor, float* J, float* r, int32_t* idx);
+/* same with a sampler choice (UWO_SAMPLER_*) */
+int uwo_residual_jacobian_ex(const uint8_t* img1, const uint8_t* img2, const int16_t* gx1, const int16_t* gy1,
+                             const float* pts, const float* warped, int n, const uwo_level* L,
+                             float z_factor, float angle_factor, int sampler, float* J, float* r, int32_t* idx);
+/* EXTENSION (not in the reference): bilinear sample of a u8 image at (x, y), 0 < x < w, 0 < y < h; neighbours clamped */
+float uwo_bilinear_u8(const uint8_t* img, int w, int h, float x, float y);
+/* EXTENSION: Huber weights, k = 1.345, scale = 1.4826 * median|q - median q| over q = lrint(r) (signed 511-bin histograms,
+ * the reference's "first bin whose cumulative count exceeds n/2" rule) */
+void  uwo_huber_weights(const float* r, int n, float* w);
 
 /* weights, Tracker.cpp:1571-1654 */
 float uwo_median_mat(const float* v, int n);

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(capi):
 
 def test_struct_layouts_match_header(capi):
     import ctypes as C
-    assert C.sizeof(capi.Params) == 23 * 4
+    assert C.sizeof(capi.Params) == 25 * 4
     assert C.sizeof(capi.Level) == 8 * 4
     assert C.sizeof(capi.Stats) == 16
     assert C.sizeof(capi.Accum) == 21 * 8 + 6 * 8 + 8 + 8

@@ -1,0 +1,155 @@
+"""Robust weights (Tukey as in the reference, src/Tracker.cpp:1571-1654; Huber extension) and the bilinear sampler
+extension: oracle semantics on CPU, GPU parity against the oracle."""
+import importlib
+
+import numpy as np
+import pytest
+
+MID = (131.25, 131.25, 79.5, 47.5)
+
+
+def test_oracle_bilinear_matches_float64_model(O):
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (20, 30), dtype=np.uint8)
+    for _ in range(200):
+        x, y = rng.uniform(0.01, 29.99), rng.uniform(0.01, 19.99)
+        x, y = float(np.float32(x)), float(np.float32(y))
+        x0, y0 = int(np.floor(x)), int(np.floor(y))
+        x1, y1 = min(x0 + 1, 29), min(y0 + 1, 19)
+        ax, ay = x - x0, y - y0
+        ref = (1 - ay) * ((1 - ax) * img[y0, x0] + ax * img[y0, x1]) + ay * ((1 - ax) * img[y1, x0] + ax * img[y1, x1])
+        assert abs(O.bilinear_u8(img, x, y) - ref) < 1e-3
+    assert O.bilinear_u8(img, 5.0, 7.0) == float(img[7, 5])           # integer coordinates hit the pixel exactly
+    assert O.bilinear_u8(img, 29.5, 19.5) == float(img[19, 29])       # last row/column: neighbours clamped
+
+
+def test_oracle_huber_weights(O):
+    r = np.array([-40, -3, -1, 0, 0, 1, 2, 3, 4, 200], np.float32)
+    w = O.huber_weights(r)
+    q = np.rint(r).astype(int)
+    def hist_median(v, lo, hi):
+        v = np.clip(v, lo, hi)
+        m = np.float32(len(v) // 2)
+        cum = 0
+        for b in range(lo, hi + 1):
+            cum += int((v == b).sum())
+            if np.float32(cum) > m:
+                return b
+        return hi
+    med = hist_median(q, -255, 255)
+    mad = np.float32(1.4826) * np.float32(hist_median(np.abs(q - med), 0, 510))
+    ax = np.abs(r * np.float32(1.0 / mad))
+    assert np.allclose(w, np.where(ax <= 1.345, 1.0, 1.345 / np.maximum(ax, 1e-30)), rtol=1e-6)
+    assert (w[[1, 2, 3, 4, 5]] == 1).all() and w[-1] < 0.1
+    assert O.huber_weights(np.zeros(6, np.float32)).tolist() == [1.0] * 6   # MAD 0 => 1
+
+
+def test_oracle_modes_change_the_result_but_stay_finite(O, synth):
+    w, h = 160, 96
+    ref, tgt, _, _, _ = synth.render_pair(w, h, *MID, seed=71)
+    tgt = tgt.copy()
+    tgt[20:40, 50:90] = 255                                              # an outlier block for the robust weights
+    base = dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0)
+    poses = {}
+    for name, over in dict(identity={}, tukey=dict(weights=1), huber=dict(weights=2), bilinear=dict(sampler=1),
+                           bilinear_huber=dict(sampler=1, weights=2)).items():
+        st, pose, tr = O.align_pair(O.default_params(w, h, *MID, **base, **over), ref, tgt, want_trace=True)
+        assert st == 0 and np.isfinite(pose).all() and len(tr) == 24
+        poses[name] = pose
+    assert not np.array_equal(poses["identity"], poses["tukey"])
+    assert not np.array_equal(poses["identity"], poses["bilinear"])
+
+
+@pytest.fixture(scope="module")
+def capi():
+    m = importlib.import_module("uw-slam_amd.capi")
+    m.lib()
+    return m
+
+
+def _setup(capi, synth, w, h, seed, depth=False, outlier=True, **over):
+    ref, tgt, dep, _, _ = synth.render_pair(w, h, *MID, seed=seed, with_depth=depth, z=1.1)
+    tgt = tgt.copy()
+    if outlier:
+        tgt[20:40, 50:90] = 255
+    if depth:
+        over["has_depth"] = 1
+    ctx = capi.Context(capi.default_params(w, h, *MID, max_frames=2, max_pairs=1, **over))
+    ctx.upload_frames(0, np.stack([ref, tgt]), np.stack([dep, dep]) if depth else None)
+    ctx.build_pyramids(0, 2)
+    ctx.apply_gradient(0, 2)
+    return ctx, ref, tgt, dep
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["tukey", "huber", "bilinear", "bilinear_huber", "tukey_depth"])
+def test_gpu_weighted_terms_bit_exact(capi, O, synth, mode):
+    w, h = 160, 96
+    over = dict(tukey=dict(weights=1), huber=dict(weights=2), bilinear=dict(sampler=1),
+                bilinear_huber=dict(sampler=1, weights=2), tukey_depth=dict(weights=1))[mode]
+    depth = mode.endswith("depth")
+    ctx, ref, tgt, dep = _setup(capi, synth, w, h, 72, depth, **over)
+    p = O.default_params(w, h, *MID, **over)
+    rng = np.random.default_rng(4)
+    a_img, b_img, dp = ref, tgt, dep
+    for lvl in range(4):
+        if lvl:
+            a_img, b_img = O.halve_u8(a_img), O.halve_u8(b_img)
+            dp = O.halve_u16(dp) if depth else None
+        L = O.level_intrinsics(p, lvl)
+        gx, gy = O.scharr3(a_img)
+        pts = O.dense_points(dp, L.w, L.h, lvl)
+        pose = O.se3_exp((rng.normal(0, 1, 6) * [0.03, 0.03, 0.01, 0.005, 0.005, 0.02]).astype(np.float32))
+        wp = O.warp(pts, pose, L)
+        J, r, idx = O.residual_jacobian_ex(a_img, b_img, gx, gy, pts, wp, L, sampler=over.get("sampler", 0))
+        wts = {0: None, 1: O.tukey_weights, 2: O.huber_weights}[over.get("weights", 0)]
+        W = wts(r) if wts else None
+        out = ctx.residual_jacobian_weighted(0, 1, lvl, pose)
+        valid = np.zeros(L.w * L.h, np.uint8)
+        valid[idx] = 1
+        assert np.array_equal(out["valid"], valid)
+        assert np.array_equal(out["r"][idx].view(np.uint32), r.view(np.uint32))
+        assert np.array_equal(out["J"][idx].view(np.uint32), J.view(np.uint32))
+        if W is not None:
+            assert np.array_equal(out["w"][idx].view(np.uint32), W.view(np.uint32))
+            assert 0 < (W < 1).sum() < len(W)                     # the weights actually bite
+        A_ref, b_ref = O.normal_equations(J, r, W, 50.0)
+        A_gpu = out["A"].astype(np.float32)
+        b_gpu = (-out["jtr"]).astype(np.float32)
+        assert np.array_equal(A_gpu, A_ref) and np.array_equal(b_gpu, b_ref)
+        e_ref, _ = O.error(r, W)
+        assert np.float32(np.float64(np.float32(1.0 / len(r))) * out["err_num"]) == np.float32(e_ref)
+        assert out["n_valid"] == len(r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["tukey", "huber", "bilinear", "bilinear_huber", "tukey_depth", "tukey_reference_schedule"])
+def test_gpu_alignment_with_weights_and_bilinear_matches_oracle(capi, O, synth, mode):
+    w, h = 160, 96
+    base = dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0)
+    over = dict(tukey=dict(weights=1), huber=dict(weights=2), bilinear=dict(sampler=1),
+                bilinear_huber=dict(sampler=1, weights=2), tukey_depth=dict(weights=1),
+                tukey_reference_schedule=dict(weights=1))[mode]
+    if mode == "tukey_reference_schedule":
+        base = dict()                                             # reference constants incl. early exit
+    depth = mode.endswith("depth")
+    n_ok = 0
+    for seed in (80, 81, 82):
+        ctx, ref, tgt, dep = _setup(capi, synth, w, h, seed, depth, **base, **over)
+        poses, stats = ctx.estimate_pose_batch([0], [1], raise_on_pair_failure=True)
+        p = O.default_params(w, h, *MID, **base, **over)
+        if depth:
+            p.has_depth = 1
+        st, pose_cpu, tr = O.align_pair(p, ref, tgt, dep if depth else None, want_trace=True)
+        assert st == 0 and stats[0]["iterations"] == len(tr)
+        assert np.array_equal(poses[0], pose_cpu)
+        n_ok += 1
+    assert n_ok == 3
+
+
+@pytest.mark.gpu
+def test_gpu_invalid_mode_combinations(capi):
+    with pytest.raises(capi.UwtError):
+        capi.Context(capi.default_params(160, 96, *MID, sampler=1, weights=1))   # reference Tukey medians need integer residuals
+    with pytest.raises(capi.UwtError):
+        capi.Context(capi.default_params(160, 96, *MID, weights=3))

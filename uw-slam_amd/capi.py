@@ -23,7 +23,7 @@ class Params(C.Structure):
         ("epsilon", C.c_float), ("gain", C.c_float), ("z_factor", C.c_float), ("angle_factor", C.c_float),
         ("depth_scale", C.c_float), ("initial_error", C.c_float),
         ("early_exit", C.c_int32), ("has_depth", C.c_int32), ("handoff_scale_t", C.c_int32),
-        ("accumulate_f64", C.c_int32), ("max_frames", C.c_int32), ("max_pairs", C.c_int32), ("device", C.c_int32),
+        ("accumulate_f64", C.c_int32), ("sampler", C.c_int32), ("weights", C.c_int32), ("max_frames", C.c_int32), ("max_pairs", C.c_int32), ("device", C.c_int32),
     ]
 
 
@@ -49,7 +49,7 @@ SYMBOLS = [
     "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
     "uwt_warp", "uwt_residual_jacobian", "uwt_ls_accumulate", "uwt_se3_exp", "uwt_se3_mul", "uwt_se3_matrix",
     "uwt_se3_handoff", "uwt_solve_delta", "uwt_accumulate_trajectory",
-    "uwt_estimate_pose_points", "uwt_gradient_magnitude", "uwt_obtain_candidate_points", "uwt_obtain_patch_points",
+    "uwt_residual_jacobian_weighted", "uwt_estimate_pose_points", "uwt_gradient_magnitude", "uwt_obtain_candidate_points", "uwt_obtain_patch_points",
 ]
 
 _lib = None
@@ -357,3 +357,25 @@ class Context:
         self._chk(lib().uwt_obtain_patch_points(self._h, slot, _p(kp, C.c_float), kp.shape[0], _p(pts, C.c_float), cap,
                                                 C.byref(cnt)))
         return pts[:min(cnt.value, cap)].copy(), cnt.value
+
+    def residual_jacobian_weighted(self, ref_slot, tgt_slot, lvl, pose):
+        pose = np.ascontiguousarray(pose, np.float32)
+        L = self.level_info(lvl)
+        n = L.w * L.h
+        acc = Accum()
+        err, inv_mad = C.c_double(), C.c_float()
+        J = np.empty((n, 6), np.float32)
+        r = np.empty(n, np.float32)
+        v = np.empty(n, np.uint8)
+        w = np.empty(n, np.float32)
+        self._chk(lib().uwt_residual_jacobian_weighted(self._h, ref_slot, tgt_slot, lvl, _p(pose, C.c_float), C.byref(acc),
+                                                       C.byref(err), C.byref(inv_mad), _p(J, C.c_float), _p(r, C.c_float),
+                                                       _p(v, C.c_uint8), _p(w, C.c_float)))
+        A = np.zeros((6, 6))
+        s = 0
+        for i in range(6):
+            for j in range(i, 6):
+                A[i, j] = A[j, i] = acc.A[s]
+                s += 1
+        return dict(A=A, jtr=np.array(acc.jtr), sum_r2=int(acc.sum_r2), n_valid=int(acc.n_valid), J=J, r=r, valid=v, w=w,
+                    err_num=err.value, inv_mad=inv_mad.value)

@@ -41,6 +41,8 @@ struct uwt_ctx {
   size_t partial_records = 0;
   float* d_poses = nullptr;
   StatsOut* d_stats = nullptr;
+  unsigned int* hist = nullptr;         // general path: [pair][2][kHistBins]
+  PairScale* scale = nullptr;           // general path: [pair]
   int* d_active = nullptr;              // early-exit polling counters
   int* h_active = nullptr;              // pinned
   void* scratch = nullptr;              // per-stage entry points
@@ -221,6 +223,45 @@ int prof_collect(uwt_ctx* c) {  // after a stream sync
   return UWT_OK;
 }
 
+GeneralArgs general_args(uwt_ctx* c) {
+  GeneralArgs ga;
+  ga.sampler = c->p.sampler;
+  ga.weights = c->p.weights;
+  ga.stage = 0;
+  ga.gain = c->p.gain;
+  ga.hist = c->hist;
+  ga.scale = c->scale;
+  return ga;
+}
+
+// One residual evaluation on the general path (robust weights and/or bilinear sampler) for pairs [pair_base, +n):
+// with weights on, two histogram passes estimate the scale first (MedianMat / MedianAbsoluteDeviation,
+// src/Tracker.cpp:1571-1619), then the weighted accumulation runs.  Records use one pixel per point and 8192 per block.
+int launch_general(uwt_ctx* c, ResidualArgs ra, int n_pairs) {
+  const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f);
+  GeneralArgs ga = general_args(c);
+  ra.groups_per_block = kBlock * 32;
+  ra.slices = (ra.L.n + ra.groups_per_block - 1) / ra.groups_per_block;
+  const dim3 grid(ra.slices, n_pairs), blk(kBlock);
+  if (ga.weights) {
+    HIPCHK(c, hipMemsetAsync(c->hist + (size_t)ra.pair_base * 2 * kHistBins, 0, sizeof(unsigned int) * 2 * kHistBins * n_pairs, c->stream));
+    for (int stage = 0; stage < 2; stage++) {
+      ga.stage = stage;
+      if (depth) hipLaunchKernelGGL(k_resid_hist<true>, grid, blk, 0, c->stream, ra, ga);
+      else hipLaunchKernelGGL(k_resid_hist<false>, grid, blk, 0, c->stream, ra, ga);
+      HIPCHK(c, hipGetLastError());
+      hipLaunchKernelGGL(k_scale_stage, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, ga, ra.state, n_pairs, ra.pair_base);
+      HIPCHK(c, hipGetLastError());
+    }
+  }
+  if (depth && unit) hipLaunchKernelGGL((k_residual_general<true, true>), grid, blk, 0, c->stream, ra, ga);
+  else if (depth) hipLaunchKernelGGL((k_residual_general<true, false>), grid, blk, 0, c->stream, ra, ga);
+  else if (unit) hipLaunchKernelGGL((k_residual_general<false, true>), grid, blk, 0, c->stream, ra, ga);
+  else hipLaunchKernelGGL((k_residual_general<false, false>), grid, blk, 0, c->stream, ra, ga);
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
 template <int VEC, bool DEPTH, bool UNIT>
 void launch_step_t(hipStream_t s, const ResidualArgs& ra, const UpdateArgs& ua, int n_upd, int n_res, bool acc64) {
   const int blocks = n_upd + n_res * ra.slices;
@@ -327,7 +368,8 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats)
   hipLaunchKernelGGL(k_init_state, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs,
                      p.initial_error);
   HIPCHK(c, hipGetLastError());
-  if (!p.early_exit && c->pipeline && n_pairs >= 2) {
+  const bool general = p.sampler != 0 || p.weights != 0;
+  if (!general && !p.early_exit && c->pipeline && n_pairs >= 2) {
     int st = enqueue_estimate_pipelined(c, n_pairs);
     if (st) return st;
   } else {
@@ -341,12 +383,16 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats)
           int st = prof_begin(c, &ev);
           if (st) return st;
         }
-        int st = launch_residual(c, ra, n_pairs, false);
+        int st = general ? launch_general(c, ra, n_pairs) : launch_residual(c, ra, n_pairs, false);
         if (st) return st;
         if (c->profiling) {
           HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
           c->prof_launches += 1;
           c->prof_pixels += (long long)n_pairs * c->lv[lvl].n;
+        }
+        if (general) {
+          ua.general = 1;
+          ua.slices = (c->lv[lvl].n + kBlock * 32 - 1) / (kBlock * 32);
         }
         ua.k = k;
         const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
@@ -451,6 +497,8 @@ int uwt_default_params(uwt_params* p, int32_t width, int32_t height, float fx, f
   p->has_depth = 0;
   p->handoff_scale_t = 0;
   p->accumulate_f64 = 1;
+  p->sampler = 0;           // nearest neighbour, round() (src/Tracker.cpp:472)
+  p->weights = 0;           // IdentityWeights (src/Tracker.cpp:495)
   p->max_frames = 2;
   p->max_pairs = 1;
   p->device = 0;
@@ -466,6 +514,8 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   if (p->first_level >= p->n_levels || p->last_level < 0 || p->last_level > p->first_level) return UWT_ERR_INVALID_ARG;
   if (p->max_iters < 1 || p->max_frames < 1 || p->max_pairs < 1) return UWT_ERR_INVALID_ARG;
   if ((uint64_t)p->width * p->height * p->width >= 0x100000000ull) return UWT_ERR_INVALID_ARG;
+  if (p->sampler < 0 || p->sampler > 1 || p->weights < 0 || p->weights > 2) return UWT_ERR_INVALID_ARG;
+  if (p->sampler == 1 && p->weights == 1) return UWT_ERR_INVALID_ARG;  // the reference's Tukey medians are defined on integer residuals
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || p->device < 0 || p->device >= ndev) return UWT_ERR_NO_DEVICE;
   hipDeviceProp_t prop;
@@ -516,6 +566,11 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_poses, sizeof(float) * 7 * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_stats, sizeof(StatsOut) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_active, sizeof(int)));
+  if (p->sampler || p->weights) {
+    CREATE_CHK(hipMalloc((void**)&c->hist, sizeof(unsigned int) * 2 * kHistBins * p->max_pairs));
+    CREATE_CHK(hipMalloc((void**)&c->scale, sizeof(PairScale) * p->max_pairs));
+    CREATE_CHK(hipMemset(c->scale, 0, sizeof(PairScale) * p->max_pairs));
+  }
   CREATE_CHK(hipHostMalloc((void**)&c->h_active, sizeof(int)));
   CREATE_CHK(hipHostMalloc((void**)&c->h_pairs, sizeof(int) * 2 * p->max_pairs));
 #undef CREATE_CHK
@@ -540,6 +595,8 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stats) (void)hipFree(c->d_stats);
   if (c->d_active) (void)hipFree(c->d_active);
+  if (c->hist) (void)hipFree(c->hist);
+  if (c->scale) (void)hipFree(c->scale);
   if (c->h_active) (void)hipHostFree(c->h_active);
   if (c->h_pairs) (void)hipHostFree(c->h_pairs);
   if (c->scratch) (void)hipFree(c->scratch);
@@ -834,6 +891,61 @@ int uwt_residual_jacobian(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, int32_
     std::memcpy(&sr2, r + 56, 8);
     acc_out->sum_r2 += sr2;
   }
+  return UWT_OK;
+}
+
+int uwt_residual_jacobian_weighted(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, int32_t lvl, const float pose[7],
+                                   uwt_accum* acc_out, double* err_num_out, float* inv_mad_out, float* J_out, float* r_out,
+                                   uint8_t* valid_out, float* w_out) {
+  if (!c || !pose || !acc_out || lvl < 0 || lvl >= c->p.n_levels || !slot_range_ok(c, ref_slot, 1) || !slot_range_ok(c, tgt_slot, 1))
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_residual_jacobian_weighted");
+  if (!c->p.sampler && !c->p.weights)
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_residual_jacobian_weighted: context uses the nearest/identity fast path");
+  int st = upload_pairs(c, 1, &ref_slot, &tgt_slot);
+  if (st) return st;
+  const size_t n = c->lv[lvl].n;
+  st = ensure_scratch(c, n * (6 * 4 + 4 + 4 + 1) + 512);
+  if (st) return st;
+  Pose P;
+  for (int k = 0; k < 4; k++) P.q[k] = pose[k];
+  for (int k = 0; k < 3; k++) P.t[k] = pose[4 + k];
+  hipLaunchKernelGGL(k_set_pose, dim3(1), dim3(64), 0, c->stream, c->state, P, c->p.initial_error);
+  HIPCHK(c, hipGetLastError());
+  ResidualArgs a = residual_args(c, lvl);
+  a.dumpJ = (float*)c->scratch;
+  a.dumpR = a.dumpJ + 6 * n;
+  a.dumpW = a.dumpR + n;
+  a.dumpV = (uint8_t*)(a.dumpW + n);
+  st = launch_general(c, a, 1);
+  if (st) return st;
+  const int slices = (int)((n + kBlock * 32 - 1) / (kBlock * 32));
+  std::vector<uint32_t> recs((size_t)slices * kRecWords);
+  HIPCHK(c, hipMemcpyAsync(recs.data(), c->partials, recs.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  PairScale sc;
+  std::memset(&sc, 0, sizeof(sc));
+  sc.inv_mad = 1.f;
+  if (c->p.weights) HIPCHK(c, hipMemcpyAsync(&sc, c->scale, sizeof(sc), hipMemcpyDeviceToHost, c->stream));
+  if (J_out) HIPCHK(c, hipMemcpyAsync(J_out, a.dumpJ, n * 24, hipMemcpyDeviceToHost, c->stream));
+  if (r_out) HIPCHK(c, hipMemcpyAsync(r_out, a.dumpR, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (w_out) HIPCHK(c, hipMemcpyAsync(w_out, a.dumpW, n * 4, hipMemcpyDeviceToHost, c->stream));
+  if (valid_out) HIPCHK(c, hipMemcpyAsync(valid_out, a.dumpV, n, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  std::memset(acc_out, 0, sizeof(*acc_out));
+  double err = 0.0;
+  for (int s = 0; s < slices; s++) {
+    const uint32_t* r = recs.data() + (size_t)s * kRecWords;
+    double d[30];
+    std::memcpy(d, r, sizeof(d));
+    for (int k = 0; k < 21; k++) acc_out->A[k] += d[k];
+    for (int k = 0; k < 6; k++) acc_out->jtr[k] += d[21 + k];
+    err += d[29];
+    acc_out->n_valid += (int32_t)r[54];
+    int64_t sr2;
+    std::memcpy(&sr2, r + 56, 8);
+    acc_out->sum_r2 += sr2;
+  }
+  if (err_num_out) *err_num_out = err;
+  if (inv_mad_out) *inv_mad_out = sc.inv_mad;
   return UWT_OK;
 }
 

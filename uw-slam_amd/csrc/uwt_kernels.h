@@ -317,13 +317,13 @@ __device__ __forceinline__ void accumulate(double acc[kAccFloats], const float J
 // the exact sums the reference's double-accumulating gemm produces (src/Tracker.cpp:560-561).
 // Stage 1 transposes 29 rows x 256 threads into LDS; stage 2: 232 threads each fold 32 columns; stage 3: 29
 // threads fold the 8 segment sums and write the 256-B record.
-template <typename AccT>
+template <typename AccT, bool HAS_EXTRA = false>
 __device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], uint32_t sum_r2, uint32_t n_valid,
-                                                   uint32_t* __restrict__ rec) {
+                                                   uint32_t* __restrict__ rec, AccT extra = (AccT)0) {
   constexpr int kPass = 14;  // accumulators per LDS pass (2 passes; keeps the f64 image under 29 KB per block)
   __shared__ AccT red[kPass][kBlock];
   __shared__ uint32_t redi[2][kBlock];
-  __shared__ double seg_f[kAccFloats][8];
+  __shared__ double seg_f[kAccFloats + 1][8];
   __shared__ unsigned long long seg_u[2][8];
   const int tid = threadIdx.x;
   const int v = tid >> 3, seg = tid & 7;
@@ -332,11 +332,11 @@ __device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], u
 #pragma unroll
   for (int pass = 0; pass < 2; pass++) {
     const int base = pass * kPass;
-    const int cnt = pass == 0 ? kPass : kAccFloats - kPass;
+    const int cnt = pass == 0 ? kPass : kAccFloats - kPass + (HAS_EXTRA ? 1 : 0);  // the extra sum rides in pass 1
     if (pass) __syncthreads();
 #pragma unroll
     for (int i = 0; i < kPass; i++)
-      if (i < cnt) red[i][tid] = acc[base + i];
+      if (i < cnt) red[i][tid] = (base + i < kAccFloats) ? acc[base + i < kAccFloats ? base + i : 0] : extra;
     __syncthreads();
     if (v < cnt) {
       double s = 0.0;
@@ -364,6 +364,11 @@ __device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], u
     unsigned long long s = 0;
     for (int k = 0; k < 8; k++) s += seg_u[1][k];
     reinterpret_cast<unsigned long long*>(rec)[28] = s;
+  } else if (HAS_EXTRA && tid == 29) {
+    double s = seg_f[kAccFloats][0];
+#pragma unroll
+    for (int k = 1; k < 8; k++) s += seg_f[kAccFloats][k];
+    reinterpret_cast<double*>(rec)[29] = s;  // Σ r·(r·w): the error numerator when residuals are not integers / weighted
   }
 }
 
@@ -391,6 +396,7 @@ struct ResidualArgs {
   float* dumpJ;             // optional per-pixel dumps (DUMP only)
   float* dumpR;
   uint8_t* dumpV;
+  float* dumpW;             // per-pixel robust weights (general path only)
 };
 
 // reference planes of one group of VEC pixels, as loaded (one vector load per plane)
@@ -525,6 +531,216 @@ __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// General residual path: robust weights (src/Tracker.cpp:495-496, 1571-1654) and the bilinear sampler extension.
+// Not the throughput path — one pixel per thread step, three passes per iteration when weights are on
+// (residual histogram -> median, deviation histogram -> MAD, weighted accumulation).
+// ------------------------------------------------------------------------------------------------------------
+enum { kWeightsIdentity = 0, kWeightsTukeyRef = 1, kWeightsHuber = 2 };
+constexpr int kHistBins = 512;  // signed residual bins q + 255 (0..510) / deviation bins 0..510
+
+struct PairScale {
+  float med0;     // median of the (saturated / signed) residuals
+  float inv_mad;  // 1 / (1.4826 * median deviation), 1 / 1 when that is 0
+  int n_valid;
+  int pad;
+};
+
+struct GeneralArgs {
+  int sampler;            // 0 nearest, 1 bilinear
+  int weights;            // kWeights*
+  int stage;              // histogram kernels: 0 residual bins, 1 deviation bins
+  float gain;
+  unsigned int* hist;     // [pair][2][kHistBins]
+  PairScale* scale;       // [pair]
+};
+
+// EXTENSION: bilinear sample; same f32 operation order as the oracle's uwo_bilinear_u8
+__device__ __forceinline__ float sample_bilinear(const uint8_t* __restrict__ I2, const LevelK& L, float x, float y) {
+  const float x0 = floorf(x), y0 = floorf(y);
+  const float ax = x - x0, ay = y - y0;
+  const int ix0 = min((int)x0, L.w - 1), iy0 = min((int)y0, L.h - 1);
+  const int ix1 = min(ix0 + 1, L.w - 1), iy1 = min(iy0 + 1, L.h - 1);
+  const float a = (float)I2[iy0 * L.w + ix0], b = (float)I2[iy0 * L.w + ix1];
+  const float c = (float)I2[iy1 * L.w + ix0], d = (float)I2[iy1 * L.w + ix1];
+  const float top = __builtin_fmaf(ax, b - a, a);
+  const float bot = __builtin_fmaf(ax, d - c, c);
+  return __builtin_fmaf(ay, bot - top, top);
+}
+
+// one pixel of the dense table: warp, validity, residual (either sampler)
+template <bool DEPTH>
+__device__ __forceinline__ bool general_pixel(const ResidualArgs& a, const LevelK& L, const WarpK& K, int sampler,
+                                              const uint8_t* I1, const uint8_t* I2, const uint16_t* DP, uint32_t idx,
+                                              float& x2, float& y2, float& iz, float& rf) {
+  const uint32_t y = __umulhi(idx, L.magic), x = idx - y * L.w;
+  float z = 1.0f;
+  bool ok = true;
+  if constexpr (DEPTH) {
+    const int d = (int)(int16_t)DP[idx];
+    ok = d > 0;
+    z = (float)d * L.zscale;
+  }
+  uint32_t gidx;
+  bool valid;
+  pixel_warp(L, K, (float)x, (float)y, z, ok, x2, y2, iz, valid, gidx);
+  const int i1 = I1[idx];
+  rf = sampler ? sample_bilinear(I2, L, x2, y2) - (float)i1 : (float)((int)I2[gidx] - i1);
+  return valid;
+}
+
+__device__ __forceinline__ float robust_weight(int mode, float rf, float inv_mad) {
+  if (mode == kWeightsTukeyRef) {  // Tracker::TukeyFunctionWeights, src/Tracker.cpp:1626-1654
+    const float b = 4.6851f;
+    const float inv_b2 = (float)(1.0 / (double)(b * b));
+    const float x = rf * inv_mad;
+    if (fabsf(x) <= b) {
+      const float t = (float)(1.0 - (double)((x * x) * inv_b2));
+      return t * t;
+    }
+    return 0.f;
+  }
+  if (mode == kWeightsHuber) {  // EXTENSION
+    const float k = 1.345f;
+    const float ax = fabsf(rf * inv_mad);
+    return ax <= k ? 1.0f : k / ax;
+  }
+  return 1.0f;
+}
+
+template <bool DEPTH>
+__global__ __launch_bounds__(kBlock) void k_resid_hist(const ResidualArgs a, const GeneralArgs ga) {
+  const int pair = blockIdx.y + a.pair_base;
+  const PairState st = a.state[pair];
+  if (st.level_done || st.status) return;
+  __shared__ unsigned int h[kHistBins];
+  for (int i = threadIdx.x; i < kHistBins; i += kBlock) h[i] = 0;
+  __syncthreads();
+  WarpK K;
+  pose_to_T12(st.pose, K.T);
+  const LevelK L = a.L;
+  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
+  const uint8_t* I1 = a.img + ref_off;
+  const uint8_t* I2 = a.img + tgt_off;
+  const uint16_t* DP = DEPTH ? a.depth + ref_off : nullptr;
+  const float med0 = ga.stage ? ga.scale[pair].med0 : 0.f;
+  const int p_begin = blockIdx.x * a.groups_per_block, p_end = min(p_begin + a.groups_per_block, L.n);
+  for (int p = p_begin + (int)threadIdx.x; p < p_end; p += kBlock) {
+    float x2, y2, iz, rf;
+    if (!general_pixel<DEPTH>(a, L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf)) continue;
+    int bin;
+    if (ga.stage == 0) {
+      const int q = (int)rintf(rf);                       // saturate_cast<uchar> rounds half to even (cvRound)
+      bin = (ga.weights == kWeightsTukeyRef ? max(q, 0) : q) + 255;   // MedianMat saturates negatives to 0 (:1572-1573)
+    } else {
+      if (ga.weights == kWeightsTukeyRef) bin = min((int)rintf(fabsf(rf - med0)), 255);   // abs(_input - median) -> u8 (:1613, 1573)
+      else bin = min(abs((int)rintf(rf) - (int)med0), 510);
+    }
+    atomicAdd(&h[bin], 1u);
+  }
+  __syncthreads();
+  unsigned int* gh = ga.hist + ((size_t)pair * 2 + ga.stage) * kHistBins;
+  for (int i = threadIdx.x; i < kHistBins; i += kBlock)
+    if (h[i]) atomicAdd(&gh[i], h[i]);
+}
+
+// median by the reference's rule (MedianMat, src/Tracker.cpp:1575-1591): first bin whose cumulative count exceeds
+// (float)(n / 2).  Stage 0 -> med0; stage 1 -> MAD = 1.4826 * median deviation (:1607-1619), 0 => 1 (:1634-1637).
+__global__ void k_scale_stage(const GeneralArgs ga, const PairState* state, int n_pairs, int pair_base) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pairs) return;
+  const int pair = i + pair_base;
+  const PairState st = state[pair];
+  if (st.level_done || st.status) return;
+  const unsigned int* gh = ga.hist + ((size_t)pair * 2 + ga.stage) * kHistBins;
+  unsigned int n = 0;
+  for (int b = 0; b < kHistBins; b++) n += gh[b];
+  const float m = (float)(n / 2);
+  unsigned int cum = 0;
+  int med = ga.stage == 0 ? 255 : (ga.weights == kWeightsTukeyRef ? 255 : 510);
+  bool found = false;
+  for (int b = 0; b < kHistBins; b++) {
+    cum += gh[b];
+    if (!found && (float)cum > m) { med = b; found = true; }
+  }
+  PairScale sc = ga.scale[pair];
+  if (ga.stage == 0) {
+    sc.med0 = n ? (float)(med - 255) : 0.f;
+    sc.n_valid = (int)n;
+  } else {
+    float mad = 1.4826f * (float)med;
+    if (!n || mad == 0.f) mad = 1.f;
+    sc.inv_mad = (float)(1.0 / (double)mad);
+  }
+  ga.scale[pair] = sc;
+}
+
+// weighted / bilinear accumulation: J <- w·J, r <- gain·r, A = Σ(wJ)(wJ)ᵀ, jtr = Σ(wJ)·((gain r)·w) (src/Tracker.cpp:554-561),
+// error numerator Σ r·(r·w) (:499-502).  With identity weights this is the plain sum with float residuals.
+template <bool DEPTH, bool UNIT_FACTORS>
+__global__ __launch_bounds__(kBlock) void k_residual_general(const ResidualArgs a, const GeneralArgs ga) {
+  const int pair = blockIdx.y + a.pair_base;
+  Pose pose;
+  if (a.state) {
+    const PairState st = a.state[pair];
+    if (st.level_done || st.status) return;
+    pose = st.pose;
+  } else {
+    pose = a.pose;
+  }
+  WarpK K;
+  pose_to_T12(pose, K.T);
+  const LevelK L = a.L;
+  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
+  const uint8_t* I1 = a.img + ref_off;
+  const uint8_t* I2 = a.img + tgt_off;
+  const int16_t* GX = a.gx + ref_off;
+  const int16_t* GY = a.gy + ref_off;
+  const uint16_t* DP = DEPTH ? a.depth + ref_off : nullptr;
+  const float inv_mad = ga.weights ? ga.scale[pair].inv_mad : 1.f;
+  double acc[kAccFloats];
+#pragma unroll
+  for (int i = 0; i < kAccFloats; i++) acc[i] = 0.0;
+  double err = 0.0;
+  uint32_t sum_r2 = 0, n_valid = 0;
+  const int p_begin = blockIdx.x * a.groups_per_block, p_end = min(p_begin + a.groups_per_block, L.n);
+  for (int p = p_begin + (int)threadIdx.x; p < p_end; p += kBlock) {
+    float x2, y2, iz, rf;
+    const bool ok = general_pixel<DEPTH>(a, L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf);
+    float J[6], w = 1.f;
+    if (ok) {
+      pixel_jacobian<UNIT_FACTORS>(L, a.zf, a.af, x2, y2, iz, (float)GX[p], (float)GY[p], J);
+      w = robust_weight(ga.weights, rf, inv_mad);
+      const float rw1 = rf * w;                 // Residuals.mul(W) for the error (:500)
+      err += (double)rf * (double)rw1;
+      float Jw[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) Jw[k] = w * J[k];   // :556
+      const float rg = rf * ga.gain;            // :559
+      const float rw = rg * w;                  // :561
+      double Jd[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) Jd[k] = (double)Jw[k];
+      int s = 0;
+#pragma unroll
+      for (int i = 0; i < 6; i++)
+#pragma unroll
+        for (int j = i; j < 6; j++, s++) acc[s] = __builtin_fma(Jd[i], Jd[j], acc[s]);
+#pragma unroll
+      for (int i = 0; i < 6; i++) acc[21 + i] = __builtin_fma(Jd[i], (double)rw, acc[21 + i]);
+      const int q = (int)rintf(rf);
+      sum_r2 += (uint32_t)(q * q);
+      n_valid += 1;
+    }
+    if (a.dumpV) a.dumpV[(size_t)pair * L.n + p] = ok ? 1 : 0;
+    if (a.dumpR) a.dumpR[(size_t)pair * L.n + p] = ok ? rf : 0.f;
+    if (a.dumpJ)
+      for (int k = 0; k < 6; k++) a.dumpJ[((size_t)pair * L.n + p) * 6 + k] = ok ? J[k] : 0.f;
+    if (a.dumpW) a.dumpW[(size_t)pair * L.n + p] = ok ? w : 0.f;
+  }
+  block_reduce_store<double, true>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + blockIdx.x) * kRecWords, err);
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // k_gn_update: one wave per pair.  Lanes 0..26 fold the block partials of one accumulator in slice order in
 // f64; lane 0 then runs the scalar tail of the iteration: error (src/Tracker.cpp:499-502), exit test (:508),
 // A/b (:554-561), A.inv()*b (:564), pose <- pose * exp(delta) (:574).
@@ -539,6 +755,7 @@ struct UpdateArgs {
   float epsilon;
   float gain;
   int pair_base;
+  int general;       // 1: records come from k_residual_general (gain already applied, error numerator in slot 29)
   int level_end;     // 1: also run the level hand-off after this update (pipelined schedule)
   int level;
   int scale_t;
@@ -556,6 +773,8 @@ __device__ inline void fold_partials(const uint32_t* __restrict__ recs, int slic
     for (int s = 0; s < slices; s++) isum += recs[(size_t)s * kRecWords + 54];
   } else if (lane == 28) {
     for (int s = 0; s < slices; s++) isum += reinterpret_cast<const long long*>(recs + (size_t)s * kRecWords)[28];
+  } else if (lane == 29) {
+    for (int s = 0; s < slices; s++) colsum += reinterpret_cast<const double*>(recs + (size_t)s * kRecWords)[29];
   }
 }
 
@@ -563,7 +782,7 @@ __device__ inline void fold_partials(const uint32_t* __restrict__ recs, int slic
 // lanes >= 64 only take part in the barrier).
 __device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair) {
   const int lane = threadIdx.x;
-  __shared__ double sums[kAccFloats];
+  __shared__ double sums[kAccFloats + 1];
   __shared__ long long isums[2];
   PairState st = a.state[pair];
   const bool live = !(st.level_done || st.status);  // block-uniform
@@ -573,6 +792,7 @@ __device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair
     fold_partials(a.partials + (size_t)pair * a.slices * kRecWords, a.slices, lane, cs, is);
     if (lane < kAccFloats) sums[lane] = cs;
     else if (lane < 29) isums[lane - 27] = is;
+    else if (lane == 29) sums[kAccFloats] = a.general ? cs : 0.0;
   }
   __syncthreads();
   if (lane != 0) return;
@@ -588,7 +808,8 @@ __device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair
       update = false;
     } else {
       const float inv_n = (float)(1.0 / (double)n);                 // src/Tracker.cpp:499
-      const float error = (float)((double)inv_n * (double)sr2);     // :501, scaled-gemm form
+      const float error = a.general ? (float)((double)inv_n * sums[kAccFloats])   // Σ r·(r·w): float / weighted residuals
+                                    : (float)((double)inv_n * (double)sr2);       // :501, scaled-gemm form (exact integer Σr²)
       st.error = error;
       if (a.early_exit &&
           (error >= st.last_error || a.k == a.max_iters - 1 || fabsf(error - st.last_error) < a.epsilon)) {  // :508
@@ -610,7 +831,8 @@ __device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair
           A[6 * j + i] = v;
         }
 #pragma unroll
-      for (int i = 0; i < 6; i++) b[i] = (float)(-((double)a.gain * sums[21 + i]));  // :559-561
+      for (int i = 0; i < 6; i++)
+        b[i] = a.general ? (float)(-sums[21 + i]) : (float)(-((double)a.gain * sums[21 + i]));  // :559-561
       solve_delta(A, b, delta, nullptr);                                              // :564
       Pose d, np;
       se3_exp(delta, d);                                                              // :574
@@ -644,6 +866,19 @@ __global__ __launch_bounds__(kBlock) void k_step(const ResidualArgs ra, const Up
     const int pair = r / ra.slices;
     residual_block<VEC, DEPTH, UNIT_FACTORS, false, AccT>(ra, pair + ra.pair_base, r - pair * ra.slices);
   }
+}
+
+__global__ void k_set_pose(PairState* state, Pose pose, float initial_error) {
+  if (threadIdx.x || blockIdx.x) return;
+  PairState st;
+  st.pose = pose;
+  st.last_error = initial_error;
+  st.error = 0.f;
+  st.level_done = 0;
+  st.status = 0;
+  st.iters = 0;
+  st.n_valid = 0;
+  state[0] = st;
 }
 
 __global__ void k_init_state(PairState* state, int n, float initial_error) {
