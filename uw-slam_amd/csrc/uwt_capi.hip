@@ -146,7 +146,9 @@ int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int 
 
 template <int VEC, bool DEPTH, bool UNIT, bool DUMP>
 void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64) {
-  if (acc64)
+  if (acc64 && UNIT && VEC == 4 && !DUMP && a.L.fx == a.L.fy)
+    hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, double, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+  else if (acc64)
     hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, double>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
   else
     hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, float>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
@@ -266,7 +268,9 @@ template <int VEC, bool DEPTH, bool UNIT>
 void launch_step_t(hipStream_t s, const ResidualArgs& ra, const UpdateArgs& ua, int n_upd, int n_res, bool acc64) {
   const int blocks = n_upd + n_res * ra.slices;
   if (blocks == 0) return;
-  if (acc64)
+  if (acc64 && UNIT && VEC == 4 && ra.L.fx == ra.L.fy && n_res > 0)
+    hipLaunchKernelGGL((k_step<VEC, DEPTH, UNIT, double, true>), dim3(blocks), dim3(kBlock), 0, s, ra, ua, n_upd);
+  else if (acc64)
     hipLaunchKernelGGL((k_step<VEC, DEPTH, UNIT, double>), dim3(blocks), dim3(kBlock), 0, s, ra, ua, n_upd);
   else
     hipLaunchKernelGGL((k_step<VEC, DEPTH, UNIT, float>), dim3(blocks), dim3(kBlock), 0, s, ra, ua, n_upd);
@@ -1206,5 +1210,13 @@ int uwt_accumulate_trajectory(uwt_ctx* c, const float* poses, int32_t n, const f
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
 }
+
+#ifdef UWT_EXP_CLOCK
+int uwt_debug_read_record(uwt_ctx* c, int32_t pair, int32_t slice, int32_t lvl, uint32_t out[64]) {
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  HIPCHK(c, hipMemcpy(out, c->partials + ((size_t)pair * c->slices[lvl] + slice) * kRecWords, 256, hipMemcpyDeviceToHost));
+  return UWT_OK;
+}
+#endif
 
 }  // extern "C"

@@ -259,21 +259,36 @@ __device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, floa
 }
 
 // Phase 2: Jw (src/Tracker.cpp:455-467) and Jacobian_row = Jl * Jw (:476-479), reference operation order.
-// (Sharing the products that coincide when fx == fy behind a uniform branch was measured: no gain, A/B ±1 %.)
-template <bool UNIT_FACTORS>
+// SQUARE (fx == fy bitwise, decided at launch): (fx*x2) = (fy*x2), (fx*y2) = (fy*y2), fx*iz = fy*iz are the same
+// rounded values, so the reference's products that coincide up to sign are computed once — bit-identical results.
+template <bool UNIT_FACTORS, bool SQUARE = false>
 __device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf, float af, float x2, float y2, float iz, float g0,
                                                float g1, float J[6]) {
   const float fx = L.fx, fy = L.fy;
-  float a0 = fx * iz;
-  float a2 = -(((fx * x2) * iz) * iz);
-  float a3 = -((((fx * x2) * y2) * iz) * iz);
+  float a0, a2, a3, a5, b1, b2, b4, b5;
+  if constexpr (SQUARE) {
+    const float fx2 = fx * x2, fy2 = fx * y2;
+    a0 = fx * iz;
+    b1 = a0;
+    b5 = fx2 * iz;                      // (fy*x2)*iz
+    a2 = -(b5 * iz);                    // -(((fx*x2)*iz)*iz)
+    b4 = ((fx2 * y2) * iz) * iz;        // (((fy*x2)*y2)*iz)*iz
+    a3 = -b4;                           // -((((fx*x2)*y2)*iz)*iz)
+    const float t = fy2 * iz;           // (fy*y2)*iz
+    a5 = -t;                            // ((-fx)*y2)*iz
+    b2 = -(t * iz);                     // -(((fy*y2)*iz)*iz)
+  } else {
+    a0 = fx * iz;
+    a2 = -(((fx * x2) * iz) * iz);
+    a3 = -((((fx * x2) * y2) * iz) * iz);
+    a5 = ((-fx) * y2) * iz;
+    b1 = fy * iz;
+    b2 = -(((fy * y2) * iz) * iz);
+    b4 = (((fy * x2) * y2) * iz) * iz;
+    b5 = (fy * x2) * iz;
+  }
   float a4 = fx * (1.0f + ((x2 * x2) * iz) * iz);
-  float a5 = ((-fx) * y2) * iz;
-  float b1 = fy * iz;
-  float b2 = -(((fy * y2) * iz) * iz);
   float b3 = -(fy * (1.0f + ((y2 * y2) * iz) * iz));
-  float b4 = (((fy * x2) * y2) * iz) * iz;
-  float b5 = (fy * x2) * iz;
   if constexpr (!UNIT_FACTORS) {
     a2 = a2 * zf; a3 = a3 * af; a4 = a4 * af; a5 = a5 * af;
     b2 = b2 * zf; b3 = b3 * af; b4 = b4 * af; b5 = b5 * af;
@@ -429,7 +444,7 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
   }
 }
 
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT>
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false>
 __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int pair, const int slice) {
   Pose pose;
   if (a.state) {
@@ -441,6 +456,9 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   }
   WarpK K;
   pose_to_T12(pose, K.T);
+#pragma unroll
+  for (int i = 0; i < 12; i++)  // the rigid matrix is block-uniform: keep it in scalar registers
+    K.T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(K.T[i])));
   const LevelK L = a.L;
   const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
   const uint8_t* __restrict__ I1 = a.img + ref_off;
@@ -449,6 +467,9 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   const int16_t* __restrict__ GY = a.gy + ref_off;
   const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
 
+#ifdef UWT_EXP_CLOCK
+  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   AccT acc[kAccFloats];
 #pragma unroll
   for (int i = 0; i < kAccFloats; i++) acc[i] = (AccT)0;
@@ -464,57 +485,73 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   int g = g_begin + (int)threadIdx.x;
   load_group<VEC, DEPTH>(nxt, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
   for (int it = 0; it < iters; it++, g += kBlock) {
-    const RefGroup<VEC> cur = nxt;
     const bool active = g < g_end;
     const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
+#ifdef UWT_EXP_NOPREFETCH
+    RefGroup<VEC> cur;
+    load_group<VEC, DEPTH>(cur, I1, GX, GY, DP, idx);
+#else
+    const RefGroup<VEC> cur = nxt;
     if (it + 1 < iters) load_group<VEC, DEPTH>(nxt, I1, GX, GY, DP, (uint32_t)min(g + kBlock, n_groups - 1) * VEC);
+#endif
     const uint32_t y = __umulhi(idx, L.magic);
     const uint32_t x = idx - y * L.w;
     const float yf = (float)y, xf0 = (float)x;
 
-    float x2[VEC], y2[VEC], iz[VEC];
-    bool ok[VEC];
-    uint32_t gidx[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; j++) {
-      float z = 1.0f;
-      bool okin = active;
-      if constexpr (DEPTH) {
-        const int d = (int)(int16_t)cur.dp[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
-        okin = okin && d > 0;
-        z = (float)d * L.zscale;
-      }
-      pixel_warp(L, K, xf0 + (float)j, yf, z, okin, x2[j], y2[j], iz[j], ok[j], gidx[j]);
-    }
-    int i2[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; j++) {
-#if defined(UWT_EXP_NOGATHER) || defined(UWT_EXP_NOMEM)
-      i2[j] = (int)cur.i1[j] + (int)(gidx[j] & 1);
+#ifndef UWT_EXP_PHASE
+    constexpr int PH = VEC;   // pixels in flight per phase (warp -> gather -> Jacobian -> accumulate)
 #else
-      i2[j] = I2[gidx[j]];                        // nearest-neighbour gather of the target level (:472)
+    constexpr int PH = (UWT_EXP_PHASE < VEC) ? UWT_EXP_PHASE : VEC;
 #endif
-    }
-    float J[VEC][6];
 #pragma unroll
-    for (int j = 0; j < VEC; j++) {
-      const float g0 = ok[j] ? (float)cur.gx[j] : 0.f;
-      const float g1 = ok[j] ? (float)cur.gy[j] : 0.f;
-      pixel_jacobian<UNIT_FACTORS>(L, a.zf, a.af, x2[j], y2[j], iz[j], g0, g1, J[j]);
-    }
+    for (int j0 = 0; j0 < VEC; j0 += PH) {
+      float x2[PH], y2[PH], iz[PH];
+      bool ok[PH];
+      uint32_t gidx[PH];
 #pragma unroll
-    for (int j = 0; j < VEC; j++) {
-      const int ri = ok[j] ? i2[j] - (int)cur.i1[j] : 0;
-      accumulate(acc, J[j], ri);
-      sum_r2 += (uint32_t)(ri * ri);
-      n_valid += ok[j] ? 1u : 0u;
-      if constexpr (DUMP) {
-        if (active) {
-          const size_t p = (size_t)pair * L.n + idx + j;
-          if (a.dumpV) a.dumpV[p] = ok[j] ? 1 : 0;
-          if (a.dumpR) a.dumpR[p] = (float)ri;
-          if (a.dumpJ)
-            for (int k = 0; k < 6; k++) a.dumpJ[p * 6 + k] = J[j][k];
+      for (int jj = 0; jj < PH; jj++) {
+        const int j = j0 + jj;
+        float z = 1.0f;
+        bool okin = active;
+        if constexpr (DEPTH) {
+          const int d = (int)(int16_t)cur.dp[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
+          okin = okin && d > 0;
+          z = (float)d * L.zscale;
+        }
+        pixel_warp(L, K, xf0 + (float)j, yf, z, okin, x2[jj], y2[jj], iz[jj], ok[jj], gidx[jj]);
+      }
+      int i2[PH];
+#pragma unroll
+      for (int jj = 0; jj < PH; jj++) {
+#if defined(UWT_EXP_NOGATHER) || defined(UWT_EXP_NOMEM)
+        i2[jj] = (int)cur.i1[j0 + jj] + (int)(gidx[jj] & 1);
+#else
+        i2[jj] = I2[gidx[jj]];                      // nearest-neighbour gather of the target level (:472)
+#endif
+      }
+      float J[PH][6];
+#pragma unroll
+      for (int jj = 0; jj < PH; jj++) {
+        const int j = j0 + jj;
+        const float g0 = ok[jj] ? (float)cur.gx[j] : 0.f;
+        const float g1 = ok[jj] ? (float)cur.gy[j] : 0.f;
+        pixel_jacobian<UNIT_FACTORS, SQUARE>(L, a.zf, a.af, x2[jj], y2[jj], iz[jj], g0, g1, J[jj]);
+      }
+#pragma unroll
+      for (int jj = 0; jj < PH; jj++) {
+        const int j = j0 + jj;
+        const int ri = ok[jj] ? i2[jj] - (int)cur.i1[j] : 0;
+        accumulate(acc, J[jj], ri);
+        sum_r2 += (uint32_t)(ri * ri);
+        n_valid += ok[jj] ? 1u : 0u;
+        if constexpr (DUMP) {
+          if (active) {
+            const size_t p = (size_t)pair * L.n + idx + j;
+            if (a.dumpV) a.dumpV[p] = ok[jj] ? 1 : 0;
+            if (a.dumpR) a.dumpR[p] = (float)ri;
+            if (a.dumpJ)
+              for (int k = 0; k < 6; k++) a.dumpJ[p * 6 + k] = J[jj][k];
+          }
         }
       }
     }
@@ -528,11 +565,23 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
 #else
   block_reduce_store<AccT>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + slice) * kRecWords);
 #endif
+#ifdef UWT_EXP_CLOCK
+  if (threadIdx.x == 0) {  // diagnostic build only: shader-clock and 100 MHz real-time deltas of this block
+    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.partials + ((size_t)pair * a.slices + slice) * kRecWords) + 30;
+    dbg[0] = __builtin_amdgcn_s_memtime() - clk0;
+    dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  }
+#endif
 }
 
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT>
-__global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
-  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
+#ifndef UWT_EXP_WAVES
+#define UWT_RESIDUAL_BOUNDS __launch_bounds__(kBlock)
+#else
+#define UWT_RESIDUAL_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(UWT_EXP_WAVES, UWT_EXP_WAVES)))
+#endif
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false>
+__global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
+  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -861,7 +910,7 @@ __global__ __launch_bounds__(64) void k_gn_update(const UpdateArgs a) { update_b
 // k_step: one launch of the pipelined schedule — the GN update of one half of the batch (blocks [0, n_upd), first
 // wave only) next to the residual evaluation of the other half (remaining blocks, pair-major).  The two halves are
 // independent, so the latency-bound updates hide behind the residual blocks, on a single stream.
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, typename AccT>
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE = false>
 __global__ __launch_bounds__(kBlock) void k_step(const ResidualArgs ra, const UpdateArgs ua, const int n_upd) {
   const int b = blockIdx.x;
   if (b < n_upd) {
@@ -869,7 +918,7 @@ __global__ __launch_bounds__(kBlock) void k_step(const ResidualArgs ra, const Up
   } else {
     const int r = b - n_upd;
     const int pair = r / ra.slices;
-    residual_block<VEC, DEPTH, UNIT_FACTORS, false, AccT>(ra, pair + ra.pair_base, r - pair * ra.slices);
+    residual_block<VEC, DEPTH, UNIT_FACTORS, false, AccT, SQUARE>(ra, pair + ra.pair_base, r - pair * ra.slices);
   }
 }
 
