@@ -149,7 +149,7 @@ def main():
     gpu_poses = poses.cpu().numpy()
 
     out = {
-        "metric": "frame-pair alignments/sec (640x480, 4 pyr lvls)",
+        "metric": "frame-pair alignments/sec (%dx%d, %d pyr lvls)" % (w, h, args.levels),
         "value": round(value, 2),
         "unit": "alignments/s",
         "n_gpus": world,
