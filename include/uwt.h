@@ -196,6 +196,27 @@ int uwt_obtain_candidate_points(uwt_ctx* ctx, int32_t slot, int32_t lvl, double 
 int uwt_obtain_patch_points(uwt_ctx* ctx, int32_t slot, const float* keypoints_xy, int32_t n_keypoints, float* pts_out,
                             int32_t cap, int32_t* count_out);
 
+/* ---- next to the path: frame ingest ---------------------------------------------------------------- */
+
+typedef struct uwt_ingest uwt_ingest;
+
+/* CameraModel::GetCameraModel's rectification setup (src/CameraModel.cpp:84-90): getOptimalNewCameraMatrix(K, dist,
+ * Size(in), 1.0, Size(out)) and initUndistortRectifyMap(K, dist, Mat(), newK, Size(out), CV_16SC2, map1, map2), computed
+ * once on the host and kept on the device.  K and newK_out are (fx, fy, cx, cy); dist is (k1, k2, p1, p2). */
+int uwt_ingest_create(const float K[4], const float dist[4], int32_t in_w, int32_t in_h, int32_t out_w, int32_t out_h,
+                      int32_t device, uwt_ingest** out, float newK_out[4]);
+int uwt_ingest_destroy(uwt_ingest* ing);
+/* the fixed-point maps (out_h x out_w x 2 int16, out_h x out_w uint16), for inspection */
+int uwt_ingest_maps(uwt_ingest* ing, int16_t* map1_out, uint16_t* map2_out);
+/* remap(raw, undistorted, map1, map2, INTER_LINEAR) of a whole frame (src/System.cpp:152, :233) to host memory */
+int uwt_ingest_undistort(uwt_ingest* ing, const uint8_t* raw, size_t row_stride, uint8_t* undistorted_out);
+/* System::CalculateROI (src/System.cpp:148-191) on a raw first frame: roi_out = x, y, w, h */
+int uwt_ingest_calculate_roi(uwt_ingest* ing, const uint8_t* raw_first, size_t row_stride, int32_t roi_out[4]);
+/* remap + crop of System::AddFrame (src/System.cpp:231-235) fused on the GPU: the ctx->width x ctx->height window of the
+ * undistorted frame starting at (x0, y0) lands directly in frame slot `slot` of `ctx` (level 0, image plane). */
+int uwt_ingest_frame(uwt_ingest* ing, uwt_ctx* ctx, int32_t slot, const uint8_t* raw, size_t row_stride, int32_t x0,
+                     int32_t y0);
+
 /* ---- next to the path: trajectory accumulation (Visualizer::UpdateMessages, src/Visualizer.cpp:304-325) --------- */
 
 /* final_i = final_{i-1} * SE3(q_i, t_scale * t_i), start = previous_pose_ (identity or the ground-truth start,

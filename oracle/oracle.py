@@ -382,3 +382,41 @@ def residual_jacobian_ex(img1, img2, gx1, gy1, pts, warped, L, z_factor=1.0, ang
                                         C.c_float(z_factor), C.c_float(angle_factor), int(sampler),
                                         _p(J, C.c_float), _p(r, C.c_float), _p(idx, C.c_int32))
     return J[:nv].copy(), r[:nv].copy(), idx[:nv].copy()
+
+
+def optimal_new_camera_matrix(K4, dist4, in_w, in_h, new_w, new_h, alpha=1.0):
+    K = np.ascontiguousarray(K4, np.float32)
+    d = np.ascontiguousarray(dist4, np.float32)
+    out = np.empty(4, np.float64)
+    lib().uwo_optimal_new_camera_matrix(_p(K, C.c_float), _p(d, C.c_float), in_w, in_h, C.c_double(alpha), new_w, new_h,
+                                        _p(out, C.c_double))
+    return out
+
+
+def init_undistort_maps(K4, dist4, newK4, w, h):
+    K = np.ascontiguousarray(K4, np.float32)
+    d = np.ascontiguousarray(dist4, np.float32)
+    nk = np.ascontiguousarray(newK4, np.float64)
+    m1 = np.empty((h, w, 2), np.int16)
+    m2 = np.empty((h, w), np.uint16)
+    lib().uwo_init_undistort_maps(_p(K, C.c_float), _p(d, C.c_float), _p(nk, C.c_double), w, h, _p(m1, C.c_int16),
+                                  _p(m2, C.c_uint16))
+    return m1, m2
+
+
+def remap_linear(src, m1, m2):
+    src = np.ascontiguousarray(src, np.uint8)
+    m1 = np.ascontiguousarray(m1, np.int16)
+    m2 = np.ascontiguousarray(m2, np.uint16)
+    dh, dw = m2.shape
+    dst = np.empty((dh, dw), np.uint8)
+    lib().uwo_remap_linear(_p(src, C.c_uint8), src.shape[1], src.shape[0], _p(m1, C.c_int16), _p(m2, C.c_uint16), dw, dh,
+                           _p(dst, C.c_uint8))
+    return dst
+
+
+def calculate_roi(und):
+    und = np.ascontiguousarray(und, np.uint8)
+    roi = np.empty(4, np.int32)
+    lib().uwo_calculate_roi(_p(und, C.c_uint8), und.shape[1], und.shape[0], _p(roi, C.c_int32))
+    return roi

@@ -797,6 +797,119 @@ void uwo_accumulate_trajectory(const float* poses, int n, const float start[7], 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* frame ingest (f-2).  OpenCV 3.2: cvUndistortPoints (5 fixed iterations), icvGetRectangles,   */
+/* cvGetOptimalNewCameraMatrix, initUndistortRectifyMap, remap INTER_LINEAR fixed point.        */
+/* ------------------------------------------------------------------------------------------ */
+
+static void undistort_point(double u, double v, const double K[4], const double k[4], const double P[4], float* ox, float* oy) {
+  double x = (u - K[2]) / K[0], y = (v - K[3]) / K[1];
+  const double x0 = x, y0 = y;
+  for (int j = 0; j < 5; j++) {
+    double r2 = x * x + y * y;
+    double icdist = 1.0 / (1.0 + ((0.0 * r2 + k[1]) * r2 + k[0]) * r2);
+    double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+    double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+    x = (x0 - deltaX) * icdist;
+    y = (y0 - deltaY) * icdist;
+  }
+  *ox = (float)(x * P[0] + P[2]);
+  *oy = (float)(y * P[1] + P[3]);
+}
+
+/* CameraModel.cpp:89: getOptimalNewCameraMatrix(K, dist, Size(in), 1.0, Size(out), nullptr, false) */
+void uwo_optimal_new_camera_matrix(const float Kf[4], const float distf[4], int in_w, int in_h, double alpha, int new_w,
+                                   int new_h, double newK[4]) {
+  const double K[4] = {Kf[0], Kf[1], Kf[2], Kf[3]}, k[4] = {distf[0], distf[1], distf[2], distf[3]};
+  const int N = 9;
+  float iX0 = -FLT_MAX, iX1 = FLT_MAX, iY0 = -FLT_MAX, iY1 = FLT_MAX;
+  float oX0 = FLT_MAX, oX1 = -FLT_MAX, oY0 = FLT_MAX, oY1 = -FLT_MAX;
+  for (int y = 0; y < N; y++)
+    for (int x = 0; x < N; x++) {
+      float px = (float)x * in_w / (N - 1), py = (float)y * in_h / (N - 1);
+      float qx, qy;
+      const double Pid[4] = {1.0, 1.0, 0.0, 0.0}; /* icvGetRectangles(K, dist, R = 0, newK = 0, ...): normalised output */
+      undistort_point(px, py, K, k, Pid, &qx, &qy);
+      if (qx < oX0) oX0 = qx;
+      if (qx > oX1) oX1 = qx;
+      if (qy < oY0) oY0 = qy;
+      if (qy > oY1) oY1 = qy;
+      if (x == 0 && qx > iX0) iX0 = qx;
+      if (x == N - 1 && qx < iX1) iX1 = qx;
+      if (y == 0 && qy > iY0) iY0 = qy;
+      if (y == N - 1 && qy < iY1) iY1 = qy;
+    }
+  const float iw = iX1 - iX0, ih = iY1 - iY0, ow = oX1 - oX0, oh = oY1 - oY0;
+  double fx0 = (float)(new_w - 1) / iw, fy0 = (float)(new_h - 1) / ih;
+  double cx0 = -fx0 * iX0, cy0 = -fy0 * iY0;
+  double fx1 = (float)(new_w - 1) / ow, fy1 = (float)(new_h - 1) / oh;
+  double cx1 = -fx1 * oX0, cy1 = -fy1 * oY0;
+  newK[0] = fx0 * (1 - alpha) + fx1 * alpha;
+  newK[1] = fy0 * (1 - alpha) + fy1 * alpha;
+  newK[2] = cx0 * (1 - alpha) + cx1 * alpha;
+  newK[3] = cy0 * (1 - alpha) + cy1 * alpha;
+}
+
+/* CameraModel.cpp:90: initUndistortRectifyMap(K, dist, Mat(), newK, Size(out), CV_16SC2, map1, map2).
+ * INTER_BITS = 5: map1 = integer source coordinates, map2 = (fy << 5) | fx sub-pixel index. */
+void uwo_init_undistort_maps(const float Kf[4], const float distf[4], const double newK[4], int w, int h, int16_t* map1,
+                             uint16_t* map2) {
+  const double fx = Kf[0], fy = Kf[1], u0 = Kf[2], v0 = Kf[3];
+  const double k1 = distf[0], k2 = distf[1], p1 = distf[2], p2 = distf[3];
+  /* ir = inverse of [newfx 0 newcx; 0 newfy newcy; 0 0 1] */
+  const double ir0 = 1.0 / newK[0], ir2 = -newK[2] / newK[0], ir4 = 1.0 / newK[1], ir5 = -newK[3] / newK[1];
+  for (int i = 0; i < h; i++) {
+    double _x = i * 0.0 + ir2, _y = i * ir4 + ir5, _w = 1.0;
+    for (int j = 0; j < w; j++, _x += ir0) {
+      double ww = 1.0 / _w, x = _x * ww, y = _y * ww;
+      double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+      double kr = (1 + ((0.0 * r2 + k2) * r2 + k1) * r2) / (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2);
+      double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2));
+      double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy);
+      double u = fx * xd + u0, v = fy * yd + v0;
+      double su = u * 32.0, sv = v * 32.0;
+      long iu = lrint(su), iv = lrint(sv); /* saturate_cast<int>(double) = cvRound */
+      int su_i = (int)iu >> 5, sv_i = (int)iv >> 5;
+      if (su_i > 32767) su_i = 32767;
+      if (su_i < -32768) su_i = -32768;
+      if (sv_i > 32767) sv_i = 32767;
+      if (sv_i < -32768) sv_i = -32768;
+      map1[2 * ((size_t)i * w + j)] = (int16_t)su_i;
+      map1[2 * ((size_t)i * w + j) + 1] = (int16_t)sv_i;
+      map2[(size_t)i * w + j] = (uint16_t)(((int)iv & 31) * 32 + ((int)iu & 31));
+    }
+  }
+}
+
+/* System.cpp:152 / :233 remap(src, dst, map1, map2, INTER_LINEAR) with BORDER_CONSTANT 0.  Fixed point: weights
+ * (32-fx)(32-fy)·32 etc. (sum 32768, INTER_REMAP_COEF_BITS = 15), value = (Σ w·p + 2^14) >> 15. */
+void uwo_remap_linear(const uint8_t* src, int sw, int sh, const int16_t* map1, const uint16_t* map2, int dw, int dh,
+                      uint8_t* dst) {
+  for (size_t q = 0; q < (size_t)dw * dh; q++) {
+    int sx = map1[2 * q], sy = map1[2 * q + 1];
+    int fxy = map2[q] & 1023, fx = fxy & 31, fy = fxy >> 5;
+    int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+    int p00 = (sx >= 0 && sx < sw && sy >= 0 && sy < sh) ? src[(size_t)sy * sw + sx] : 0;
+    int p01 = (sx + 1 >= 0 && sx + 1 < sw && sy >= 0 && sy < sh) ? src[(size_t)sy * sw + sx + 1] : 0;
+    int p10 = (sx >= 0 && sx < sw && sy + 1 >= 0 && sy + 1 < sh) ? src[(size_t)(sy + 1) * sw + sx] : 0;
+    int p11 = (sx + 1 >= 0 && sx + 1 < sw && sy + 1 >= 0 && sy + 1 < sh) ? src[(size_t)(sy + 1) * sw + sx + 1] : 0;
+    int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+    dst[q] = (uint8_t)(v > 255 ? 255 : v);
+  }
+}
+
+/* System::CalculateROI, System.cpp:148-191: roi = {x, y, w, h} with Rect(p1, p2) semantics (w = p2.x - p1.x). */
+void uwo_calculate_roi(const uint8_t* und, int w, int h, int32_t roi[4]) {
+  int x_middle = (int)((w - 1) * 0.5), y_middle = (int)((h - 1) * 0.5);
+  int p1x = 0, p1y = 0, p2x = w - 1, p2y = h - 1;
+  while (p1x < w - 1 && und[(size_t)y_middle * w + p1x] == 0) p1x++;
+  while (p2x > 0 && und[(size_t)y_middle * w + p2x] == 0) p2x--;
+  while (p1y < h - 1 && und[(size_t)p1y * w + x_middle] == 0) p1y++;
+  while (p2y > 0 && und[(size_t)p2y * w + x_middle] == 0) p2y--;
+  p1x += 5; p2x -= 5; p1y += 5; p2y -= 5; /* :180-183 */
+  roi[0] = p1x; roi[1] = p1y; roi[2] = p2x - p1x; roi[3] = p2y - p1y;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* LS, LeastSquares.cpp:30-209                                                                  */
 /* ------------------------------------------------------------------------------------------ */
 

@@ -176,6 +176,17 @@ int uwo_align_pair_points(const uwo_params* p, const uint8_t* ref_gray, const ui
 void uwo_accumulate_trajectory(const float* poses, int n, const float start[7], float t_scale, int reference_axes,
                                float* traj_out);
 
+/* ---- frame ingest: CameraModel::GetCameraModel (CameraModel.cpp:84-90), System::CalculateROI
+ * (System.cpp:148-191), System::AddFrame remap + crop (System.cpp:231-235).  OpenCV 3.2 calib3d / imgproc algorithms
+ * restated: getOptimalNewCameraMatrix(alpha = 1), initUndistortRectifyMap(CV_16SC2), remap(INTER_LINEAR, border 0). */
+void uwo_optimal_new_camera_matrix(const float K[4], const float dist[4], int in_w, int in_h, double alpha, int new_w,
+                                   int new_h, double newK[4]);
+void uwo_init_undistort_maps(const float K[4], const float dist[4], const double newK[4], int w, int h, int16_t* map1,
+                             uint16_t* map2);
+void uwo_remap_linear(const uint8_t* src, int sw, int sh, const int16_t* map1, const uint16_t* map2, int dw, int dh,
+                      uint8_t* dst);
+void uwo_calculate_roi(const uint8_t* undistorted, int w, int h, int32_t roi[4]);
+
 /* LS, LeastSquares.cpp:30-209 */
 typedef struct uwo_ls {
   float A[36];

@@ -49,7 +49,10 @@ SYMBOLS = [
     "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
     "uwt_warp", "uwt_residual_jacobian", "uwt_ls_accumulate", "uwt_se3_exp", "uwt_se3_mul", "uwt_se3_matrix",
     "uwt_se3_handoff", "uwt_solve_delta", "uwt_accumulate_trajectory",
-    "uwt_residual_jacobian_weighted", "uwt_estimate_pose_points", "uwt_gradient_magnitude", "uwt_obtain_candidate_points", "uwt_obtain_patch_points",
+    "uwt_residual_jacobian_weighted", "uwt_estimate_pose_points", "uwt_gradient_magnitude",
+    "uwt_obtain_candidate_points", "uwt_obtain_patch_points",
+    "uwt_ingest_create", "uwt_ingest_destroy", "uwt_ingest_maps", "uwt_ingest_undistort", "uwt_ingest_calculate_roi",
+    "uwt_ingest_frame",
 ]
 
 _lib = None
@@ -379,3 +382,58 @@ class Context:
                 s += 1
         return dict(A=A, jtr=np.array(acc.jtr), sum_r2=int(acc.sum_r2), n_valid=int(acc.n_valid), J=J, r=r, valid=v, w=w,
                     err_num=err.value, inv_mad=inv_mad.value)
+
+
+class Ingest:
+    """Frame ingest next to the path: undistortion maps + fused remap/crop into a tracker slot."""
+
+    def __init__(self, K4, dist4, in_w, in_h, out_w, out_h, device=0):
+        K = np.ascontiguousarray(K4, np.float32)
+        d = np.ascontiguousarray(dist4, np.float32)
+        self._h = C.c_void_p()
+        nk = np.empty(4, np.float32)
+        st = lib().uwt_ingest_create(_p(K, C.c_float), _p(d, C.c_float), in_w, in_h, out_w, out_h, device, C.byref(self._h),
+                                     _p(nk, C.c_float))
+        if st:
+            raise UwtError(st, lib().uwt_status_string(st).decode())
+        self.newK = nk
+        self.in_w, self.in_h, self.out_w, self.out_h = in_w, in_h, out_w, out_h
+
+    def close(self):
+        if self._h:
+            lib().uwt_ingest_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, st):
+        if st:
+            raise UwtError(st, lib().uwt_status_string(st).decode())
+
+    def maps(self):
+        m1 = np.empty((self.out_h, self.out_w, 2), np.int16)
+        m2 = np.empty((self.out_h, self.out_w), np.uint16)
+        self._chk(lib().uwt_ingest_maps(self._h, _p(m1, C.c_int16), _p(m2, C.c_uint16)))
+        return m1, m2
+
+    def undistort(self, raw):
+        raw = np.asarray(raw)
+        assert raw.dtype == np.uint8 and raw.shape == (self.in_h, self.in_w) and raw.strides[1] == 1
+        out = np.empty((self.out_h, self.out_w), np.uint8)
+        self._chk(lib().uwt_ingest_undistort(self._h, _p(raw, C.c_uint8), C.c_size_t(raw.strides[0]), _p(out, C.c_uint8)))
+        return out
+
+    def calculate_roi(self, raw_first):
+        raw = np.asarray(raw_first)
+        roi = np.empty(4, np.int32)
+        self._chk(lib().uwt_ingest_calculate_roi(self._h, _p(raw, C.c_uint8), C.c_size_t(raw.strides[0]), _p(roi, C.c_int32)))
+        return roi
+
+    def frame(self, ctx, slot, raw, x0, y0):
+        raw = np.asarray(raw)
+        assert raw.dtype == np.uint8 and raw.shape == (self.in_h, self.in_w) and raw.strides[1] == 1
+        self._chk(lib().uwt_ingest_frame(self._h, ctx._h, slot, _p(raw, C.c_uint8), C.c_size_t(raw.strides[0]), x0, y0))

@@ -1191,6 +1191,196 @@ int uwt_obtain_patch_points(uwt_ctx* c, int32_t slot, const float* kp, int32_t n
   return UWT_OK;
 }
 
+/* ---- frame ingest ------------------------------------------------------------------------------------------------- */
+
+struct uwt_ingest {
+  int in_w, in_h, out_w, out_h, device;
+  double newK[4];
+  std::vector<int16_t> h_map1;
+  std::vector<uint16_t> h_map2;
+  short2* d_map1 = nullptr;
+  uint16_t* d_map2 = nullptr;
+  uint8_t* d_raw = nullptr;
+  uint8_t* d_und = nullptr;
+  hipStream_t stream = nullptr;
+};
+
+namespace {
+
+// cvUndistortPoints with 5 fixed iterations and no rectification/projection (normalised output), as
+// icvGetRectangles calls it from cvGetOptimalNewCameraMatrix (OpenCV 3.2 calib3d).
+void undistort_normalised(double u, double v, const double K[4], const double k[4], float* ox, float* oy) {
+  double x = (u - K[2]) / K[0], y = (v - K[3]) / K[1];
+  const double x0 = x, y0 = y;
+  for (int j = 0; j < 5; j++) {
+    const double r2 = x * x + y * y;
+    const double icdist = 1.0 / (1.0 + ((0.0 * r2 + k[1]) * r2 + k[0]) * r2);
+    const double dX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x);
+    const double dY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y;
+    x = (x0 - dX) * icdist;
+    y = (y0 - dY) * icdist;
+  }
+  *ox = (float)x;
+  *oy = (float)y;
+}
+
+// getOptimalNewCameraMatrix(K, dist, Size(in), alpha = 1, Size(out), nullptr, false)  (src/CameraModel.cpp:89)
+void optimal_new_camera_matrix(const double K[4], const double k[4], int in_w, int in_h, double alpha, int new_w, int new_h,
+                               double newK[4]) {
+  const int N = 9;
+  float iX0 = -3.4028235e38f, iX1 = 3.4028235e38f, iY0 = -3.4028235e38f, iY1 = 3.4028235e38f;
+  float oX0 = 3.4028235e38f, oX1 = -3.4028235e38f, oY0 = 3.4028235e38f, oY1 = -3.4028235e38f;
+  for (int y = 0; y < N; y++)
+    for (int x = 0; x < N; x++) {
+      const float px = (float)x * in_w / (N - 1), py = (float)y * in_h / (N - 1);
+      float qx, qy;
+      undistort_normalised(px, py, K, k, &qx, &qy);
+      oX0 = std::min(oX0, qx); oX1 = std::max(oX1, qx); oY0 = std::min(oY0, qy); oY1 = std::max(oY1, qy);
+      if (x == 0) iX0 = std::max(iX0, qx);
+      if (x == N - 1) iX1 = std::min(iX1, qx);
+      if (y == 0) iY0 = std::max(iY0, qy);
+      if (y == N - 1) iY1 = std::min(iY1, qy);
+    }
+  const float iw = iX1 - iX0, ih = iY1 - iY0, ow = oX1 - oX0, oh = oY1 - oY0;
+  const double fx0 = (float)(new_w - 1) / iw, fy0 = (float)(new_h - 1) / ih;
+  const double cx0 = -fx0 * iX0, cy0 = -fy0 * iY0;
+  const double fx1 = (float)(new_w - 1) / ow, fy1 = (float)(new_h - 1) / oh;
+  const double cx1 = -fx1 * oX0, cy1 = -fy1 * oY0;
+  newK[0] = fx0 * (1 - alpha) + fx1 * alpha;
+  newK[1] = fy0 * (1 - alpha) + fy1 * alpha;
+  newK[2] = cx0 * (1 - alpha) + cx1 * alpha;
+  newK[3] = cy0 * (1 - alpha) + cy1 * alpha;
+}
+
+// initUndistortRectifyMap(K, dist, Mat(), newK, size, CV_16SC2, map1, map2)  (src/CameraModel.cpp:90)
+void init_undistort_maps(const double K[4], const double k[4], const double newK[4], int w, int h, int16_t* map1,
+                         uint16_t* map2) {
+  const double ir0 = 1.0 / newK[0], ir2 = -newK[2] / newK[0], ir4 = 1.0 / newK[1], ir5 = -newK[3] / newK[1];
+  for (int i = 0; i < h; i++) {
+    double _x = i * 0.0 + ir2;
+    const double _y = i * ir4 + ir5, _w = 1.0;
+    for (int j = 0; j < w; j++, _x += ir0) {
+      const double ww = 1.0 / _w, x = _x * ww, y = _y * ww;
+      const double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+      const double kr = (1 + ((0.0 * r2 + k[1]) * r2 + k[0]) * r2) / (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2);
+      const double xd = (x * kr + k[2] * _2xy + k[3] * (r2 + 2 * x2));
+      const double yd = (y * kr + k[2] * (r2 + 2 * y2) + k[3] * _2xy);
+      const double u = K[0] * xd + K[2], v = K[1] * yd + K[3];
+      const long iu = std::lrint(u * 32.0), iv = std::lrint(v * 32.0);
+      const int su = std::max(-32768, std::min(32767, (int)iu >> 5)), sv = std::max(-32768, std::min(32767, (int)iv >> 5));
+      map1[2 * ((size_t)i * w + j)] = (int16_t)su;
+      map1[2 * ((size_t)i * w + j) + 1] = (int16_t)sv;
+      map2[(size_t)i * w + j] = (uint16_t)(((int)iv & 31) * 32 + ((int)iu & 31));
+    }
+  }
+}
+
+#define ING_CHK(expr)                              \
+  do {                                             \
+    if ((expr) != hipSuccess) return UWT_ERR_HIP;  \
+  } while (0)
+
+int ingest_remap(uwt_ingest* g, const uint8_t* raw, size_t stride, int x0, int y0, int cw, int ch, uint8_t* d_dst) {
+  ING_CHK(hipSetDevice(g->device));
+  ING_CHK(hipMemcpy2DAsync(g->d_raw, g->in_w, raw, stride, g->in_w, g->in_h, hipMemcpyHostToDevice, g->stream));
+  hipLaunchKernelGGL(k_remap_crop, dim3((cw * ch + kBlock - 1) / kBlock), dim3(kBlock), 0, g->stream, g->d_raw, g->in_w,
+                     g->in_h, (size_t)g->in_w, g->d_map1, g->d_map2, g->out_w, x0, y0, d_dst, cw, ch);
+  ING_CHK(hipGetLastError());
+  return UWT_OK;
+}
+
+}  // namespace
+
+int uwt_ingest_create(const float K[4], const float dist[4], int32_t in_w, int32_t in_h, int32_t out_w, int32_t out_h,
+                      int32_t device, uwt_ingest** out, float newK_out[4]) {
+  if (!K || !dist || !out || in_w < 2 || in_h < 2 || out_w < 1 || out_h < 1) return UWT_ERR_INVALID_ARG;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return UWT_ERR_NO_DEVICE;
+  uwt_ingest* g = new (std::nothrow) uwt_ingest();
+  if (!g) return UWT_ERR_CAPACITY;
+  g->in_w = in_w; g->in_h = in_h; g->out_w = out_w; g->out_h = out_h; g->device = device;
+  const double Kd[4] = {K[0], K[1], K[2], K[3]}, kd[4] = {dist[0], dist[1], dist[2], dist[3]};
+  optimal_new_camera_matrix(Kd, kd, in_w, in_h, 1.0, out_w, out_h, g->newK);
+  g->h_map1.resize((size_t)out_w * out_h * 2);
+  g->h_map2.resize((size_t)out_w * out_h);
+  init_undistort_maps(Kd, kd, g->newK, out_w, out_h, g->h_map1.data(), g->h_map2.data());
+  if (newK_out)
+    for (int i = 0; i < 4; i++) newK_out[i] = (float)g->newK[i];
+  bool ok = hipSetDevice(device) == hipSuccess && hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipMalloc((void**)&g->d_map1, g->h_map1.size() * 2) == hipSuccess &&
+            hipMalloc((void**)&g->d_map2, g->h_map2.size() * 2) == hipSuccess &&
+            hipMalloc((void**)&g->d_raw, (size_t)in_w * in_h) == hipSuccess &&
+            hipMalloc((void**)&g->d_und, (size_t)out_w * out_h) == hipSuccess &&
+            hipMemcpy(g->d_map1, g->h_map1.data(), g->h_map1.size() * 2, hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(g->d_map2, g->h_map2.data(), g->h_map2.size() * 2, hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) {
+    uwt_ingest_destroy(g);
+    return UWT_ERR_HIP;
+  }
+  *out = g;
+  return UWT_OK;
+}
+
+int uwt_ingest_destroy(uwt_ingest* g) {
+  if (!g) return UWT_ERR_INVALID_ARG;
+  (void)hipSetDevice(g->device);
+  if (g->stream) (void)hipStreamSynchronize(g->stream);
+  if (g->d_map1) (void)hipFree(g->d_map1);
+  if (g->d_map2) (void)hipFree(g->d_map2);
+  if (g->d_raw) (void)hipFree(g->d_raw);
+  if (g->d_und) (void)hipFree(g->d_und);
+  if (g->stream) (void)hipStreamDestroy(g->stream);
+  delete g;
+  return UWT_OK;
+}
+
+int uwt_ingest_maps(uwt_ingest* g, int16_t* map1_out, uint16_t* map2_out) {
+  if (!g || !map1_out || !map2_out) return UWT_ERR_INVALID_ARG;
+  std::memcpy(map1_out, g->h_map1.data(), g->h_map1.size() * 2);
+  std::memcpy(map2_out, g->h_map2.data(), g->h_map2.size() * 2);
+  return UWT_OK;
+}
+
+int uwt_ingest_undistort(uwt_ingest* g, const uint8_t* raw, size_t stride, uint8_t* und_out) {
+  if (!g || !raw || !und_out || stride < (size_t)g->in_w) return UWT_ERR_INVALID_ARG;
+  int st = ingest_remap(g, raw, stride, 0, 0, g->out_w, g->out_h, g->d_und);
+  if (st) return st;
+  ING_CHK(hipMemcpyAsync(und_out, g->d_und, (size_t)g->out_w * g->out_h, hipMemcpyDeviceToHost, g->stream));
+  ING_CHK(hipStreamSynchronize(g->stream));
+  return UWT_OK;
+}
+
+int uwt_ingest_calculate_roi(uwt_ingest* g, const uint8_t* raw_first, size_t stride, int32_t roi[4]) {
+  if (!g || !roi) return UWT_ERR_INVALID_ARG;
+  std::vector<uint8_t> und((size_t)g->out_w * g->out_h);
+  int st = uwt_ingest_undistort(g, raw_first, stride, und.data());
+  if (st) return st;
+  // System::CalculateROI (src/System.cpp:148-191): walk in from the four sides along the middle row / column while the
+  // undistorted image is 0, then a 5-pixel margin; Rect(p1, p2) => width = p2.x - p1.x.
+  const int w = g->out_w, h = g->out_h;
+  const int xm = (int)((w - 1) * 0.5), ym = (int)((h - 1) * 0.5);
+  int p1x = 0, p1y = 0, p2x = w - 1, p2y = h - 1;
+  while (p1x < w - 1 && und[(size_t)ym * w + p1x] == 0) p1x++;
+  while (p2x > 0 && und[(size_t)ym * w + p2x] == 0) p2x--;
+  while (p1y < h - 1 && und[(size_t)p1y * w + xm] == 0) p1y++;
+  while (p2y > 0 && und[(size_t)p2y * w + xm] == 0) p2y--;
+  p1x += 5; p2x -= 5; p1y += 5; p2y -= 5;
+  roi[0] = p1x; roi[1] = p1y; roi[2] = p2x - p1x; roi[3] = p2y - p1y;
+  return UWT_OK;
+}
+
+int uwt_ingest_frame(uwt_ingest* g, uwt_ctx* c, int32_t slot, const uint8_t* raw, size_t stride, int32_t x0, int32_t y0) {
+  if (!g || !c || !raw || stride < (size_t)g->in_w || !slot_range_ok(c, slot, 1)) return UWT_ERR_INVALID_ARG;
+  const int cw = c->p.width, ch = c->p.height;
+  if (x0 < 0 || y0 < 0 || x0 + cw > g->out_w || y0 + ch > g->out_h || g->device != c->p.device)
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_ingest_frame: crop window outside the undistorted frame");
+  int st = ingest_remap(g, raw, stride, x0, y0, cw, ch, c->img[0] + (size_t)slot * cw * ch);
+  if (st) return st;
+  ING_CHK(hipStreamSynchronize(g->stream));
+  return UWT_OK;
+}
+
 int uwt_accumulate_trajectory(uwt_ctx* c, const float* poses, int32_t n, const float start_pose[7], float t_scale,
                               int32_t reference_axes, float* traj_out) {
   if (!c || !poses || !start_pose || !traj_out || n < 0) return fail(c, UWT_ERR_INVALID_ARG, "uwt_accumulate_trajectory");

@@ -1237,6 +1237,32 @@ __global__ __launch_bounds__(256) void k_patch_points(const float2* __restrict__
         }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// frame ingest: cv::remap(raw, undistorted, map1, map2, INTER_LINEAR) + ROI crop of System::AddFrame
+// (src/System.cpp:231-235) fused: each output pixel of the crop window gathers its 2x2 source patch through the
+// fixed-point maps (CV_16SC2 + 5-bit fractions) and blends with the 15-bit weights, border constant 0.
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_remap_crop(const uint8_t* __restrict__ src, int sw, int sh, size_t s_stride,
+                                                       const short2* __restrict__ map1, const uint16_t* __restrict__ map2,
+                                                       int mw, int x0, int y0, uint8_t* __restrict__ dst, int cw, int ch) {
+  const int q = blockIdx.x * kBlock + threadIdx.x;
+  if (q >= cw * ch) return;
+  const int oy = q / cw, ox = q - oy * cw;
+  const size_t m = (size_t)(y0 + oy) * mw + (x0 + ox);
+  const short2 s = map1[m];
+  const int sx = s.x, sy = s.y;
+  const int fxy = map2[m] & 1023, fx = fxy & 31, fy = fxy >> 5;
+  const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32, w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
+  const bool xin0 = sx >= 0 && sx < sw, xin1 = sx + 1 >= 0 && sx + 1 < sw;
+  const bool yin0 = sy >= 0 && sy < sh, yin1 = sy + 1 >= 0 && sy + 1 < sh;
+  const int p00 = (xin0 && yin0) ? src[(size_t)sy * s_stride + sx] : 0;
+  const int p01 = (xin1 && yin0) ? src[(size_t)sy * s_stride + sx + 1] : 0;
+  const int p10 = (xin0 && yin1) ? src[(size_t)(sy + 1) * s_stride + sx] : 0;
+  const int p11 = (xin1 && yin1) ? src[(size_t)(sy + 1) * s_stride + sx + 1] : 0;
+  const int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+  dst[(size_t)oy * cw + ox] = (uint8_t)min(v, 255);
+}
+
 // Visualizer::UpdateMessages pose accumulation (src/Visualizer.cpp:304-325): final_i = final_{i-1} * SE3(q_i, s·t_i).
 // Strictly sequential (float SE(3) products are not associative to the last bit), one lane; n is a trajectory
 // length, not a pixel count.
