@@ -39,7 +39,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs", type=int, default=512, help="resident frame pairs per GPU")
+    ap.add_argument("--pairs", type=int, default=1024,
+                    help="resident frame pairs per GPU (BASELINE config 4: 8192 pairs over 8 GPUs = 1024 per GPU)")
     ap.add_argument("--unique", type=int, default=16, help="distinct synthetic pairs generated per rank (tiled to --pairs)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
