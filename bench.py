@@ -41,14 +41,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=1024,
                     help="resident frame pairs per GPU (BASELINE config 4: 8192 pairs over 8 GPUs = 1024 per GPU)")
-    ap.add_argument("--unique", type=int, default=16, help="distinct synthetic pairs generated per rank (tiled to --pairs)")
+    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pairs generated per rank (tiled to --pairs)")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--acc", choices=["f64", "f32"], default="f64")
     ap.add_argument("--no-depth", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=24, help="pairs timed on the CPU oracle (rank 0, N=1 only; 0 = skip)")
+    ap.add_argument("--weights", choices=["identity", "tukey", "huber"], default="identity",
+                    help="robust weights (general path; identity is the reference's live setting)")
+    ap.add_argument("--bilinear", action="store_true", help="bilinear sampler extension (general path)")
+    ap.add_argument("--cpu-pairs", type=int, default=96,
+                    help="alignments timed on the CPU oracle, 1 thread (rank 0, N=1 only; 0 = skip); ~10 s at 640x480")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the residual kernel with HIP events")
     args = ap.parse_args()
 
@@ -81,7 +85,8 @@ def main():
     intr = (f, f, w / 2 - 0.5, h / 2 - 0.5)
     has_depth = 0 if args.no_depth else 1
     over = dict(n_levels=args.levels, first_level=args.levels - 1, last_level=0, max_iters=args.iters, early_exit=0,
-                has_depth=has_depth, accumulate_f64=1 if args.acc == "f64" else 0)
+                has_depth=has_depth, accumulate_f64=1 if args.acc == "f64" else 0,
+                weights={"identity": 0, "tukey": 1, "huber": 2}[args.weights], sampler=int(args.bilinear))
     params = capi.default_params(w, h, *intr, max_frames=2 * P, max_pairs=P, device=local_rank, **over)
     ctx = capi.Context(params)
 
@@ -167,7 +172,8 @@ def main():
                         "dense points%s, %d pairs resident per GPU (%d distinct), pyramids+gradients+alignment per step"
                         % (w, h, args.levels, args.levels - 1, args.iters, ", u16 depth plane" if has_depth else ", z=1",
                            P, U),
-            "normal_equation_accumulation": args.acc, "pairs_per_gpu": P, "sharding": "round-robin pairs, RCCL all_gather of poses" if use_dist else "single GPU",
+            "normal_equation_accumulation": args.acc, "weights": args.weights,
+            "sampler": "bilinear" if args.bilinear else "nearest", "pairs_per_gpu": P, "sharding": "round-robin pairs, RCCL all_gather of poses" if use_dist else "single GPU",
         },
     }
     if rank == 0:
@@ -188,15 +194,17 @@ def main():
         if world == 1 and args.cpu_pairs > 0:
             from oracle import oracle as O          # test infrastructure, used here only as the timed CPU baseline/checker
             po = O.default_params(w, h, *intr, **{k: v for k, v in over.items() if k != "accumulate_f64"})
-            n_cpu = min(args.cpu_pairs, U)
+            n_cpu = args.cpu_pairs                  # cycles over the U distinct pairs
             t0 = time.perf_counter()
             cpu_poses = []
-            for u in range(n_cpu):
+            for k in range(n_cpu):
+                u = k % U
                 st, pose, _ = O.align_pair(po, refs[u], tgts[u], deps[u] if has_depth else None)
-                cpu_poses.append(pose)
+                if k < U:
+                    cpu_poses.append(pose)
             t_cpu = time.perf_counter() - t0
             dr, dtr, bit = [], [], 0
-            for u in range(n_cpu):
+            for u in range(len(cpu_poses)):
                 a, b = gpu_poses[u].astype(np.float64), cpu_poses[u].astype(np.float64)
                 wv = abs(float(np.dot(a[:4], b[:4])))
                 v = b[3] * a[:3] - a[3] * b[:3] - np.cross(a[:3], b[:3])
@@ -205,10 +213,24 @@ def main():
                 bit += int(np.array_equal(gpu_poses[u].view(np.uint32), cpu_poses[u].view(np.uint32)))
             out["cpu_baseline"] = {
                 "value": round(n_cpu / t_cpu, 4), "unit": "alignments/s", "cores": 1, "kind": "port",
-                "sample": "%d of the batch's distinct pairs through oracle/uwt_oracle.c (pyramid+gradients+EstimatePose), "
-                          "1 thread, %.1f s" % (n_cpu, t_cpu),
+                "sample": "%d alignments over the batch's %d distinct pairs through oracle/uwt_oracle.c "
+                          "(pyramid+gradients+EstimatePose), 1 thread, %.1f s" % (n_cpu, U, t_cpu),
             }
-            out["parity"] = {"pairs": n_cpu, "max_rot_rad": float(np.max(dr)), "max_trans_m": float(np.max(dtr)),
+            # the same work spread over every host core (ctypes releases the GIL): pair-parallel thread pool
+            from concurrent.futures import ThreadPoolExecutor
+            cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+            cores = max(1, min(cores, 64))                  # a thread pool of ctypes calls stops scaling well before that
+            def _one(k):
+                u = k % U
+                return O.align_pair(po, refs[u], tgts[u], deps[u] if has_depth else None)[0]
+            n_mt = cores * 8
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                list(ex.map(_one, range(n_mt)))
+            t_mt = time.perf_counter() - t0
+            out["cpu_baseline_all_cores"] = {"value": round(n_mt / t_mt, 4), "unit": "alignments/s", "cores": cores,
+                                             "kind": "port", "sample": "%d alignments, thread pool, %.1f s" % (n_mt, t_mt)}
+            out["parity"] = {"pairs": len(cpu_poses), "max_rot_rad": float(np.max(dr)), "max_trans_m": float(np.max(dtr)),
                              "bit_identical_poses": bit, "tolerance": "1e-4 rad / 1e-4 m"}
         print(json.dumps(out), flush=True)
     if use_dist and rank == 0:
