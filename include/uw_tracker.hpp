@@ -63,6 +63,8 @@ class Frame {
   bool obtained_gradients_ = false;
   bool obtained_candidatePoints_ = false;
   SE3 rigid_transformation_;
+  std::vector<float> keypoints_;                         // x0 y0 x1 y1 ... (cv::KeyPoint::pt of Frame::keypoints_)
+  std::vector<float> candidatePoints_[PYRAMID_LEVELS];   // N x 4 [x y z w] per level when a sparse producer ran
   int slot_ = -1;      // device frame slot once bound
 };
 
@@ -119,6 +121,71 @@ class Tracker {
     const int32_t a = bind(_previous_frame), b = bind(_current_frame);
     check(uwt_estimate_pose_batch(ctx(), 1, &a, &b, _previous_frame->rigid_transformation_.data(), &last_stats_),
           "uwt_estimate_pose_batch");
+  }
+  // include/Tracker.h:145 — gradient_ > mean + GRADIENT_THRESHOLD (src/Options.cpp:27) on every level, x-major order
+  void ObtainCandidatePoints(Frame* _frame, double gradient_threshold = 20.0) {
+    const int slot = bind(_frame);
+    if (!_frame->obtained_gradients_) throw std::runtime_error("ObtainCandidatePoints: ApplyGradient not called");
+    for (int l = 0; l < params_.n_levels && l < PYRAMID_LEVELS; l++) {
+      const uwt_level L = level(l);
+      std::vector<float>& t = _frame->candidatePoints_[l];
+      t.resize((size_t)L.w * L.h * 4);
+      int32_t n = 0;
+      check(uwt_obtain_candidate_points(ctx(), slot, l, gradient_threshold, t.data(), L.w * L.h, &n), "uwt_obtain_candidate_points");
+      t.resize((size_t)n * 4);
+    }
+    _frame->obtained_candidatePoints_ = true;
+  }
+  // include/Tracker.h:155 — 11x11 level-0 patches around Frame::keypoints_ (at most 200)
+  void ObtainPatchesPoints(Frame* _previous_frame) {
+    const int slot = bind(_previous_frame);
+    std::vector<float>& t = _previous_frame->candidatePoints_[0];
+    const int cap = 200 * 144;
+    t.resize((size_t)cap * 4);
+    int32_t n = 0;
+    check(uwt_obtain_patch_points(ctx(), slot, _previous_frame->keypoints_.data(), (int)(_previous_frame->keypoints_.size() / 2),
+                                  t.data(), cap, &n), "uwt_obtain_patch_points");
+    t.resize((size_t)(n < cap ? n : cap) * 4);
+    _previous_frame->obtained_candidatePoints_ = true;
+  }
+  // include/Tracker.h:128 — the reference's live variant: level 0 only, 10 iterations, gain 1, z_factor 0.002
+  // (src/Tracker.cpp:634-640, 834), over previous->candidatePoints_[0]
+  void EstimatePoseFeatures(Frame* _previous_frame, Frame* _current_frame) {
+    const int32_t a = bind(_previous_frame), b = bind(_current_frame);
+    if (!_previous_frame->obtained_gradients_) throw std::runtime_error("EstimatePoseFeatures: ApplyGradient(previous) not called");
+    uwt_params saved;
+    check(uwt_get_params(ctx(), &saved), "uwt_get_params");
+    uwt_params f = saved;
+    f.first_level = 0; f.last_level = 0; f.max_iters = 10; f.gain = 1.0f; f.z_factor = 0.002f; f.angle_factor = 1.0f;
+    f.handoff_scale_t = 1; f.early_exit = 1;
+    check(uwt_update_params(ctx(), &f), "uwt_update_params");
+    const float* tables[UWT_MAX_LEVELS] = {};
+    int32_t counts[UWT_MAX_LEVELS] = {};
+    tables[0] = _previous_frame->candidatePoints_[0].data();
+    counts[0] = (int32_t)(_previous_frame->candidatePoints_[0].size() / 4);
+    const int st = uwt_estimate_pose_points(ctx(), a, b, tables, counts, _previous_frame->rigid_transformation_.data(), &last_stats_);
+    uwt_update_params(ctx(), &saved);
+    check(st, "uwt_estimate_pose_points");
+  }
+  // EstimatePose over the sparse tables a producer left in previous->candidatePoints_[lvl] (src/Tracker.cpp:401)
+  void EstimatePoseOverCandidatePoints(Frame* _previous_frame, Frame* _current_frame) {
+    const int32_t a = bind(_previous_frame), b = bind(_current_frame);
+    const float* tables[UWT_MAX_LEVELS] = {};
+    int32_t counts[UWT_MAX_LEVELS] = {};
+    for (int l = 0; l < PYRAMID_LEVELS; l++) {
+      tables[l] = _previous_frame->candidatePoints_[l].data();
+      counts[l] = (int32_t)(_previous_frame->candidatePoints_[l].size() / 4);
+    }
+    check(uwt_estimate_pose_points(ctx(), a, b, tables, counts, _previous_frame->rigid_transformation_.data(), &last_stats_),
+          "uwt_estimate_pose_points");
+  }
+  // include/Tracker.h:224 / :235 — selects the weighting of the following EstimatePose calls (the reference switches by
+  // commenting src/Tracker.cpp:495-496): 0 IdentityWeights, 1 TukeyFunctionWeights, 2 Huber (extension)
+  void SetWeights(int weights) {
+    uwt_params p;
+    check(uwt_get_params(ctx(), &p), "uwt_get_params");
+    p.weights = weights;
+    check(uwt_update_params(ctx(), &p), "uwt_update_params");
   }
   const uwt_stats& last_stats() const { return last_stats_; }
   uwt_level level(int lvl) {  // w_/h_/fx_/fy_/cx_/cy_/invfx_/invfy_[lvl], include/Tracker.h:516-526

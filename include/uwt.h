@@ -94,6 +94,13 @@ int uwt_default_params(uwt_params* p, int32_t width, int32_t height, float fx, f
 
 /* new Tracker(depth) + Tracker::InitializePyramid(w, h, K)  (src/System.cpp:121-122, src/Tracker.cpp:272, 297-340) */
 int uwt_create(const uwt_params* p, uwt_ctx** out);
+/* Changes the solver constants of a live context — the locals the reference re-declares at the top of each
+ * EstimatePose* variant (src/Tracker.cpp:364-372, 634-640, 877-885): first/last level, max_iters, epsilon, gain, z_factor,
+ * angle_factor, initial_error, early_exit, handoff_scale_t, accumulate_f64, sampler, weights.  Geometry and capacity
+ * (size, intrinsics, n_levels, has_depth, max_frames, max_pairs, device) must equal the context's. */
+int uwt_update_params(uwt_ctx* ctx, const uwt_params* p);
+/* the context's current parameters */
+int uwt_get_params(const uwt_ctx* ctx, uwt_params* out);
 /* Tracker::~Tracker (src/Tracker.cpp:280-293) */
 int uwt_destroy(uwt_ctx* ctx);
 /* reads back w_/h_/fx_/fy_/cx_/cy_/invfx_/invfy_[lvl] (include/Tracker.h:516-526) */

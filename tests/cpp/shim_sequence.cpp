@@ -30,6 +30,16 @@ int main(int argc, char** argv) {
     const uw::SE3& T = previous_frame_.rigid_transformation_;
     std::printf("%.9g %.9g %.9g %.9g %.9g %.9g %.9g %d\n", T.q[0], T.q[1], T.q[2], T.q[3], T.t[0], T.t[1], T.t[2],
                 tracker_->last_stats().iterations);
+    // the reference's live flow (src/System.cpp:193-223): key points -> ObtainPatchesPoints -> EstimatePoseFeatures
+    for (int k = 0; k < 40; k++) {
+      previous_frame_.keypoints_.push_back(8.0f + (float)((k * 37) % (w - 16)));
+      previous_frame_.keypoints_.push_back(8.0f + (float)((k * 23) % (h - 16)));
+    }
+    tracker_->ObtainPatchesPoints(&previous_frame_);
+    tracker_->EstimatePoseFeatures(&previous_frame_, &current_frame_);
+    const uw::SE3& F = previous_frame_.rigid_transformation_;
+    std::printf("FEATURES %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d %d\n", F.q[0], F.q[1], F.q[2], F.q[3], F.t[0], F.t[1], F.t[2],
+                tracker_->last_stats().iterations, (int)(previous_frame_.candidatePoints_[0].size() / 4));
     // LS mirror: one row, closed form A = (J J^T) w, b = -w r J
     uw::LS ls(tracker_->ctx());
     const float J[6] = {1, 2, 3, 4, 5, 6};

@@ -43,5 +43,14 @@ def test_shim_sequence_matches_oracle(O, synth, tmp_path):
     st, pose_cpu, tr = O.align_pair(O.default_params(w, h, f, f, w / 2 - 0.5, h / 2 - 0.5), ref, tgt, want_trace=True)
     assert st == 0 and int(vals[7]) == len(tr)
     assert np.array_equal(pose, pose_cpu)
-    ls = lines[1].split()
+    ft = lines[1].split()
+    assert ft[0] == "FEATURES"
+    kp = np.array([[8.0 + (k * 37) % (w - 16), 8.0 + (k * 23) % (h - 16)] for k in range(40)], np.float32)
+    pts, n = O.patch_points(kp, None, w, h)
+    feat = dict(n_levels=5, first_level=0, last_level=0, max_iters=10, early_exit=1, gain=1.0, z_factor=0.002, handoff_scale_t=1)
+    so, pose_f, tr_f = O.align_pair_points(O.default_params(w, h, f, f, w / 2 - 0.5, h / 2 - 0.5, **feat), ref, tgt, {0: pts},
+                                           want_trace=True)
+    assert so == 0 and int(ft[9]) == n and int(ft[8]) == len(tr_f)
+    assert np.array_equal(np.array([float(v) for v in ft[1:8]], np.float32), pose_f)
+    ls = lines[2].split()
     assert ls[0] == "LS" and float(ls[1]) == 1.0 and float(ls[2]) == -3.0 and float(ls[3]) == 2.0 and int(ls[4]) == 1

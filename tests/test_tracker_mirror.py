@@ -1,0 +1,62 @@
+"""The Python mirror of the reference's Tracker / LS / Frame surface (uw-slam_amd/tracker.py) driven like
+System::Tracking() (src/System.cpp:193-223); results must equal the oracle's."""
+import importlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_system_tracking_sequences(O, synth):
+    T = importlib.import_module("uw-slam_amd.tracker")
+    capi = importlib.import_module("uw-slam_amd.capi")
+    w, h = 160, 96
+    f = 525.0 * w / 640.0
+    intr = (f, f, w / 2 - 0.5, h / 2 - 0.5)
+    K = np.array([[f, 0, intr[2]], [0, f, intr[3]], [0, 0, 1]], np.float32)
+    ref, tgt, _, _, _ = synth.render_pair(w, h, *intr, seed=91)
+    # dense variant (EstimatePose un-commented at src/System.cpp:220)
+    tracker_ = T.Tracker(False)
+    tracker_.InitializePyramid(w, h, K)
+    tracker_.InitializeMasks()
+    previous_frame_, current_frame_ = T.Frame(ref, id_frame=0), T.Frame(tgt, id_frame=1)
+    tracker_.ApplyGradient(previous_frame_)
+    tracker_.ApplyGradient(current_frame_)
+    tracker_.ObtainAllPoints(previous_frame_)
+    st = tracker_.EstimatePose(previous_frame_, current_frame_)
+    so, pose_cpu, tr = O.align_pair(O.default_params(w, h, *intr), ref, tgt, want_trace=True)
+    assert so == 0 and st["iterations"] == len(tr) and np.array_equal(previous_frame_.rigid_transformation_, pose_cpu)
+    assert tracker_.w_ == [160, 80, 40, 20, 10] and tracker_.fx_[2] == np.float32(f / 4)
+    gx, _ = O.scharr3(O.halve_u8(ref))
+    assert np.array_equal(tracker_.GetFrameData(previous_frame_, 1, capi.PLANE_GRADX), gx)
+    # the live variant: ObtainPatchesPoints + EstimatePoseFeatures (src/System.cpp:221-222)
+    rng = np.random.default_rng(1)
+    previous_frame_.keypoints_ = rng.uniform([6, 6], [w - 7, h - 7], (60, 2)).astype(np.float32)
+    tracker_.ObtainPatchesPoints(previous_frame_)
+    st = tracker_.EstimatePoseFeatures(previous_frame_, current_frame_)
+    feat = dict(first_level=0, last_level=0, max_iters=10, gain=1.0, z_factor=0.002, handoff_scale_t=1)
+    pts, _ = O.patch_points(previous_frame_.keypoints_, None, w, h)
+    so, pose_f, tr = O.align_pair_points(O.default_params(w, h, *intr, **feat), ref, tgt, {0: pts}, want_trace=True)
+    assert so == 0 and st["iterations"] == len(tr) and np.array_equal(previous_frame_.rigid_transformation_, pose_f)
+    # the solver constants are restored afterwards: the dense call gives the dense answer again
+    tracker_.EstimatePose(previous_frame_, current_frame_)
+    assert np.array_equal(previous_frame_.rigid_transformation_, pose_cpu)
+    # semi-dense producer
+    tracker_.ObtainCandidatePoints(previous_frame_)
+    mag = O.gradient_mag(*O.scharr3(ref))
+    assert np.array_equal(previous_frame_.candidatePoints_[0], O.candidate_points(mag)[0])
+    # LS mirror
+    ls = T.LS(tracker_._ctx)
+    ls.initialize(4)
+    J = rng.normal(0, 5, (4, 6)).astype(np.float32)
+    for i in range(4):
+        ls.update(J[i], float(i - 1), 0.5)
+    ls.finish()
+    o = O.ls_new()
+    for i in range(4):
+        O.ls_update(o, J[i], float(i - 1), 0.5)
+    A, b, e, n = O.ls_finish(o, True)
+    assert ls.num_constraints == n == 4 and np.allclose(ls.A, A, rtol=1e-5, atol=1e-5) and np.allclose(ls.b, b, rtol=1e-5, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        tracker_.EstimatePose(T.Frame(ref), current_frame_)       # ApplyGradient not called on the new frame

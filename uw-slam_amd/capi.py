@@ -52,7 +52,7 @@ SYMBOLS = [
     "uwt_residual_jacobian_weighted", "uwt_estimate_pose_points", "uwt_gradient_magnitude",
     "uwt_obtain_candidate_points", "uwt_obtain_patch_points",
     "uwt_ingest_create", "uwt_ingest_destroy", "uwt_ingest_maps", "uwt_ingest_undistort", "uwt_ingest_calculate_roi",
-    "uwt_ingest_frame",
+    "uwt_ingest_frame", "uwt_update_params", "uwt_get_params",
 ]
 
 _lib = None
@@ -136,6 +136,17 @@ class Context:
         if st and st not in allow:
             raise UwtError(st, lib().uwt_last_error(self._h).decode())
         return st
+
+    def update_params(self, **over):
+        """Change solver constants of the live context (uwt_update_params)."""
+        p = Params()
+        self._chk(lib().uwt_get_params(self._h, C.byref(p)))
+        for k, v in over.items():
+            if not hasattr(p, k):
+                raise AttributeError(k)
+            setattr(p, k, v)
+        self._chk(lib().uwt_update_params(self._h, C.byref(p)))
+        self.params = p
 
     # -- frames
     def level_info(self, lvl):

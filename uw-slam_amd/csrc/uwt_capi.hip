@@ -610,6 +610,33 @@ int uwt_destroy(uwt_ctx* c) {
   return UWT_OK;
 }
 
+int uwt_get_params(const uwt_ctx* c, uwt_params* out) {
+  if (!c || !out) return UWT_ERR_INVALID_ARG;
+  *out = c->p;
+  return UWT_OK;
+}
+
+int uwt_update_params(uwt_ctx* c, const uwt_params* p) {
+  if (!c || !p) return UWT_ERR_INVALID_ARG;
+  const uwt_params& o = c->p;
+  if (p->width != o.width || p->height != o.height || p->fx != o.fx || p->fy != o.fy || p->cx != o.cx || p->cy != o.cy ||
+      p->n_levels != o.n_levels || p->has_depth != o.has_depth || p->max_frames != o.max_frames ||
+      p->max_pairs != o.max_pairs || p->device != o.device || p->depth_scale != o.depth_scale)
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_update_params: geometry / capacity fields differ from the context's");
+  if (p->first_level >= p->n_levels || p->last_level < 0 || p->last_level > p->first_level || p->max_iters < 1 ||
+      p->sampler < 0 || p->sampler > 1 || p->weights < 0 || p->weights > 2 || (p->sampler == 1 && p->weights == 1))
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_update_params: bad solver constants");
+  (void)hipSetDevice(o.device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if ((p->sampler || p->weights) && !c->hist) {
+    HIPCHK(c, hipMalloc((void**)&c->hist, sizeof(unsigned int) * 2 * kHistBins * o.max_pairs));
+    HIPCHK(c, hipMalloc((void**)&c->scale, sizeof(PairScale) * o.max_pairs));
+    HIPCHK(c, hipMemset(c->scale, 0, sizeof(PairScale) * o.max_pairs));
+  }
+  c->p = *p;
+  return UWT_OK;
+}
+
 int uwt_level_info(const uwt_ctx* c, int32_t lvl, uwt_level* out) {
   if (!c || !out || lvl < 0 || lvl >= c->p.n_levels) return UWT_ERR_INVALID_ARG;
   *out = c->info[lvl];
@@ -618,6 +645,7 @@ int uwt_level_info(const uwt_ctx* c, int32_t lvl, uwt_level* out) {
 
 int uwt_set_frame(uwt_ctx* c, int32_t slot, const uint8_t* gray, size_t row_stride, const uint16_t* depth,
                   size_t depth_row_stride) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !gray || !slot_range_ok(c, slot, 1)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: bad slot/pointer");
   const int w = c->p.width, h = c->p.height;
   if (row_stride < (size_t)w) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: row stride < width");
@@ -632,6 +660,7 @@ int uwt_set_frame(uwt_ctx* c, int32_t slot, const uint8_t* gray, size_t row_stri
 }
 
 int uwt_upload_frames(uwt_ctx* c, int32_t first_slot, int32_t n, const uint8_t* gray, const uint16_t* depth) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !gray || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_upload_frames: bad range");
   const size_t px = (size_t)c->p.width * c->p.height;
   HIPCHK(c, hipMemcpyAsync(c->img[0] + first_slot * px, gray, px * n, hipMemcpyHostToDevice, c->stream));
@@ -665,6 +694,7 @@ int uwt_plane_device_ptr(uwt_ctx* c, int32_t slot, int32_t lvl, int32_t plane, v
 }
 
 int uwt_get_plane(uwt_ctx* c, int32_t slot, int32_t lvl, int32_t plane, void* host_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   void* d;
   size_t bytes;
   int st = plane_ptr(c, slot, lvl, plane, &d, &bytes);
@@ -696,6 +726,7 @@ static int enqueue_gradients(uwt_ctx* c, int first_slot, int n, const int* d_slo
 }
 
 int uwt_build_pyramids(uwt_ctx* c, int32_t first_slot, int32_t n) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_build_pyramids: bad range");
   int st = enqueue_pyramids(c, first_slot, n);
   if (st) return st;
@@ -704,6 +735,7 @@ int uwt_build_pyramids(uwt_ctx* c, int32_t first_slot, int32_t n) {
 }
 
 int uwt_apply_gradient(uwt_ctx* c, int32_t first_slot, int32_t n) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_apply_gradient: bad range");
   int st = enqueue_gradients(c, first_slot, n);
   if (st) return st;
@@ -713,6 +745,7 @@ int uwt_apply_gradient(uwt_ctx* c, int32_t first_slot, int32_t n) {
 
 int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
                             float* poses_out, uwt_stats* stats_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !poses_out) return fail(c, UWT_ERR_INVALID_ARG, "uwt_estimate_pose_batch: null argument");
   int st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
   if (st) return st;
@@ -739,6 +772,7 @@ int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slot
 
 int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only, int32_t n_pairs,
                           const int32_t* ref_slots, const int32_t* tgt_slots, float* d_poses_out, uwt_stats* d_stats_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !d_poses_out || !slot_range_ok(c, first_slot, n_frames))
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_track_batch_async: bad argument");
   int st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
@@ -758,6 +792,7 @@ int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int3
 
 int uwt_sync(uwt_ctx* c) {
   if (!c) return UWT_ERR_INVALID_ARG;
+  (void)hipSetDevice(c->p.device);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->profiling) return prof_collect(c);
   return UWT_OK;
@@ -770,6 +805,7 @@ int uwt_stream(uwt_ctx* c, void** out) {
 }
 
 int uwt_profile_enable(uwt_ctx* c, int32_t on) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c) return UWT_ERR_INVALID_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->ev_used = 0;
@@ -791,6 +827,7 @@ int uwt_profile_read(uwt_ctx* c, double* ms_total, int64_t* launches, int64_t* p
 /* ---- per-stage entry points ---------------------------------------------------------------------------------- */
 
 int uwt_halve_u8(uwt_ctx* c, const uint8_t* src, int32_t w, int32_t h, uint8_t* dst) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !src || !dst || w < 2 || h < 2 || (w & 1) || (h & 1)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_halve_u8");
   const size_t ns = (size_t)w * h, nd = ns / 4, off = (ns + 255) & ~(size_t)255;
   int st = ensure_scratch(c, off + nd);
@@ -805,6 +842,7 @@ int uwt_halve_u8(uwt_ctx* c, const uint8_t* src, int32_t w, int32_t h, uint8_t* 
 }
 
 int uwt_halve_u16(uwt_ctx* c, const uint16_t* src, int32_t w, int32_t h, uint16_t* dst) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !src || !dst || w < 2 || h < 2 || (w & 1) || (h & 1)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_halve_u16");
   const size_t ns = (size_t)w * h, nd = ns / 4, off = (ns * 2 + 255) & ~(size_t)255;
   int st = ensure_scratch(c, off + nd * 2);
@@ -819,6 +857,7 @@ int uwt_halve_u16(uwt_ctx* c, const uint16_t* src, int32_t w, int32_t h, uint16_
 }
 
 int uwt_scharr3(uwt_ctx* c, const uint8_t* src, int32_t w, int32_t h, int16_t* gx, int16_t* gy) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !src || !gx || !gy || w < 1 || h < 1) return fail(c, UWT_ERR_INVALID_ARG, "uwt_scharr3");
   const size_t n = (size_t)w * h, off = (n + 255) & ~(size_t)255;
   int st = ensure_scratch(c, off + n * 4);
@@ -836,6 +875,7 @@ int uwt_scharr3(uwt_ctx* c, const uint8_t* src, int32_t w, int32_t h, int16_t* g
 }
 
 int uwt_warp(uwt_ctx* c, int32_t lvl, const float* pts, int32_t n, const float pose[7], float* warped_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !pts || !pose || !warped_out || n < 1 || lvl < 0 || lvl >= c->p.n_levels)
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_warp");
   const size_t bytes = sizeof(float) * 4 * (size_t)n;
@@ -856,6 +896,7 @@ int uwt_warp(uwt_ctx* c, int32_t lvl, const float* pts, int32_t n, const float p
 
 int uwt_residual_jacobian(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, int32_t lvl, const float pose[7],
                           uwt_accum* acc_out, float* J_out, float* r_out, uint8_t* valid_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !pose || !acc_out || lvl < 0 || lvl >= c->p.n_levels || !slot_range_ok(c, ref_slot, 1) || !slot_range_ok(c, tgt_slot, 1))
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_residual_jacobian");
   int st = upload_pairs(c, 1, &ref_slot, &tgt_slot);
@@ -901,6 +942,7 @@ int uwt_residual_jacobian(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, int32_
 int uwt_residual_jacobian_weighted(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, int32_t lvl, const float pose[7],
                                    uwt_accum* acc_out, double* err_num_out, float* inv_mad_out, float* J_out, float* r_out,
                                    uint8_t* valid_out, float* w_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !pose || !acc_out || lvl < 0 || lvl >= c->p.n_levels || !slot_range_ok(c, ref_slot, 1) || !slot_range_ok(c, tgt_slot, 1))
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_residual_jacobian_weighted");
   if (!c->p.sampler && !c->p.weights)
@@ -955,6 +997,7 @@ int uwt_residual_jacobian_weighted(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slo
 
 int uwt_ls_accumulate(uwt_ctx* c, const float* J, const float* r, const float* w, int32_t n, int32_t divide, float A[36],
                       float b[6], float* error, int32_t* num_constraints) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !J || !r || !A || !b || !error || !num_constraints || n < 0) return fail(c, UWT_ERR_INVALID_ARG, "uwt_ls_accumulate");
   const int blocks = n == 0 ? 1 : std::min(1024, (n + kBlock - 1) / kBlock);
   const size_t fl = (size_t)n * 8 + (size_t)blocks * 28 + 64;
@@ -993,21 +1036,25 @@ int uwt_ls_accumulate(uwt_ctx* c, const float* J, const float* r, const float* w
 }
 
 int uwt_se3_exp(uwt_ctx* c, const float xi[6], float pose_out[7]) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!xi || !pose_out) return UWT_ERR_INVALID_ARG;
   return run_se3_op(c, 0, xi, 6, nullptr, 0, pose_out, 7, nullptr);
 }
 
 int uwt_se3_mul(uwt_ctx* c, const float a[7], const float b[7], float out[7]) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!a || !b || !out) return UWT_ERR_INVALID_ARG;
   return run_se3_op(c, 1, a, 7, b, 7, out, 7, nullptr);
 }
 
 int uwt_se3_matrix(uwt_ctx* c, const float pose[7], float T_out[16]) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!pose || !T_out) return UWT_ERR_INVALID_ARG;
   return run_se3_op(c, 2, pose, 7, nullptr, 0, T_out, 16, nullptr);
 }
 
 int uwt_se3_handoff(uwt_ctx* c, float pose[7], int32_t scale_t) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!pose) return UWT_ERR_INVALID_ARG;
   float out[7];
   int flag = 1;
@@ -1019,6 +1066,7 @@ int uwt_se3_handoff(uwt_ctx* c, float pose[7], int32_t scale_t) {
 }
 
 int uwt_solve_delta(uwt_ctx* c, const float A[36], const float b[6], float delta_out[6], float* Ainv_out, int32_t* nonsingular) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!A || !b || !delta_out) return UWT_ERR_INVALID_ARG;
   float out[42];
   int flag = 0;
@@ -1032,6 +1080,7 @@ int uwt_solve_delta(uwt_ctx* c, const float A[36], const float b[6], float delta
 
 int uwt_estimate_pose_points(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, const float* const* tables,
                              const int32_t* n_points, float pose_out[7], uwt_stats* stats_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !tables || !n_points || !pose_out) return fail(c, UWT_ERR_INVALID_ARG, "uwt_estimate_pose_points: null argument");
   const uwt_params& p = c->p;
   size_t total = 0;
@@ -1117,6 +1166,7 @@ static int mag_to_scratch(uwt_ctx* c, int slot, int lvl, uint8_t** d_mag, unsign
 }
 
 int uwt_gradient_magnitude(uwt_ctx* c, int32_t slot, int32_t lvl, uint8_t* mag_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !mag_out || !slot_range_ok(c, slot, 1) || lvl < 0 || lvl >= c->p.n_levels)
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_gradient_magnitude");
   uint8_t* d_mag;
@@ -1130,6 +1180,7 @@ int uwt_gradient_magnitude(uwt_ctx* c, int32_t slot, int32_t lvl, uint8_t* mag_o
 
 int uwt_obtain_candidate_points(uwt_ctx* c, int32_t slot, int32_t lvl, double threshold, float* pts_out, int32_t cap,
                                 int32_t* count_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !count_out || cap < 0 || (cap > 0 && !pts_out) || !slot_range_ok(c, slot, 1) || lvl < 0 || lvl >= c->p.n_levels)
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_obtain_candidate_points");
   uint8_t* d_mag;
@@ -1162,6 +1213,7 @@ int uwt_obtain_candidate_points(uwt_ctx* c, int32_t slot, int32_t lvl, double th
 
 int uwt_obtain_patch_points(uwt_ctx* c, int32_t slot, const float* kp, int32_t n_kp, float* pts_out, int32_t cap,
                             int32_t* count_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !count_out || n_kp < 0 || (n_kp > 0 && !kp) || cap < 0 || (cap > 0 && !pts_out) || !slot_range_ok(c, slot, 1))
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_obtain_patch_points");
   const int w = c->lv[0].w, h = c->lv[0].h;
@@ -1383,6 +1435,7 @@ int uwt_ingest_frame(uwt_ingest* g, uwt_ctx* c, int32_t slot, const uint8_t* raw
 
 int uwt_accumulate_trajectory(uwt_ctx* c, const float* poses, int32_t n, const float start_pose[7], float t_scale,
                               int32_t reference_axes, float* traj_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !poses || !start_pose || !traj_out || n < 0) return fail(c, UWT_ERR_INVALID_ARG, "uwt_accumulate_trajectory");
   if (n == 0) return UWT_OK;
   const size_t bytes = sizeof(float) * 7 * (size_t)n;
@@ -1403,6 +1456,7 @@ int uwt_accumulate_trajectory(uwt_ctx* c, const float* poses, int32_t n, const f
 
 #ifdef UWT_EXP_CLOCK
 int uwt_debug_read_record(uwt_ctx* c, int32_t pair, int32_t slice, int32_t lvl, uint32_t out[64]) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   HIPCHK(c, hipStreamSynchronize(c->stream));
   HIPCHK(c, hipMemcpy(out, c->partials + ((size_t)pair * c->slices[lvl] + slice) * kRecWords, 256, hipMemcpyDeviceToHost));
   return UWT_OK;

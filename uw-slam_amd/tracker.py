@@ -30,6 +30,8 @@ class Frame:
         self.obtained_gradients_ = False
         self.obtained_candidatePoints_ = False
         self.rigid_transformation_ = np.array([0, 0, 0, 1, 0, 0, 0], np.float32)  # qx qy qz qw tx ty tz
+        self.keypoints_ = np.zeros((0, 2), np.float32)       # cv::KeyPoint::pt of Frame::keypoints_
+        self.candidatePoints_ = {}                           # level -> N x 4 [x y z w] when a sparse producer ran
         self._slot = None
 
 
@@ -95,6 +97,33 @@ class Tracker:
         poses, stats = self._ctx.estimate_pose_batch([a], [b], raise_on_pair_failure=True)
         _previous_frame.rigid_transformation_ = poses[0]
         return stats[0]
+
+    def ObtainCandidatePoints(self, _frame, gradient_threshold=20.0):
+        """src/Tracker.cpp:1314-1398 (GRADIENT_THRESHOLD, src/Options.cpp:27)."""
+        slot = self._bind(_frame)
+        for l in range(self._ctx.params.n_levels):
+            _frame.candidatePoints_[l] = self._ctx.obtain_candidate_points(slot, l, gradient_threshold)[0]
+        _frame.obtained_candidatePoints_ = True
+
+    def ObtainPatchesPoints(self, _previous_frame):
+        """src/Tracker.cpp:1178-1257."""
+        slot = self._bind(_previous_frame)
+        _previous_frame.candidatePoints_[0] = self._ctx.obtain_patch_points(slot, _previous_frame.keypoints_)[0]
+        _previous_frame.obtained_candidatePoints_ = True
+
+    def EstimatePoseFeatures(self, _previous_frame, _current_frame):
+        """src/Tracker.cpp:632-872 — the reference's live variant (constants :634-640, :834, :856)."""
+        a, b = self._bind(_previous_frame), self._bind(_current_frame)
+        saved = {k: getattr(self._ctx.params, k) for k in ("first_level", "last_level", "max_iters", "gain", "z_factor",
+                                                            "angle_factor", "handoff_scale_t", "early_exit")}
+        self._ctx.update_params(first_level=0, last_level=0, max_iters=10, gain=1.0, z_factor=0.002, angle_factor=1.0,
+                                handoff_scale_t=1, early_exit=1)
+        try:
+            pose, st = self._ctx.estimate_pose_points(a, b, {0: _previous_frame.candidatePoints_[0]})
+        finally:
+            self._ctx.update_params(**saved)
+        _previous_frame.rigid_transformation_ = pose
+        return st
 
     def GetFrameData(self, _frame, lvl, plane):
         return self._ctx.get_plane(self._bind(_frame), lvl, plane)
