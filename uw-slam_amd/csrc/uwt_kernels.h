@@ -556,15 +556,7 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
       }
     }
   }
-#ifdef UWT_EXP_NOREDUCE
-  {
-    double s = 0;
-    for (int i = 0; i < kAccFloats; i++) s += (double)acc[i];
-    if (s == 1.2345 && sum_r2 == 77 && n_valid == 3) a.partials[threadIdx.x] = 1;
-  }
-#else
   block_reduce_store<AccT>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + slice) * kRecWords);
-#endif
 #ifdef UWT_EXP_CLOCK
   if (threadIdx.x == 0) {  // diagnostic build only: shader-clock and 100 MHz real-time deltas of this block
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.partials + ((size_t)pair * a.slices + slice) * kRecWords) + 30;
