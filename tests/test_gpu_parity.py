@@ -433,3 +433,54 @@ def test_track_batch_async_device_outputs_match_sync_path(capi, O, synth):
     bad_a = [i for i in range(n) if not np.array_equal(a[i], cpu[i])]
     bad_b = [i for i in range(n) if not np.array_equal(b[i], cpu[i])]
     assert bad_a == [] and bad_b == [], "async!=cpu %s ; sync!=cpu %s ; a==b %s" % (bad_a, bad_b, np.array_equal(a, b))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 33])
+@pytest.mark.parametrize("cfg", ["fixed_4lvl", "fixed_1lvl_1it", "fixed_top_only", "reference"])
+def test_batch_sizes_and_schedules_match_oracle(capi, O, synth, n, cfg):
+    """Odd / tiny batches through the pipelined half-batch schedule (and the reference schedule), every pose checked."""
+    w, h = 64, 48
+    over = dict(fixed_4lvl=dict(n_levels=3, first_level=2, last_level=0, max_iters=4, early_exit=0),
+                fixed_1lvl_1it=dict(n_levels=3, first_level=0, last_level=0, max_iters=1, early_exit=0),
+                fixed_top_only=dict(n_levels=3, first_level=2, last_level=2, max_iters=3, early_exit=0),
+                reference=dict(n_levels=3, first_level=2, last_level=1, max_iters=50, early_exit=1))[cfg]
+    ctx = make_ctx(capi, w, h, SMALL, max_frames=2 * n, max_pairs=n, **over)
+    p = O.default_params(w, h, *SMALL, **over)
+    frames, cpu = [], []
+    for s in range(n):
+        ref, tgt, _, _, _ = synth.render_pair(w, h, *SMALL, seed=7000 + s, max_t=0.02, max_deg=1.0)
+        frames += [ref, tgt]
+        cpu.append(O.align_pair(p, ref, tgt, want_trace=True))
+    ctx.upload_frames(0, np.stack(frames))
+    ctx.build_pyramids(0, 2 * n)
+    ctx.apply_gradient(0, 2 * n)
+    poses, stats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1, raise_on_pair_failure=True)
+    for i in range(n):
+        assert cpu[i][0] == 0 and stats[i]["iterations"] == len(cpu[i][2])
+        assert np.array_equal(poses[i], cpu[i][1]), (i, poses[i], cpu[i][1])
+
+
+def test_failing_pair_does_not_disturb_its_batch(capi, O, synth):
+    """One pair with no valid depth gets UWT_ERR_NO_VALID_POINTS; the other pairs of both half-batches are untouched."""
+    w, h, n = 64, 48, 6
+    over = dict(n_levels=3, first_level=2, last_level=0, max_iters=4, early_exit=0, has_depth=1)
+    ctx = make_ctx(capi, w, h, SMALL, max_frames=2 * n, max_pairs=n, **over)
+    p = O.default_params(w, h, *SMALL, **over)
+    frames, depths, cpu = [], [], []
+    for s in range(n):
+        ref, tgt, dep, _, _ = synth.render_pair(w, h, *SMALL, seed=7100 + s, with_depth=True)
+        if s in (1, 4):
+            dep = np.zeros_like(dep)
+        frames += [ref, tgt]
+        depths += [dep, dep]
+        cpu.append(O.align_pair(p, ref, tgt, dep))
+    ctx.upload_frames(0, np.stack(frames), np.stack(depths))
+    ctx.build_pyramids(0, 2 * n)
+    ctx.apply_gradient(0, 2 * n)
+    poses, stats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1)
+    for i in range(n):
+        assert stats[i]["status"] == cpu[i][0] == (capi.ERR_NO_VALID_POINTS if i in (1, 4) else 0)
+        if i not in (1, 4):
+            assert np.array_equal(poses[i], cpu[i][1])
+        else:
+            assert np.array_equal(poses[i], np.array([0, 0, 0, 1, 0, 0, 0], np.float32)) and stats[i]["iterations"] == 1
