@@ -51,6 +51,9 @@ def main():
     ap.add_argument("--weights", choices=["identity", "tukey", "huber"], default="identity",
                     help="robust weights (general path; identity is the reference's live setting)")
     ap.add_argument("--bilinear", action="store_true", help="bilinear sampler extension (general path)")
+    ap.add_argument("--reference-schedule", action="store_true",
+                    help="the reference's EstimatePose constants: 5 levels, iterate 4..1, <= 50 iterations, early exit "
+                         "(src/Tracker.cpp:364-372); not the headline workload")
     ap.add_argument("--cpu-pairs", type=int, default=96,
                     help="alignments timed on the CPU oracle, 1 thread (rank 0, N=1 only; 0 = skip); ~10 s at 640x480")
     ap.add_argument("--no-profile", action="store_true", help="do not bracket the residual kernel with HIP events")
@@ -87,6 +90,8 @@ def main():
     over = dict(n_levels=args.levels, first_level=args.levels - 1, last_level=0, max_iters=args.iters, early_exit=0,
                 has_depth=has_depth, accumulate_f64=1 if args.acc == "f64" else 0,
                 weights={"identity": 0, "tukey": 1, "huber": 2}[args.weights], sampler=int(args.bilinear))
+    if args.reference_schedule:
+        over.update(n_levels=5, first_level=4, last_level=1, max_iters=50, early_exit=1)
     params = capi.default_params(w, h, *intr, max_frames=2 * P, max_pairs=P, device=local_rank, **over)
     ctx = capi.Context(params)
 
@@ -168,10 +173,12 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": "synthetic %dx%d pairs, %d pyramid levels (0..%d), %d GN iterations/level, no early exit, "
-                        "dense points%s, %d pairs resident per GPU (%d distinct), pyramids+gradients+alignment per step"
-                        % (w, h, args.levels, args.levels - 1, args.iters, ", u16 depth plane" if has_depth else ", z=1",
-                           P, U),
+            "workload": ("synthetic %dx%d pairs, %s, "
+                         "dense points%s, %d pairs resident per GPU (%d distinct), pyramids+gradients+alignment per step"
+                         % (w, h, "reference schedule: 5 pyramid levels, iterate 4..1, <= 50 iterations, early exit"
+                            if args.reference_schedule else
+                            "%d pyramid levels (0..%d), %d GN iterations/level, no early exit" % (args.levels, args.levels - 1, args.iters),
+                            ", u16 depth plane" if has_depth else ", z=1", P, U)),
             "normal_equation_accumulation": args.acc, "weights": args.weights,
             "sampler": "bilinear" if args.bilinear else "nearest", "pairs_per_gpu": P, "sharding": "round-robin pairs, RCCL all_gather of poses" if use_dist else "single GPU",
         },

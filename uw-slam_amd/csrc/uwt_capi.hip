@@ -237,7 +237,7 @@ GeneralArgs general_args(uwt_ctx* c) {
 }
 
 // One residual evaluation on the general path (robust weights and/or bilinear sampler) for pairs [pair_base, +n):
-// with weights on, two histogram passes estimate the scale first (MedianMat / MedianAbsoluteDeviation,
+// with weights on, one histogram pass estimates the scale first (MedianMat / MedianAbsoluteDeviation,
 // src/Tracker.cpp:1571-1619), then the weighted accumulation runs.  Records use one pixel per point and 8192 per block.
 int launch_general(uwt_ctx* c, ResidualArgs ra, int n_pairs) {
   const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f);
@@ -246,15 +246,12 @@ int launch_general(uwt_ctx* c, ResidualArgs ra, int n_pairs) {
   ra.slices = (ra.L.n + ra.groups_per_block - 1) / ra.groups_per_block;
   const dim3 grid(ra.slices, n_pairs), blk(kBlock);
   if (ga.weights) {
-    HIPCHK(c, hipMemsetAsync(c->hist + (size_t)ra.pair_base * 2 * kHistBins, 0, sizeof(unsigned int) * 2 * kHistBins * n_pairs, c->stream));
-    for (int stage = 0; stage < 2; stage++) {
-      ga.stage = stage;
-      if (depth) hipLaunchKernelGGL(k_resid_hist<true>, grid, blk, 0, c->stream, ra, ga);
-      else hipLaunchKernelGGL(k_resid_hist<false>, grid, blk, 0, c->stream, ra, ga);
-      HIPCHK(c, hipGetLastError());
-      hipLaunchKernelGGL(k_scale_stage, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, ga, ra.state, n_pairs, ra.pair_base);
-      HIPCHK(c, hipGetLastError());
-    }
+    HIPCHK(c, hipMemsetAsync(c->hist + (size_t)ra.pair_base * kHistBins, 0, sizeof(unsigned int) * kHistBins * n_pairs, c->stream));
+    if (depth) hipLaunchKernelGGL(k_resid_hist<true>, grid, blk, 0, c->stream, ra, ga);
+    else hipLaunchKernelGGL(k_resid_hist<false>, grid, blk, 0, c->stream, ra, ga);
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_scale_stage, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, ga, ra.state, n_pairs, ra.pair_base);
+    HIPCHK(c, hipGetLastError());
   }
   if (depth && unit) hipLaunchKernelGGL((k_residual_general<true, true>), grid, blk, 0, c->stream, ra, ga);
   else if (depth) hipLaunchKernelGGL((k_residual_general<true, false>), grid, blk, 0, c->stream, ra, ga);
@@ -571,7 +568,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_stats, sizeof(StatsOut) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_active, sizeof(int)));
   if (p->sampler || p->weights) {
-    CREATE_CHK(hipMalloc((void**)&c->hist, sizeof(unsigned int) * 2 * kHistBins * p->max_pairs));
+    CREATE_CHK(hipMalloc((void**)&c->hist, sizeof(unsigned int) * kHistBins * p->max_pairs));
     CREATE_CHK(hipMalloc((void**)&c->scale, sizeof(PairScale) * p->max_pairs));
     CREATE_CHK(hipMemset(c->scale, 0, sizeof(PairScale) * p->max_pairs));
   }
@@ -629,7 +626,7 @@ int uwt_update_params(uwt_ctx* c, const uwt_params* p) {
   (void)hipSetDevice(o.device);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if ((p->sampler || p->weights) && !c->hist) {
-    HIPCHK(c, hipMalloc((void**)&c->hist, sizeof(unsigned int) * 2 * kHistBins * o.max_pairs));
+    HIPCHK(c, hipMalloc((void**)&c->hist, sizeof(unsigned int) * kHistBins * o.max_pairs));
     HIPCHK(c, hipMalloc((void**)&c->scale, sizeof(PairScale) * o.max_pairs));
     HIPCHK(c, hipMemset(c->scale, 0, sizeof(PairScale) * o.max_pairs));
   }

@@ -594,9 +594,9 @@ struct PairScale {
 struct GeneralArgs {
   int sampler;            // 0 nearest, 1 bilinear
   int weights;            // kWeights*
-  int stage;              // histogram kernels: 0 residual bins, 1 deviation bins
+  int stage;              // unused (kept for layout)
   float gain;
-  unsigned int* hist;     // [pair][2][kHistBins]
+  unsigned int* hist;     // [pair][kHistBins]: signed bins q + 255 of the rounded residuals
   PairScale* scale;       // [pair]
 };
 
@@ -668,55 +668,83 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist(const ResidualArgs a, con
   const uint8_t* I1 = a.img + ref_off;
   const uint8_t* I2 = a.img + tgt_off;
   const uint16_t* DP = DEPTH ? a.depth + ref_off : nullptr;
-  const float med0 = ga.stage ? ga.scale[pair].med0 : 0.f;
   const int p_begin = blockIdx.x * a.groups_per_block, p_end = min(p_begin + a.groups_per_block, L.n);
   for (int p = p_begin + (int)threadIdx.x; p < p_end; p += kBlock) {
     float x2, y2, iz, rf;
     if (!general_pixel<DEPTH>(a, L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf)) continue;
-    int bin;
-    if (ga.stage == 0) {
-      const int q = (int)rintf(rf);                       // saturate_cast<uchar> rounds half to even (cvRound)
-      bin = (ga.weights == kWeightsTukeyRef ? max(q, 0) : q) + 255;   // MedianMat saturates negatives to 0 (:1572-1573)
-    } else {
-      if (ga.weights == kWeightsTukeyRef) bin = min((int)rintf(fabsf(rf - med0)), 255);   // abs(_input - median) -> u8 (:1613, 1573)
-      else bin = min(abs((int)rintf(rf) - (int)med0), 510);
-    }
-    atomicAdd(&h[bin], 1u);
+    const int q = (int)rintf(rf);   // saturate_cast<uchar> / lrint: round half to even; |q| <= 255
+    atomicAdd(&h[q + 255], 1u);     // signed bins; integer atomics are order-independent
   }
   __syncthreads();
-  unsigned int* gh = ga.hist + ((size_t)pair * 2 + ga.stage) * kHistBins;
+  unsigned int* gh = ga.hist + (size_t)pair * kHistBins;
   for (int i = threadIdx.x; i < kHistBins; i += kBlock)
     if (h[i]) atomicAdd(&gh[i], h[i]);
 }
 
-// median by the reference's rule (MedianMat, src/Tracker.cpp:1575-1591): first bin whose cumulative count exceeds
-// (float)(n / 2).  Stage 0 -> med0; stage 1 -> MAD = 1.4826 * median deviation (:1607-1619), 0 => 1 (:1634-1637).
+// Scale from the signed residual histogram alone (residuals are integers, or are binned by their rounded value):
+//   median by the reference's rule (MedianMat, src/Tracker.cpp:1575-1591: first bin whose cumulative count exceeds
+//   (float)(n / 2)); the reference Tukey saturates negatives to 0 first (:1572-1573), Huber keeps the sign;
+//   the deviation histogram |q - med| follows from the same bins (clamped at 255 like the u8 conversion of
+//   MedianAbsoluteDeviation's input, :1613, or at 510 for Huber); MAD = 1.4826 * its median (:1607-1619), 0 => 1 (:1634-1637).
 __global__ void k_scale_stage(const GeneralArgs ga, const PairState* state, int n_pairs, int pair_base) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_pairs) return;
   const int pair = i + pair_base;
   const PairState st = state[pair];
   if (st.level_done || st.status) return;
-  const unsigned int* gh = ga.hist + ((size_t)pair * 2 + ga.stage) * kHistBins;
+  const unsigned int* gh = ga.hist + (size_t)pair * kHistBins;
+  const bool tukey = ga.weights == kWeightsTukeyRef;
   unsigned int n = 0;
-  for (int b = 0; b < kHistBins; b++) n += gh[b];
+  for (int b = 0; b < 511; b++) n += gh[b];
   const float m = (float)(n / 2);
-  unsigned int cum = 0;
-  int med = ga.stage == 0 ? 255 : (ga.weights == kWeightsTukeyRef ? 255 : 510);
-  bool found = false;
-  for (int b = 0; b < kHistBins; b++) {
-    cum += gh[b];
-    if (!found && (float)cum > m) { med = b; found = true; }
+  // median of the residuals
+  int med = 0;
+  {
+    unsigned int cum = 0;
+    bool found = false;
+    if (tukey) {
+      for (int b = 0; b <= 255; b++) cum += gh[b];          // every q <= 0 lands in bin 0 of the saturated histogram
+      if ((float)cum > m) { med = 0; found = true; }
+      for (int v = 1; v <= 255 && !found; v++) {
+        cum += gh[v + 255];
+        if ((float)cum > m) { med = v; found = true; }
+      }
+      if (!found) med = 255;
+    } else {
+      for (int b = 0; b < 511 && !found; b++) {
+        cum += gh[b];
+        if ((float)cum > m) { med = b - 255; found = true; }
+      }
+      if (!found) med = 255;
+    }
   }
-  PairScale sc = ga.scale[pair];
-  if (ga.stage == 0) {
-    sc.med0 = n ? (float)(med - 255) : 0.f;
-    sc.n_valid = (int)n;
-  } else {
-    float mad = 1.4826f * (float)med;
-    if (!n || mad == 0.f) mad = 1.f;
-    sc.inv_mad = (float)(1.0 / (double)mad);
+  // median of |q - med| from the same histogram
+  const int dmax = tukey ? 255 : 510;
+  int dmed = dmax;
+  {
+    unsigned int cum = 0;
+    bool found = false;
+    for (int d = 0; d <= dmax && !found; d++) {
+      unsigned int c = 0;
+      if (d < dmax) {
+        const int lo = med - d, hi = med + d;
+        if (lo >= -255) c += gh[lo + 255];
+        if (d > 0 && hi <= 255) c += gh[hi + 255];
+      } else {  // clamp bin: every deviation >= dmax
+        for (int q = -255; q <= 255; q++)
+          if (abs(q - med) >= dmax) c += gh[q + 255];
+      }
+      cum += c;
+      if ((float)cum > m) { dmed = d; found = true; }
+    }
   }
+  PairScale sc;
+  sc.med0 = (float)med;
+  sc.n_valid = (int)n;
+  sc.pad = 0;
+  float mad = 1.4826f * (float)dmed;
+  if (!n || mad == 0.f) mad = 1.f;
+  sc.inv_mad = (float)(1.0 / (double)mad);
   ga.scale[pair] = sc;
 }
 
