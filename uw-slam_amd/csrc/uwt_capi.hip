@@ -198,6 +198,8 @@ ResidualArgs residual_args(uwt_ctx* c, int lvl) {
   a.groups_per_block = c->groups_per_block[lvl];
   a.slices = c->slices[lvl];
   a.partials = c->partials;
+  a.scale = c->scale;
+  a.gain = c->p.gain;
   return a;
 }
 
@@ -239,7 +241,59 @@ GeneralArgs general_args(uwt_ctx* c) {
 // One residual evaluation on the general path (robust weights and/or bilinear sampler) for pairs [pair_base, +n):
 // with weights on, one histogram pass estimates the scale first (MedianMat / MedianAbsoluteDeviation,
 // src/Tracker.cpp:1571-1619), then the weighted accumulation runs.  Records use one pixel per point and 8192 per block.
-int launch_general(uwt_ctx* c, ResidualArgs ra, int n_pairs) {
+template <int VEC, bool DEPTH, bool UNIT>
+void launch_general_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sampler, int weights) {
+  const dim3 grid(a.slices, n_pairs), blk(kBlock);
+  const int key = sampler * 3 + weights;
+  switch (key) {
+    case 1: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, false, 0, 1>), grid, blk, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, false, 0, 2>), grid, blk, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, false, 1, 0>), grid, blk, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, false, 1, 2>), grid, blk, 0, s, a); break;
+  }
+}
+
+// The alignment loop's launch on the general path: the scale pass (weights only), then the dense kernel specialised for
+// the sampler / weights.  Same slicing as the fast path.
+int launch_general(uwt_ctx* c, const ResidualArgs& ra, int n_pairs) {
+  const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f);
+  GeneralArgs ga = general_args(c);
+  if (ga.weights) {
+    HIPCHK(c, hipMemsetAsync(c->hist + (size_t)ra.pair_base * kHistBins, 0, sizeof(unsigned int) * kHistBins * n_pairs, c->stream));
+    const dim3 grid(ra.slices, n_pairs), blk(kBlock);
+    const int hk = (c->vec == 4 ? 4 : 0) | (depth ? 2 : 0) | (ga.sampler ? 1 : 0);
+    switch (hk) {
+      case 0: hipLaunchKernelGGL((k_resid_hist_v<1, false, 0>), grid, blk, 0, c->stream, ra, c->hist); break;
+      case 1: hipLaunchKernelGGL((k_resid_hist_v<1, false, 1>), grid, blk, 0, c->stream, ra, c->hist); break;
+      case 2: hipLaunchKernelGGL((k_resid_hist_v<1, true, 0>), grid, blk, 0, c->stream, ra, c->hist); break;
+      case 3: hipLaunchKernelGGL((k_resid_hist_v<1, true, 1>), grid, blk, 0, c->stream, ra, c->hist); break;
+      case 4: hipLaunchKernelGGL((k_resid_hist_v<4, false, 0>), grid, blk, 0, c->stream, ra, c->hist); break;
+      case 5: hipLaunchKernelGGL((k_resid_hist_v<4, false, 1>), grid, blk, 0, c->stream, ra, c->hist); break;
+      case 6: hipLaunchKernelGGL((k_resid_hist_v<4, true, 0>), grid, blk, 0, c->stream, ra, c->hist); break;
+      default: hipLaunchKernelGGL((k_resid_hist_v<4, true, 1>), grid, blk, 0, c->stream, ra, c->hist); break;
+    }
+    HIPCHK(c, hipGetLastError());
+    hipLaunchKernelGGL(k_scale_stage, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, ga, ra.state, n_pairs, ra.pair_base);
+    HIPCHK(c, hipGetLastError());
+  }
+  const int key = (c->vec == 4 ? 4 : 0) | (depth ? 2 : 0) | (unit ? 1 : 0);
+  hipStream_t s = c->stream;
+  switch (key) {
+    case 0: launch_general_t<1, false, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 1: launch_general_t<1, false, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 2: launch_general_t<1, true, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 3: launch_general_t<1, true, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 4: launch_general_t<4, false, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 5: launch_general_t<4, false, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 6: launch_general_t<4, true, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    default: launch_general_t<4, true, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+  }
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
+// The per-stage (dump-capable) form of the same evaluation: k_residual_general, one pixel per thread step.
+int launch_general_dump(uwt_ctx* c, ResidualArgs ra, int n_pairs) {
   const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f);
   GeneralArgs ga = general_args(c);
   ra.groups_per_block = kBlock * 32;
@@ -391,10 +445,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats)
           c->prof_launches += 1;
           c->prof_pixels += (long long)n_pairs * c->lv[lvl].n;
         }
-        if (general) {
-          ua.general = 1;
-          ua.slices = (c->lv[lvl].n + kBlock * 32 - 1) / (kBlock * 32);
-        }
+        if (general) ua.general = 1;
         ua.k = k;
         const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
         ua.active = poll ? c->d_active : nullptr;
@@ -959,7 +1010,7 @@ int uwt_residual_jacobian_weighted(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slo
   a.dumpR = a.dumpJ + 6 * n;
   a.dumpW = a.dumpR + n;
   a.dumpV = (uint8_t*)(a.dumpW + n);
-  st = launch_general(c, a, 1);
+  st = launch_general_dump(c, a, 1);
   if (st) return st;
   const int slices = (int)((n + kBlock * 32 - 1) / (kBlock * 32));
   std::vector<uint32_t> recs((size_t)slices * kRecWords);

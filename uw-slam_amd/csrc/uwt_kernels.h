@@ -328,6 +328,26 @@ __device__ __forceinline__ void accumulate(double acc[kAccFloats], const float J
   for (int i = 0; i < 6; i++) acc[21 + i] = __builtin_fma(Jd[i], rd, acc[21 + i]);
 }
 
+// General path: J <- w·J, r <- gain·r, A += (wJ)(wJ)ᵀ, jtr += (wJ)·((gain r)·w) (src/Tracker.cpp:554-561) and the error
+// numerator Σ r·(r·w) (:499-502).  An invalid (sanitised) pixel has J = 0 and r = 0, so it adds exact zeros.
+template <typename AccT>
+__device__ __forceinline__ void accumulate_weighted(AccT acc[kAccFloats], AccT& err, const float J[6], float rf, float w,
+                                                    float gain) {
+  const float rw1 = rf * w;
+  err = (AccT)__builtin_fma((double)rf, (double)rw1, (double)err);
+  const float rw = (rf * gain) * w;
+  double Jd[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) Jd[k] = (double)(w * J[k]);
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++, s++) acc[s] = (AccT)__builtin_fma(Jd[i], Jd[j], (double)acc[s]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) acc[21 + i] = (AccT)__builtin_fma(Jd[i], (double)rw, (double)acc[21 + i]);
+}
+
 // Deterministic block reduction of the per-thread accumulators through LDS (fixed order, no atomics).
 // Threads accumulate a handful of pixels in f32; from here on every sum is f64 so that the totals are, to ~1e-9,
 // the exact sums the reference's double-accumulating gemm produces (src/Tracker.cpp:560-561).
@@ -388,6 +408,50 @@ __device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], u
   }
 }
 
+// robust weights / bilinear sampler shared by the dense kernels and the general (dump-capable) kernel
+enum { kWeightsIdentity = 0, kWeightsTukeyRef = 1, kWeightsHuber = 2 };
+constexpr int kHistBins = 512;  // signed residual bins q + 255 (0..510) / deviation bins 0..510
+
+struct PairScale {
+  float med0;     // median of the (saturated / signed) residuals
+  float inv_mad;  // 1 / (1.4826 * median deviation), 1 / 1 when that is 0
+  int n_valid;
+  int pad;
+};
+
+// EXTENSION: bilinear sample; same f32 operation order as the oracle's uwo_bilinear_u8
+__device__ __forceinline__ float sample_bilinear(const uint8_t* __restrict__ I2, const LevelK& L, float x, float y) {
+  const float x0 = floorf(x), y0 = floorf(y);
+  const float ax = x - x0, ay = y - y0;
+  const int ix0 = min((int)x0, L.w - 1), iy0 = min((int)y0, L.h - 1);
+  const int ix1 = min(ix0 + 1, L.w - 1), iy1 = min(iy0 + 1, L.h - 1);
+  const float a = (float)I2[iy0 * L.w + ix0], b = (float)I2[iy0 * L.w + ix1];
+  const float c = (float)I2[iy1 * L.w + ix0], d = (float)I2[iy1 * L.w + ix1];
+  const float top = __builtin_fmaf(ax, b - a, a);
+  const float bot = __builtin_fmaf(ax, d - c, c);
+  return __builtin_fmaf(ay, bot - top, top);
+}
+
+__device__ __forceinline__ float robust_weight(int mode, float rf, float inv_mad) {
+  if (mode == kWeightsTukeyRef) {  // Tracker::TukeyFunctionWeights, src/Tracker.cpp:1626-1654
+    const float b = 4.6851f;
+    const float inv_b2 = (float)(1.0 / (double)(b * b));
+    const float x = rf * inv_mad;
+    if (fabsf(x) <= b) {
+      const float t = (float)(1.0 - (double)((x * x) * inv_b2));
+      return t * t;
+    }
+    return 0.f;
+  }
+  if (mode == kWeightsHuber) {  // EXTENSION
+    const float k = 1.345f;
+    const float ax = fabsf(rf * inv_mad);
+    return ax <= k ? 1.0f : k / ax;
+  }
+  return 1.0f;
+}
+
+
 // ------------------------------------------------------------------------------------------------------------
 // k_residual: one launch = one Gauss-Newton residual evaluation of one pyramid level for a whole batch.
 // grid = (slices, pairs); each block walks `groups_per_block` groups of VEC consecutive pixels of its pair's
@@ -409,6 +473,8 @@ struct ResidualArgs {
   int slices;
   int pair_base;            // first pair of this launch (sub-batches run on separate streams)
   uint32_t* partials;       // [pair][slice][kRecWords]
+  const PairScale* scale;   // robust-weight scale per pair (WEIGHTS != 0)
+  float gain;               // residual gain, applied inside the kernel on the weighted / bilinear path (src/Tracker.cpp:559)
   float* dumpJ;             // optional per-pixel dumps (DUMP only)
   float* dumpR;
   uint8_t* dumpV;
@@ -444,7 +510,7 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
   }
 }
 
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false>
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0>
 __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int pair, const int slice) {
   Pose pose;
   if (a.state) {
@@ -474,6 +540,10 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
 #pragma unroll
   for (int i = 0; i < kAccFloats; i++) acc[i] = (AccT)0;
   uint32_t sum_r2 = 0, n_valid = 0;
+  constexpr bool GENERAL = SAMPLER != 0 || WEIGHTS != 0;  // float residuals and/or robust weights
+  AccT err = (AccT)0;                                      // Σ r·(r·w), the error numerator on the general path
+  float inv_mad = 1.f;
+  if constexpr (WEIGHTS != 0) inv_mad = a.scale[pair].inv_mad;
 
   const int n_groups = L.n / VEC;
   const int g_begin = slice * a.groups_per_block;
@@ -521,12 +591,14 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
         pixel_warp(L, K, xf0 + (float)j, yf, z, okin, x2[jj], y2[jj], iz[jj], ok[jj], gidx[jj]);
       }
       int i2[PH];
+      float s2[PH];
 #pragma unroll
       for (int jj = 0; jj < PH; jj++) {
 #if defined(UWT_EXP_NOGATHER) || defined(UWT_EXP_NOMEM)
         i2[jj] = (int)cur.i1[j0 + jj] + (int)(gidx[jj] & 1);
 #else
-        i2[jj] = I2[gidx[jj]];                      // nearest-neighbour gather of the target level (:472)
+        if constexpr (SAMPLER == 0) i2[jj] = I2[gidx[jj]];   // nearest-neighbour gather of the target level (:472)
+        else s2[jj] = sample_bilinear(I2, L, x2[jj], y2[jj]);  // EXTENSION; x2 = y2 = 0 for sanitised invalid pixels
 #endif
       }
       float J[PH][6];
@@ -540,8 +612,18 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
 #pragma unroll
       for (int jj = 0; jj < PH; jj++) {
         const int j = j0 + jj;
-        const int ri = ok[jj] ? i2[jj] - (int)cur.i1[j] : 0;
-        accumulate(acc, J[jj], ri);
+        int ri = 0;
+        if constexpr (!GENERAL) {
+          ri = ok[jj] ? i2[jj] - (int)cur.i1[j] : 0;
+          accumulate(acc, J[jj], ri);
+        } else {
+          float rf;
+          if constexpr (SAMPLER == 0) rf = (float)(ok[jj] ? i2[jj] - (int)cur.i1[j] : 0);
+          else rf = ok[jj] ? s2[jj] - (float)cur.i1[j] : 0.f;
+          const float w = robust_weight(WEIGHTS, rf, inv_mad);
+          accumulate_weighted(acc, err, J[jj], rf, w, a.gain);
+          ri = (int)rintf(rf);
+        }
         sum_r2 += (uint32_t)(ri * ri);
         n_valid += ok[jj] ? 1u : 0u;
         if constexpr (DUMP) {
@@ -556,7 +638,7 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
       }
     }
   }
-  block_reduce_store<AccT>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + slice) * kRecWords);
+  block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + slice) * kRecWords, err);
 #ifdef UWT_EXP_CLOCK
   if (threadIdx.x == 0) {  // diagnostic build only: shader-clock and 100 MHz real-time deltas of this block
     unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.partials + ((size_t)pair * a.slices + slice) * kRecWords) + 30;
@@ -571,9 +653,9 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
 #else
 #define UWT_RESIDUAL_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(UWT_EXP_WAVES, UWT_EXP_WAVES)))
 #endif
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false>
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0>
 __global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
-  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
+  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -581,16 +663,6 @@ __global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
 // Not the throughput path — one pixel per thread step, three passes per iteration when weights are on
 // (residual histogram -> median, deviation histogram -> MAD, weighted accumulation).
 // ------------------------------------------------------------------------------------------------------------
-enum { kWeightsIdentity = 0, kWeightsTukeyRef = 1, kWeightsHuber = 2 };
-constexpr int kHistBins = 512;  // signed residual bins q + 255 (0..510) / deviation bins 0..510
-
-struct PairScale {
-  float med0;     // median of the (saturated / signed) residuals
-  float inv_mad;  // 1 / (1.4826 * median deviation), 1 / 1 when that is 0
-  int n_valid;
-  int pad;
-};
-
 struct GeneralArgs {
   int sampler;            // 0 nearest, 1 bilinear
   int weights;            // kWeights*
@@ -599,19 +671,6 @@ struct GeneralArgs {
   unsigned int* hist;     // [pair][kHistBins]: signed bins q + 255 of the rounded residuals
   PairScale* scale;       // [pair]
 };
-
-// EXTENSION: bilinear sample; same f32 operation order as the oracle's uwo_bilinear_u8
-__device__ __forceinline__ float sample_bilinear(const uint8_t* __restrict__ I2, const LevelK& L, float x, float y) {
-  const float x0 = floorf(x), y0 = floorf(y);
-  const float ax = x - x0, ay = y - y0;
-  const int ix0 = min((int)x0, L.w - 1), iy0 = min((int)y0, L.h - 1);
-  const int ix1 = min(ix0 + 1, L.w - 1), iy1 = min(iy0 + 1, L.h - 1);
-  const float a = (float)I2[iy0 * L.w + ix0], b = (float)I2[iy0 * L.w + ix1];
-  const float c = (float)I2[iy1 * L.w + ix0], d = (float)I2[iy1 * L.w + ix1];
-  const float top = __builtin_fmaf(ax, b - a, a);
-  const float bot = __builtin_fmaf(ax, d - c, c);
-  return __builtin_fmaf(ay, bot - top, top);
-}
 
 // one pixel of the dense table: warp, validity, residual (either sampler)
 template <bool DEPTH>
@@ -632,25 +691,6 @@ __device__ __forceinline__ bool general_pixel(const ResidualArgs& a, const Level
   const int i1 = I1[idx];
   rf = sampler ? sample_bilinear(I2, L, x2, y2) - (float)i1 : (float)((int)I2[gidx] - i1);
   return valid;
-}
-
-__device__ __forceinline__ float robust_weight(int mode, float rf, float inv_mad) {
-  if (mode == kWeightsTukeyRef) {  // Tracker::TukeyFunctionWeights, src/Tracker.cpp:1626-1654
-    const float b = 4.6851f;
-    const float inv_b2 = (float)(1.0 / (double)(b * b));
-    const float x = rf * inv_mad;
-    if (fabsf(x) <= b) {
-      const float t = (float)(1.0 - (double)((x * x) * inv_b2));
-      return t * t;
-    }
-    return 0.f;
-  }
-  if (mode == kWeightsHuber) {  // EXTENSION
-    const float k = 1.345f;
-    const float ax = fabsf(rf * inv_mad);
-    return ax <= k ? 1.0f : k / ax;
-  }
-  return 1.0f;
 }
 
 template <bool DEPTH>
@@ -679,6 +719,75 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist(const ResidualArgs a, con
   unsigned int* gh = ga.hist + (size_t)pair * kHistBins;
   for (int i = threadIdx.x; i < kHistBins; i += kBlock)
     if (h[i]) atomicAdd(&gh[i], h[i]);
+}
+
+// Vector form used by the alignment loop: same group walk as residual_block (VEC pixels per step, planes prefetched),
+// and kHistRep lane-interleaved replicas of the LDS histogram — residuals pile up around 0, and same-address LDS
+// atomics of one wave serialise.
+constexpr int kHistRep = 8;
+
+template <int VEC, bool DEPTH, int SAMPLER>
+__global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, unsigned int* __restrict__ hist) {
+  const int pair = blockIdx.y + a.pair_base;
+  const PairState st = a.state[pair];
+  if (st.level_done || st.status) return;
+  __shared__ unsigned int h[kHistRep][kHistBins];
+  for (int i = threadIdx.x; i < kHistRep * kHistBins; i += kBlock) (&h[0][0])[i] = 0;
+  __syncthreads();
+  WarpK K;
+  pose_to_T12(st.pose, K.T);
+  const LevelK L = a.L;
+  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
+  const uint8_t* __restrict__ I1 = a.img + ref_off;
+  const uint8_t* __restrict__ I2 = a.img + tgt_off;
+  const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
+  unsigned int* myh = h[threadIdx.x & (kHistRep - 1)];
+  const int n_groups = L.n / VEC;
+  const int g_begin = blockIdx.x * a.groups_per_block, g_end = min(g_begin + a.groups_per_block, n_groups);
+  for (int g = g_begin + (int)threadIdx.x; g < g_end; g += kBlock) {
+    const uint32_t idx = (uint32_t)g * VEC;
+    const uint32_t y = __umulhi(idx, L.magic), x = idx - y * L.w;
+    uint8_t i1[VEC];
+    uint16_t dp[VEC];
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<uint32_t*>(i1) = *reinterpret_cast<const uint32_t*>(I1 + idx);
+      if constexpr (DEPTH) *reinterpret_cast<uint2*>(dp) = *reinterpret_cast<const uint2*>(DP + idx);
+    } else {
+      i1[0] = I1[idx];
+      if constexpr (DEPTH) dp[0] = DP[idx];
+    }
+    float x2[VEC], y2[VEC], iz;
+    bool ok[VEC];
+    uint32_t gidx[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      float z = 1.0f;
+      bool okin = true;
+      if constexpr (DEPTH) {
+        const int d = (int)(int16_t)dp[j];
+        okin = d > 0;
+        z = (float)d * L.zscale;
+      }
+      pixel_warp(L, K, (float)x + (float)j, (float)y, z, okin, x2[j], y2[j], iz, ok[j], gidx[j]);
+    }
+    float rf[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      if constexpr (SAMPLER == 0) rf[j] = (float)((int)I2[gidx[j]] - (int)i1[j]);
+      else rf[j] = sample_bilinear(I2, L, x2[j], y2[j]) - (float)i1[j];
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; j++)
+      if (ok[j]) atomicAdd(&myh[(int)rintf(rf[j]) + 255], 1u);
+  }
+  __syncthreads();
+  unsigned int* gh = hist + (size_t)pair * kHistBins;
+  for (int i = threadIdx.x; i < kHistBins; i += kBlock) {
+    unsigned int t = 0;
+#pragma unroll
+    for (int r = 0; r < kHistRep; r++) t += h[r][i];
+    if (t) atomicAdd(&gh[i], t);
+  }
 }
 
 // Scale from the signed residual histogram alone (residuals are integers, or are binned by their rounded value):
