@@ -484,3 +484,27 @@ def test_failing_pair_does_not_disturb_its_batch(capi, O, synth):
             assert np.array_equal(poses[i], cpu[i][1])
         else:
             assert np.array_equal(poses[i], np.array([0, 0, 0, 1, 0, 0, 0], np.float32)) and stats[i]["iterations"] == 1
+
+
+@pytest.mark.parametrize("depth", [False, True])
+def test_non_square_intrinsics(capi, O, synth, depth):
+    """fx != fy (EUROC-like) takes the general Jw formulation instead of the fx == fy specialisation."""
+    w, h, n = 160, 96, 4
+    intr = (458.654 * w / 752, 457.296 * w / 752, 367.215 * w / 752 - 8, 248.375 * w / 752 - 4)
+    over = dict(n_levels=4, first_level=3, last_level=0, max_iters=5, early_exit=0, has_depth=int(depth))
+    ctx = make_ctx(capi, w, h, intr, max_frames=2 * n, max_pairs=n, **over)
+    p = O.default_params(w, h, *intr, **over)
+    frames, depths, cpu = [], [], []
+    for s in range(n):
+        ref, tgt, dep, _, _ = synth.render_pair(w, h, *intr, seed=7200 + s, with_depth=depth)
+        frames += [ref, tgt]
+        depths += [dep, dep]
+        cpu.append(O.align_pair(p, ref, tgt, dep if depth else None))
+    ctx.upload_frames(0, np.stack(frames), np.stack(depths) if depth else None)
+    ctx.build_pyramids(0, 2 * n)
+    ctx.apply_gradient(0, 2 * n)
+    poses, stats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1, raise_on_pair_failure=True)
+    for i in range(n):
+        assert cpu[i][0] == 0 and np.array_equal(poses[i], cpu[i][1])
+    out = ctx.residual_jacobian(0, 1, 1, cpu[0][1])
+    assert out["n_valid"] > 0
