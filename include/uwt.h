@@ -172,6 +172,11 @@ int uwt_residual_jacobian_weighted(uwt_ctx* ctx, int32_t ref_slot, int32_t tgt_s
  * 39-146) on the GPU reduction.  A: 36 row-major, b: 6 (stored sign: b = -Σ w r J), error, count. */
 int uwt_ls_accumulate(uwt_ctx* ctx, const float* J, const float* r, const float* w_or_null, int32_t n, int32_t divide,
                       float A[36], float b[6], float* error, int32_t* num_constraints);
+/* LS::initialize + (n/4) x LS::updateSSE + LS::finishNoDivide / finish (src/LeastSquares.cpp:148-202): the 4-wide form's
+ * product association ((J_i·w)·J_j, (r·w)·J_i, (r·w)·r); n must be a multiple of 4.  count_quirk != 0 reproduces
+ * "num_constraints += 6" per four points (:201); 0 counts 4. */
+int uwt_ls_accumulate_sse(uwt_ctx* ctx, const float* J, const float* r, const float* w, int32_t n, int32_t divide,
+                          int32_t count_quirk, float A[36], float b[6], float* error, int32_t* num_constraints);
 /* Sophus::SE3f::exp (thirdparty/sophus/se3.hpp:723-744) */
 int uwt_se3_exp(uwt_ctx* ctx, const float xi[6], float pose_out[7]);
 /* SE3f::operator* (se3.hpp:285-321) */

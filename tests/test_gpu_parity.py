@@ -262,6 +262,14 @@ def test_ls_accumulate_matches_oracle_ls(capi, O, golden_dir):
     assert np.isclose(err, (rd * rd * wd).sum(), rtol=1e-6) and np.array_equal(A, A.T)
     A, b, err, n = ctx.ls_accumulate(np.zeros((0, 6), np.float32), np.zeros(0, np.float32))
     assert n == 0 and not A.any() and not b.any() and err == 0.0   # LS::initialize state
+    # LS::updateSSE form incl. the "+= 6 per 4 points" quirk (src/LeastSquares.cpp:201)
+    A4, b4, e4, n4 = ctx.ls_accumulate_sse(g["J"], g["r"], g["w"], divide=False, count_quirk=True)
+    assert n4 == 24 == int(g["n_sse"])
+    assert np.allclose(A4, g["A_sse"], rtol=1e-5, atol=1e-3) and np.allclose(b4, g["b_sse"], rtol=1e-5, atol=1e-2)
+    assert np.isclose(e4, float(g["err_sse"]), rtol=1e-5)
+    assert ctx.ls_accumulate_sse(g["J"], g["r"], g["w"], count_quirk=False)[3] == 16
+    with pytest.raises(capi.UwtError):
+        ctx.ls_accumulate_sse(g["J"][:5], g["r"][:5], g["w"][:5])
 
 
 # ------------------------------------------------------------------ whole alignment

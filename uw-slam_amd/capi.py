@@ -52,7 +52,7 @@ SYMBOLS = [
     "uwt_residual_jacobian_weighted", "uwt_estimate_pose_points", "uwt_gradient_magnitude",
     "uwt_obtain_candidate_points", "uwt_obtain_patch_points",
     "uwt_ingest_create", "uwt_ingest_destroy", "uwt_ingest_maps", "uwt_ingest_undistort", "uwt_ingest_calculate_roi",
-    "uwt_ingest_frame", "uwt_update_params", "uwt_get_params",
+    "uwt_ingest_frame", "uwt_update_params", "uwt_get_params", "uwt_ls_accumulate_sse",
 ]
 
 _lib = None
@@ -288,6 +288,20 @@ class Context:
             wp = _p(w, C.c_float)
         self._chk(lib().uwt_ls_accumulate(self._h, _p(J, C.c_float), _p(r, C.c_float), wp, r.size, int(divide),
                                           _p(A, C.c_float), _p(b, C.c_float), C.byref(err), C.byref(cnt)))
+        return A.reshape(6, 6), b, err.value, cnt.value
+
+    def ls_accumulate_sse(self, J, r, w=None, divide=False, count_quirk=True):
+        J = np.ascontiguousarray(J, np.float32)
+        r = np.ascontiguousarray(r, np.float32)
+        A = np.empty(36, np.float32)
+        b = np.empty(6, np.float32)
+        err, cnt = C.c_float(), C.c_int32()
+        wp = None
+        if w is not None:
+            w = np.ascontiguousarray(w, np.float32)
+            wp = _p(w, C.c_float)
+        self._chk(lib().uwt_ls_accumulate_sse(self._h, _p(J, C.c_float), _p(r, C.c_float), wp, r.size, int(divide),
+                                              int(count_quirk), _p(A, C.c_float), _p(b, C.c_float), C.byref(err), C.byref(cnt)))
         return A.reshape(6, 6), b, err.value, cnt.value
 
     def se3_exp(self, xi):

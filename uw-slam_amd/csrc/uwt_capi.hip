@@ -1043,8 +1043,8 @@ int uwt_residual_jacobian_weighted(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slo
   return UWT_OK;
 }
 
-int uwt_ls_accumulate(uwt_ctx* c, const float* J, const float* r, const float* w, int32_t n, int32_t divide, float A[36],
-                      float b[6], float* error, int32_t* num_constraints) {
+static int ls_accumulate_impl(uwt_ctx* c, const float* J, const float* r, const float* w, int32_t n, int32_t divide, bool sse,
+                              int32_t count, float A[36], float b[6], float* error, int32_t* num_constraints) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !J || !r || !A || !b || !error || !num_constraints || n < 0) return fail(c, UWT_ERR_INVALID_ARG, "uwt_ls_accumulate");
   const int blocks = n == 0 ? 1 : std::min(1024, (n + kBlock - 1) / kBlock);
@@ -1060,7 +1060,8 @@ int uwt_ls_accumulate(uwt_ctx* c, const float* J, const float* r, const float* w
     HIPCHK(c, hipMemcpyAsync(dr, r, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     if (w) HIPCHK(c, hipMemcpyAsync(dw, w, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
   }
-  hipLaunchKernelGGL(k_ls_accumulate, dim3(blocks), dim3(kBlock), 0, c->stream, dJ, dr, w ? dw : nullptr, n, dp);
+  if (sse) hipLaunchKernelGGL(k_ls_accumulate<true>, dim3(blocks), dim3(kBlock), 0, c->stream, dJ, dr, w ? dw : nullptr, n, dp);
+  else hipLaunchKernelGGL(k_ls_accumulate<false>, dim3(blocks), dim3(kBlock), 0, c->stream, dJ, dr, w ? dw : nullptr, n, dp);
   HIPCHK(c, hipGetLastError());
   std::vector<float> parts((size_t)blocks * 28);
   HIPCHK(c, hipMemcpyAsync(parts.data(), dp, parts.size() * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1073,14 +1074,25 @@ int uwt_ls_accumulate(uwt_ctx* c, const float* J, const float* r, const float* w
     for (int j = i; j < 6; j++, q++) { A[6 * i + j] = (float)s[q]; A[6 * j + i] = (float)s[q]; }
   for (int i = 0; i < 6; i++) b[i] = (float)(-s[21 + i]);  // LS stores b = -Σ w r J (src/LeastSquares.cpp:206)
   *error = (float)s[27];
-  *num_constraints = n;  // one per LS::update call (:208)
+  *num_constraints = count;
   if (divide) {          // LS::finish (:141-146)
-    const float nf = (float)n;
+    const float nf = (float)count;
     for (int i = 0; i < 36; i++) A[i] = A[i] / nf;
     for (int i = 0; i < 6; i++) b[i] = b[i] / nf;
     *error = *error / nf;
   }
   return UWT_OK;
+}
+
+int uwt_ls_accumulate(uwt_ctx* c, const float* J, const float* r, const float* w, int32_t n, int32_t divide, float A[36],
+                      float b[6], float* error, int32_t* num_constraints) {
+  return ls_accumulate_impl(c, J, r, w, n, divide, false, n /* one per LS::update call (:208) */, A, b, error, num_constraints);
+}
+
+int uwt_ls_accumulate_sse(uwt_ctx* c, const float* J, const float* r, const float* w, int32_t n, int32_t divide,
+                          int32_t count_quirk, float A[36], float b[6], float* error, int32_t* num_constraints) {
+  if (n < 0 || (n & 3)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_ls_accumulate_sse: n must be a multiple of 4");
+  return ls_accumulate_impl(c, J, r, w, n, divide, true, count_quirk ? (n / 4) * 6 : n, A, b, error, num_constraints);
 }
 
 int uwt_se3_exp(uwt_ctx* c, const float xi[6], float pose_out[7]) {

@@ -1141,6 +1141,7 @@ __global__ void k_warp_table(const float4* __restrict__ pts, float4* __restrict_
 
 // LS::update over n rows (src/LeastSquares.cpp:204-209) as a grid reduction: thread-sequential over a strided
 // subset, then the same deterministic block fold; weights enter as (J_i·J_j)·w, (r·w)·J_i, (r·r)·w.
+template <bool SSE_ORDER>
 __global__ __launch_bounds__(kBlock) void k_ls_accumulate(const float* __restrict__ J, const float* __restrict__ r,
                                                           const float* __restrict__ w, int n, float* partials) {
   float acc[28];
@@ -1155,11 +1156,13 @@ __global__ __launch_bounds__(kBlock) void k_ls_accumulate(const float* __restric
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
-      for (int j = i; j < 6; j++, s++) acc[s] += (Jr[i] * Jr[j]) * wi;
+      for (int j = i; j < 6; j++, s++)
+        acc[s] += SSE_ORDER ? (Jr[i] * wi) * Jr[j]    // LS::updateSSE: J1w = J1*weight; J1w*J2 (src/LeastSquares.cpp:151-153)
+                            : (Jr[i] * Jr[j]) * wi;   // LS::update: J * J^T * weight (:205)
     const float rw = ri * wi;
 #pragma unroll
-    for (int i = 0; i < 6; i++) acc[21 + i] += Jr[i] * rw;
-    acc[27] += ri * ri * wi;
+    for (int i = 0; i < 6; i++) acc[21 + i] += SSE_ORDER ? rw * Jr[i] : Jr[i] * rw;
+    acc[27] += SSE_ORDER ? rw * ri : ri * ri * wi;   // (res*weight)*res (:198) vs res*res*weight (:207)
   }
   __shared__ float red[28][kBlock];
   const int tid = threadIdx.x;
