@@ -27,11 +27,11 @@ if ROOT not in sys.path:
 
 ALG_BYTES_PER_PIXEL_ITER = 10          # I_ref 1 + gx 2 + gy 2 + z 4 + I_tgt 1
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
-# HBM traffic of the residual kernel from rocprofv3 PMC passes (profiles/r01/pmc_summary_bench_p512_pipelined.csv): per
-# k_step launch (one half-batch of 256 pairs), averaged over the four levels, 2 x FETCH_SIZE + WRITE_SIZE =
-# 2 x 103040.97 + 851.75 KiB (the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM; it reproduces the
-# compulsory byte count of this access pattern).  Only valid for the default workload (640x480, 4 levels, u16 depth).
-TRAFFIC_BYTES_PER_PAIR_LAUNCH = (2 * 103040.97 + 851.75) * 1024.0 / 256.0
+# HBM traffic of the residual kernel from rocprofv3 PMC passes (profiles/r01/pmc_summary_bench_default_p1024.csv): per
+# k_residual launch of 1024 pairs, averaged over the four levels, 2 x FETCH_SIZE + WRITE_SIZE = 2 x 409242.35 + 3328.0 KiB
+# (the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM; it reproduces the compulsory byte count of this
+# access pattern, 8 B per pixel).  Only valid for the default workload (640x480, 4 levels, u16 depth plane).
+TRAFFIC_BYTES_PER_PAIR_LAUNCH = (2 * 409242.35 + 3328.0) * 1024.0 / 1024.0
 
 
 def main():
@@ -188,7 +188,7 @@ def main():
             alg_bytes = ALG_BYTES_PER_PIXEL_ITER * res_pixels
             achieved = alg_bytes / (res_ms * 1e-3) / 1e9
             out["roofline"] = {
-                "bound": "hbm", "kernel": "k_step (fused warp+residual+Jacobian+reduction of one half-batch, + GN update of the other)",
+                "bound": "hbm", "kernel": "k_residual (fused warp+residual+Jacobian+reduction)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": (int(TRAFFIC_BYTES_PER_PAIR_LAUNCH * res_pixels / res_launches / px_per_align * args.levels)

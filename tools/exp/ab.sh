@@ -4,6 +4,6 @@ rounds=$1; shift
 for r in $(seq 1 $rounds); do
   for v in "$@"; do
     cp tools/exp/lib_$v.so uw-slam_amd/libuwt_hip.so
-    UWT_PIPELINE=0 tools/exp/run_l0.sh "$v#$r" UWT_PIPELINE=0
+    tools/exp/run_l0.sh "$v#$r"
   done
 done

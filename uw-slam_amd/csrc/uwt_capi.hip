@@ -27,7 +27,6 @@ struct uwt_ctx {
   int slices[UWT_MAX_LEVELS];
   int groups_per_block[UWT_MAX_LEVELS];
   hipStream_t stream = nullptr;
-  int pipeline = 1;                     // 1: two half-batches pipelined through k_step (fixed-iteration mode)
   uint8_t* img[UWT_MAX_LEVELS] = {};
   uint16_t* depth[UWT_MAX_LEVELS] = {};
   int16_t* gx[UWT_MAX_LEVELS] = {};
@@ -315,36 +314,6 @@ int launch_general_dump(uwt_ctx* c, ResidualArgs ra, int n_pairs) {
   return UWT_OK;
 }
 
-template <int VEC, bool DEPTH, bool UNIT>
-void launch_step_t(hipStream_t s, const ResidualArgs& ra, const UpdateArgs& ua, int n_upd, int n_res, bool acc64) {
-  const int blocks = n_upd + n_res * ra.slices;
-  if (blocks == 0) return;
-  if (acc64 && UNIT && VEC == 4 && ra.L.fx == ra.L.fy && n_res > 0)
-    hipLaunchKernelGGL((k_step<VEC, DEPTH, UNIT, double, true>), dim3(blocks), dim3(kBlock), 0, s, ra, ua, n_upd);
-  else if (acc64)
-    hipLaunchKernelGGL((k_step<VEC, DEPTH, UNIT, double>), dim3(blocks), dim3(kBlock), 0, s, ra, ua, n_upd);
-  else
-    hipLaunchKernelGGL((k_step<VEC, DEPTH, UNIT, float>), dim3(blocks), dim3(kBlock), 0, s, ra, ua, n_upd);
-}
-
-int launch_step(uwt_ctx* c, const ResidualArgs& ra, const UpdateArgs& ua, int n_upd, int n_res) {
-  const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f), acc64 = c->p.accumulate_f64 != 0;
-  const int key = (c->vec == 4 ? 4 : 0) | (depth ? 2 : 0) | (unit ? 1 : 0);
-  hipStream_t s = c->stream;
-  switch (key) {
-    case 0: launch_step_t<1, false, false>(s, ra, ua, n_upd, n_res, acc64); break;
-    case 1: launch_step_t<1, false, true>(s, ra, ua, n_upd, n_res, acc64); break;
-    case 2: launch_step_t<1, true, false>(s, ra, ua, n_upd, n_res, acc64); break;
-    case 3: launch_step_t<1, true, true>(s, ra, ua, n_upd, n_res, acc64); break;
-    case 4: launch_step_t<4, false, false>(s, ra, ua, n_upd, n_res, acc64); break;
-    case 5: launch_step_t<4, false, true>(s, ra, ua, n_upd, n_res, acc64); break;
-    case 6: launch_step_t<4, true, false>(s, ra, ua, n_upd, n_res, acc64); break;
-    default: launch_step_t<4, true, true>(s, ra, ua, n_upd, n_res, acc64); break;
-  }
-  HIPCHK(c, hipGetLastError());
-  return UWT_OK;
-}
-
 UpdateArgs update_args(uwt_ctx* c, int lvl) {
   UpdateArgs ua;
   std::memset(&ua, 0, sizeof(ua));
@@ -355,65 +324,7 @@ UpdateArgs update_args(uwt_ctx* c, int lvl) {
   ua.early_exit = c->p.early_exit;
   ua.epsilon = c->p.epsilon;
   ua.gain = c->p.gain;
-  ua.level = lvl;
-  ua.scale_t = c->p.handoff_scale_t;
-  ua.initial_error = c->p.initial_error;
   return ua;
-}
-
-// Fixed-iteration schedule (early_exit == 0): the batch is cut into halves A and B whose (residual, update) chains are
-// interleaved on ONE stream — launch i carries the update of one half and the residual of the other:
-//   res(A,0) | upd(A,0)+res(B,0) | upd(B,0)+res(A,1) | ... | upd(A,last)+res(B,last) | upd(B,last)
-// The level hand-off rides on the last update of each level, so the chain runs across levels without a bubble.
-int enqueue_estimate_pipelined(uwt_ctx* c, int n_pairs) {
-  const uwt_params& p = c->p;
-  const int nA = (n_pairs + 1) / 2, nB = n_pairs - nA;
-  const int base[2] = {0, nA}, cnt[2] = {nA, nB};
-  struct Item { int lvl, k; };
-  std::vector<Item> seq;
-  for (int lvl = p.first_level; lvl >= p.last_level; lvl--)
-    for (int k = 0; k < p.max_iters; k++) seq.push_back({lvl, k});
-  const int T = (int)seq.size();
-  // launch t (0..2T): residual of chain step t (half t&1, item t>>1) and update of chain step t-1
-  for (int t = 0; t <= 2 * T; t++) {
-    const bool has_res = t < 2 * T, has_upd = t >= 1;
-    ResidualArgs ra;
-    std::memset(&ra, 0, sizeof(ra));
-    ra.slices = 1;
-    int n_res = 0, n_upd = 0;
-    if (has_res) {
-      const int h = t & 1;
-      ra = residual_args(c, seq[t >> 1].lvl);
-      ra.pair_base = base[h];
-      n_res = cnt[h];
-    }
-    UpdateArgs ua;
-    std::memset(&ua, 0, sizeof(ua));
-    if (has_upd) {
-      const int u = t - 1, h = u & 1;
-      const Item it = seq[u >> 1];
-      ua = update_args(c, it.lvl);
-      ua.k = it.k;
-      ua.pair_base = base[h];
-      ua.level_end = (it.k == p.max_iters - 1) ? 1 : 0;
-      n_upd = cnt[h];
-    }
-    if (n_res == 0 && n_upd == 0) continue;
-    size_t ev = 0;
-    const bool prof = c->profiling && n_res > 0;
-    if (prof) {
-      int st = prof_begin(c, &ev);
-      if (st) return st;
-    }
-    int st = launch_step(c, ra, ua, n_upd, n_res);
-    if (st) return st;
-    if (prof) {
-      HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
-      c->prof_launches += 1;
-      c->prof_pixels += (long long)n_res * c->lv[seq[t >> 1].lvl].n;
-    }
-  }
-  return UWT_OK;
 }
 
 // Tracker::EstimatePose for a batch, enqueued on the context's stream (src/Tracker.cpp:362-597)
@@ -424,10 +335,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats)
                      p.initial_error);
   HIPCHK(c, hipGetLastError());
   const bool general = p.sampler != 0 || p.weights != 0;
-  if (!general && !p.early_exit && c->pipeline && n_pairs >= 2) {
-    int st = enqueue_estimate_pipelined(c, n_pairs);
-    if (st) return st;
-  } else {
+  {
     for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
       ResidualArgs ra = residual_args(c, lvl);
       UpdateArgs ua = update_args(c, lvl);
@@ -603,7 +511,6 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   } while (0)
   CREATE_CHK(hipSetDevice(p->device));
   CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-  if (const char* e = std::getenv("UWT_PIPELINE")) c->pipeline = std::atoi(e) != 0;  // tuning experiments only
   for (int l = 0; l < p->n_levels; l++) {
     const size_t n = (size_t)c->lv[l].n * p->max_frames;
     CREATE_CHK(hipMalloc((void**)&c->img[l], n));

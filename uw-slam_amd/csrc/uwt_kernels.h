@@ -939,10 +939,6 @@ struct UpdateArgs {
   float gain;
   int pair_base;
   int general;       // 1: records come from k_residual_general (gain already applied, error numerator in slot 29)
-  int level_end;     // 1: also run the level hand-off after this update (pipelined schedule)
-  int level;
-  int scale_t;
-  float initial_error;
   int* active;       // optional: counts the pairs still iterating after this update (early-exit polling)
 };
 
@@ -961,8 +957,7 @@ __device__ inline void fold_partials(const uint32_t* __restrict__ recs, int slic
   }
 }
 
-// The scalar tail of one GN iteration for one pair; executed by the first wave of the calling block (any block size:
-// lanes >= 64 only take part in the barrier).
+// The scalar tail of one GN iteration for one pair, executed by one wave.
 __device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair) {
   const int lane = threadIdx.x;
   __shared__ double sums[kAccFloats + 1];
@@ -1024,32 +1019,10 @@ __device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair
       if (a.active) atomicAdd(a.active, 1);
     }
   }
-  if (a.level_end) {  // last iteration of the level in the pipelined schedule: hand-off + re-arm (:580-590, :392-393)
-    if (st.status == 0 && a.level != 0) {
-      if (!se3_handoff(st.pose, a.scale_t != 0)) st.status = 1;  // SOPHUS_ENSURE would abort
-    }
-    st.level_done = 0;
-    st.last_error = a.initial_error;
-  }
   a.state[pair] = st;
 }
 
 __global__ __launch_bounds__(64) void k_gn_update(const UpdateArgs a) { update_block(a, (int)blockIdx.x + a.pair_base); }
-
-// k_step: one launch of the pipelined schedule — the GN update of one half of the batch (blocks [0, n_upd), first
-// wave only) next to the residual evaluation of the other half (remaining blocks, pair-major).  The two halves are
-// independent, so the latency-bound updates hide behind the residual blocks, on a single stream.
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE = false>
-__global__ __launch_bounds__(kBlock) void k_step(const ResidualArgs ra, const UpdateArgs ua, const int n_upd) {
-  const int b = blockIdx.x;
-  if (b < n_upd) {
-    update_block(ua, b + ua.pair_base);
-  } else {
-    const int r = b - n_upd;
-    const int pair = r / ra.slices;
-    residual_block<VEC, DEPTH, UNIT_FACTORS, false, AccT, SQUARE>(ra, pair + ra.pair_base, r - pair * ra.slices);
-  }
-}
 
 __global__ void k_set_pose(PairState* state, Pose pose, float initial_error) {
   if (threadIdx.x || blockIdx.x) return;
