@@ -255,7 +255,7 @@ __device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, floa
   int ix2 = round_pos(x2), iy2 = round_pos(y2);
   ix2 = min(ix2, L.w - 1);  // the reference reads one past the edge here (:450, :472); clamp
   iy2 = min(iy2, L.h - 1);
-  gidx = (uint32_t)(iy2 * L.w + ix2);
+  gidx = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;  // 24-bit multiply-add: one full-rate op (dims < 2^24)
 }
 
 // Phase 2: Jw (src/Tracker.cpp:455-467) and Jacobian_row = Jl * Jw (:476-479), reference operation order.
