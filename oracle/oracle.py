@@ -25,7 +25,7 @@ class Params(C.Structure):
         ("epsilon", C.c_float), ("gain", C.c_float), ("z_factor", C.c_float), ("angle_factor", C.c_float),
         ("depth_scale", C.c_float), ("initial_error", C.c_float),
         ("early_exit", C.c_int32), ("has_depth", C.c_int32), ("handoff_scale_t", C.c_int32),
-        ("weights", C.c_int32), ("sampler", C.c_int32),
+        ("weights", C.c_int32), ("sampler", C.c_int32), ("small_products_f64", C.c_int32),
     ]
 
 

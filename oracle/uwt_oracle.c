@@ -296,6 +296,9 @@ int uwo_se3_handoff(float pose[7], int scale_t) {
 /* warp + per-point terms                                                                       */
 /* ------------------------------------------------------------------------------------------ */
 
+static int g_small_f64 = 0;
+void uwo_set_small_products_f64(int on) { g_small_f64 = on; }
+
 /* Tracker::WarpFunction, Tracker.cpp:1417-1471.  The 4x4·4xN product follows S1. */
 void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, float* warped) {
   float T[16];
@@ -310,6 +313,10 @@ void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, 
     Y = Y * z;                     /* :1444 */
     float o[4];
     for (int k = 0; k < 4; k++) {  /* :1450 rigid * P^T */
+      if (g_small_f64) { /* sensitivity study: double accumulation of the generic cv::gemm path */
+        o[k] = (float)((double)T[4 * k] * X + (double)T[4 * k + 1] * Y + (double)T[4 * k + 2] * z + (double)T[4 * k + 3] * w);
+        continue;
+      }
       float s = T[4 * k] * X;
       s = fmaf(T[4 * k + 1], Y, s);
       s = fmaf(T[4 * k + 2], z, s);
@@ -387,6 +394,7 @@ int uwo_residual_jacobian_ex(const uint8_t* img1, const uint8_t* img2, const int
         float jl1 = (float)gy1[(size_t)iy1 * w + ix1]; /* :477 */
         float* Jr = J + 6 * (size_t)nv;
         for (int k = 0; k < 6; k++) { /* :479 Jl * Jw (S1) */
+          if (g_small_f64) { Jr[k] = (float)((double)jl0 * Jw[0][k] + (double)jl1 * Jw[1][k]); continue; }
           float s = jl0 * Jw[0][k];
           s = fmaf(jl1, Jw[1][k], s);
           Jr[k] = s;
@@ -592,6 +600,7 @@ int uwo_estimate_pose(const uwo_params* p, const uwo_frame* prev, const uwo_fram
 int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const uwo_frame* cur,
                              const float* const* tables, const int32_t* n_points,
                              float pose_out[7], uwo_trace* trace, int32_t* n_trace) {
+  g_small_f64 = p->small_products_f64;
   if (p->first_level >= p->n_levels || p->last_level < 0 || p->last_level > p->first_level) return UWO_ERR_INVALID_ARG;
   int cap = (trace && n_trace) ? *n_trace : 0;
   int nt = 0;

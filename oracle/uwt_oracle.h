@@ -70,6 +70,9 @@ typedef struct uwo_params {
   int32_t handoff_scale_t;   /* 0: EstimatePose (:580-590); 1: EstimatePoseFeatures (:856) */
   int32_t weights;           /* UWO_WEIGHTS_* */
   int32_t sampler;           /* UWO_SAMPLER_* (bilinear is a north-star extension, not in the reference) */
+  int32_t small_products_f64;/* 0 (pinned default, S1): 4-term / 2-term products as f32 FMA chains; 1: accumulate them in
+                                f64 and round once, as OpenCV's generic gemm path would.  Sensitivity study only: the GPU
+                                implements S1. */
 } uwo_params;
 
 typedef struct uwo_level {
@@ -114,6 +117,8 @@ int  uwo_se3_handoff(float pose[7], int scale_t);                   /* Tracker.c
 
 /* Tracker::WarpFunction, Tracker.cpp:1417-1471 */
 void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, float* warped);
+/* process-wide switch for the sensitivity study (see uwo_params::small_products_f64) */
+void uwo_set_small_products_f64(int on);
 
 /* per-point loop of Tracker::EstimatePose, Tracker.cpp:432-490.
  * J (n x 6) and r (n) receive the valid rows compacted; idx (n, optional) their point index. */
