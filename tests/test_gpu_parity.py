@@ -516,3 +516,54 @@ def test_non_square_intrinsics(capi, O, synth, depth):
         assert cpu[i][0] == 0 and np.array_equal(poses[i], cpu[i][1])
     out = ctx.residual_jacobian(0, 1, 1, cpu[0][1])
     assert out["n_valid"] > 0
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_per_pixel_terms_bit_exact(capi, O, seed):
+    """Random sizes (vector and scalar level widths), intrinsics (square or not), depth on/off, factors, images with hard
+    edges and saturated regions, large and small motions: valid masks, residuals and Jacobian rows stay bit-identical."""
+    rng = np.random.default_rng(90000 + seed)
+    w = int(rng.choice([32, 48, 80, 96, 112, 160, 208]))
+    h = int(rng.choice([16, 32, 48, 64, 96]))
+    n_levels = 3 if rng.random() < 0.5 else 2
+    fx = float(np.float32(rng.uniform(0.5, 1.5) * w))
+    fy = fx if rng.random() < 0.5 else float(np.float32(fx * rng.uniform(0.9, 1.1)))
+    intr = (fx, fy, float(np.float32(w / 2 + rng.uniform(-5, 5))), float(np.float32(h / 2 + rng.uniform(-5, 5))))
+    depth = bool(rng.random() < 0.5)
+    over = dict(n_levels=n_levels, first_level=n_levels - 1, last_level=0, has_depth=int(depth))
+    if rng.random() < 0.4:
+        over.update(z_factor=float(np.float32(rng.uniform(0.001, 2))), angle_factor=float(np.float32(rng.uniform(0.1, 3))))
+    ref = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    ref[: h // 3] = 255
+    ref[:, : w // 5] = 0
+    tgt = np.roll(ref, (int(rng.integers(-3, 4)), int(rng.integers(-3, 4))), axis=(0, 1))
+    dep = None
+    if depth:
+        dep = rng.integers(0, 40000, (h, w)).astype(np.uint16)
+        dep[rng.random((h, w)) < 0.2] = 0
+    ctx = make_ctx(capi, w, h, intr, **over)
+    _load_pair(ctx, ref, tgt, dep)
+    p = O.default_params(w, h, *intr, **over)
+    a_img, b_img, dp = ref, tgt, dep
+    for lvl in range(n_levels):
+        if lvl:
+            a_img, b_img = O.halve_u8(a_img), O.halve_u8(b_img)
+            dp = O.halve_u16(dp) if depth else None
+        L = O.level_intrinsics(p, lvl)
+        gx, gy = O.scharr3(a_img)
+        pts = O.dense_points(dp, L.w, L.h, lvl)
+        scale = 10.0 ** rng.uniform(-3, -0.5)
+        pose = O.se3_exp((rng.normal(0, 1, 6) * scale).astype(np.float32))
+        wp = O.warp(pts, pose, L)
+        J, r, idx = O.residual_jacobian(a_img, b_img, gx, gy, pts, wp, L, p.z_factor, p.angle_factor)
+        out = ctx.residual_jacobian(0, 1, lvl, pose)
+        valid = np.zeros(L.w * L.h, np.uint8)
+        valid[idx] = 1
+        assert np.array_equal(out["valid"], valid)
+        assert np.array_equal(out["r"][idx], r)
+        assert np.array_equal(out["J"][idx].view(np.uint32), J.view(np.uint32))
+        assert out["n_valid"] == len(idx) and out["sum_r2"] == int((r.astype(np.int64) ** 2).sum())
+        if len(idx):
+            A_ref, b_ref = O.normal_equations(J, r, None, 1.0)
+            assert np.array_equal(out["A"].astype(np.float32), A_ref)
+            assert np.array_equal((-out["jtr"]).astype(np.float32), b_ref)

@@ -261,7 +261,10 @@ __device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, floa
 // Phase 2: Jw (src/Tracker.cpp:455-467) and Jacobian_row = Jl * Jw (:476-479), reference operation order.
 // SQUARE (fx == fy bitwise, decided at launch): (fx*x2) = (fy*x2), (fx*y2) = (fy*y2), fx*iz = fy*iz are the same
 // rounded values, so the reference's products that coincide up to sign are computed once — bit-identical results.
-template <bool UNIT_FACTORS, bool SQUARE = false>
+// SIGNED_ZEROS (the per-stage dump entry points): keep the reference's fma with the structural zero of Jw, which decides
+// the sign of a zero J[0] / J[1] (g0 * a0 = -0, g1 * 0 = +0 -> +0).  The sums never see the difference (x + -0 = x,
+// +0 + -0 = +0), so the solver path drops the two operations.
+template <bool UNIT_FACTORS, bool SQUARE = false, bool SIGNED_ZEROS = false>
 __device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf, float af, float x2, float y2, float iz, float g0,
                                                float g1, float J[6]) {
   const float fx = L.fx, fy = L.fy;
@@ -293,8 +296,13 @@ __device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf, float 
     a2 = a2 * zf; a3 = a3 * af; a4 = a4 * af; a5 = a5 * af;
     b2 = b2 * zf; b3 = b3 * af; b4 = b4 * af; b5 = b5 * af;
   }
-  J[0] = g0 * a0;                                   // fma(g1, 0, g0*a0)
-  J[1] = g1 * b1;                                   // fma(g1, b1, g0*0)
+  if constexpr (SIGNED_ZEROS) {
+    J[0] = __builtin_fmaf(g1, 0.0f, g0 * a0);
+    J[1] = __builtin_fmaf(g1, b1, g0 * 0.0f);
+  } else {
+    J[0] = g0 * a0;
+    J[1] = g1 * b1;
+  }
   J[2] = __builtin_fmaf(g1, b2, g0 * a2);
   J[3] = __builtin_fmaf(g1, b3, g0 * a3);
   J[4] = __builtin_fmaf(g1, b4, g0 * a4);
@@ -607,7 +615,7 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
         const int j = j0 + jj;
         const float g0 = ok[jj] ? (float)cur.gx[j] : 0.f;
         const float g1 = ok[jj] ? (float)cur.gy[j] : 0.f;
-        pixel_jacobian<UNIT_FACTORS, SQUARE>(L, a.zf, a.af, x2[jj], y2[jj], iz[jj], g0, g1, J[jj]);
+        pixel_jacobian<UNIT_FACTORS, SQUARE, DUMP>(L, a.zf, a.af, x2[jj], y2[jj], iz[jj], g0, g1, J[jj]);
       }
 #pragma unroll
       for (int jj = 0; jj < PH; jj++) {
@@ -891,7 +899,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_general(const ResidualArgs 
     const bool ok = general_pixel<DEPTH>(a, L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf);
     float J[6], w = 1.f;
     if (ok) {
-      pixel_jacobian<UNIT_FACTORS>(L, a.zf, a.af, x2, y2, iz, (float)GX[p], (float)GY[p], J);
+      pixel_jacobian<UNIT_FACTORS, false, true>(L, a.zf, a.af, x2, y2, iz, (float)GX[p], (float)GY[p], J);
       w = robust_weight(ga.weights, rf, inv_mad);
       const float rw1 = rf * w;                 // Residuals.mul(W) for the error (:500)
       err += (double)rf * (double)rw1;
@@ -1219,7 +1227,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_points(const ResidualArgs a
       ix2 = min(ix2, L.w - 1);
       iy2 = min(iy2, L.h - 1);
       ri = (int)I2[iy2 * L.w + ix2] - (int)I1[i1x];
-      pixel_jacobian<UNIT_FACTORS>(L, a.zf, a.af, x2, y2, iz, (float)GX[i1x], (float)GY[i1x], J);
+      pixel_jacobian<UNIT_FACTORS, false, DUMP>(L, a.zf, a.af, x2, y2, iz, (float)GX[i1x], (float)GY[i1x], J);
       accumulate(acc, J, ri);
       sum_r2 += (uint32_t)(ri * ri);
       n_valid += 1;
