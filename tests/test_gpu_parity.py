@@ -41,6 +41,7 @@ def make_ctx(capi, w, h, intr, max_frames=2, max_pairs=1, **over):
     return capi.Context(capi.default_params(w, h, *intr, max_frames=max_frames, max_pairs=max_pairs, **over))
 
 
+FUZZ_SEEDS = int(os.environ.get("UWT_FUZZ_SEEDS", "12"))  # raise for a longer hunt
 SMALL = (64.0, 64.0, 31.5, 23.5)
 MID = (131.25, 131.25, 79.5, 47.5)
 TUM = (525.0, 525.0, 319.5, 239.5)
@@ -518,7 +519,7 @@ def test_non_square_intrinsics(capi, O, synth, depth):
     assert out["n_valid"] > 0
 
 
-@pytest.mark.parametrize("seed", range(10))
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS))
 def test_fuzz_per_pixel_terms_bit_exact(capi, O, seed):
     """Random sizes (vector and scalar level widths), intrinsics (square or not), depth on/off, factors, images with hard
     edges and saturated regions, large and small motions: valid masks, residuals and Jacobian rows stay bit-identical."""
@@ -567,3 +568,54 @@ def test_fuzz_per_pixel_terms_bit_exact(capi, O, seed):
             A_ref, b_ref = O.normal_equations(J, r, None, 1.0)
             assert np.array_equal(out["A"].astype(np.float32), A_ref)
             assert np.array_equal((-out["jtr"]).astype(np.float32), b_ref)
+
+
+@pytest.mark.parametrize("seed", range(FUZZ_SEEDS))
+def test_fuzz_whole_alignment_bit_identical(capi, O, synth, seed):
+    """Random solver configurations (level range, iteration cap, early exit, gain, epsilon, factors, weights, sampler,
+    depth, square or non-square intrinsics, vector and scalar level widths): status, iteration count, final error and
+    pose bits equal the oracle's for every pair of a small batch."""
+    rng = np.random.default_rng(91000 + seed)
+    w = int(rng.choice([64, 96, 112, 160, 208]))
+    h = int(rng.choice([32, 48, 64, 96]))
+    n_levels = int(rng.integers(2, 5))
+    while (w >> (n_levels - 1)) < 8 or (h >> (n_levels - 1)) < 4:
+        n_levels -= 1
+    first = int(rng.integers(0, n_levels))
+    last = int(rng.integers(0, first + 1))
+    fx = float(np.float32(rng.uniform(0.7, 1.3) * w))
+    fy = fx if rng.random() < 0.5 else float(np.float32(fx * rng.uniform(0.95, 1.05)))
+    intr = (fx, fy, float(np.float32(w / 2 - 0.5)), float(np.float32(h / 2 - 0.5)))
+    depth = bool(rng.random() < 0.5)
+    over = dict(n_levels=n_levels, first_level=first, last_level=last, has_depth=int(depth),
+                max_iters=int(rng.integers(1, 12)), early_exit=int(rng.random() < 0.5),
+                gain=float(np.float32(rng.choice([1.0, 10.0, 50.0]))), epsilon=float(np.float32(10.0 ** rng.uniform(-5, -2))),
+                handoff_scale_t=int(rng.random() < 0.8))
+    if rng.random() < 0.3:
+        over.update(z_factor=float(np.float32(rng.uniform(0.002, 1))), angle_factor=float(np.float32(rng.uniform(0.5, 2))))
+    r = rng.random()
+    if r < 0.2:
+        over.update(weights=1)
+    elif r < 0.3:
+        over.update(weights=2)
+    elif r < 0.4:
+        over.update(sampler=1)
+    n = 3
+    ctx = make_ctx(capi, w, h, intr, max_frames=2 * n, max_pairs=n, **over)
+    p = O.default_params(w, h, *intr, **over)
+    frames, depths, cpu = [], [], []
+    for s in range(n):
+        ref, tgt, dep, _, _ = synth.render_pair(w, h, *intr, seed=91000 + 10 * seed + s, with_depth=depth,
+                                                max_t=float(rng.uniform(0.002, 0.03)), max_deg=float(rng.uniform(0.1, 1.5)))
+        frames += [ref, tgt]
+        depths += [dep, dep]
+        cpu.append(O.align_pair(p, ref, tgt, dep if depth else None, want_trace=True))
+    ctx.upload_frames(0, np.stack(frames), np.stack(depths) if depth else None)
+    ctx.build_pyramids(0, 2 * n)
+    ctx.apply_gradient(0, 2 * n)
+    poses, stats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1)
+    for i in range(n):
+        assert stats[i]["status"] == cpu[i][0], (over, i)
+        if cpu[i][0] == 0:
+            assert stats[i]["iterations"] == len(cpu[i][2]), (over, i)
+            assert np.array_equal(poses[i], cpu[i][1]), (over, i, poses[i], cpu[i][1])
