@@ -950,18 +950,36 @@ struct UpdateArgs {
   int* active;       // optional: counts the pairs still iterating after this update (early-exit polling)
 };
 
+// Slice order is kept (the f64 sums are order-dependent in the last bit); the loads of kFoldBatch records are issued
+// together so that a level-0 fold (38 slices) costs a few memory round trips instead of one per slice.
+constexpr int kFoldBatch = 8;
+
+template <typename T>
+__device__ __forceinline__ void fold_column(const T* __restrict__ col, int slices, T& sum) {
+  constexpr int kStride = kRecWords * 4 / (int)sizeof(T);  // record stride in units of T
+  int s = 0;
+  for (; s + kFoldBatch <= slices; s += kFoldBatch) {
+    T v[kFoldBatch];
+#pragma unroll
+    for (int u = 0; u < kFoldBatch; u++) v[u] = col[(size_t)(s + u) * kStride];
+#pragma unroll
+    for (int u = 0; u < kFoldBatch; u++) sum += v[u];
+  }
+  for (; s < slices; s++) sum += col[(size_t)s * kStride];
+}
+
 __device__ inline void fold_partials(const uint32_t* __restrict__ recs, int slices, int lane, double& colsum,
                                      long long& isum) {
   colsum = 0.0;
   isum = 0;
-  if (lane < kAccFloats) {
-    for (int s = 0; s < slices; s++) colsum += reinterpret_cast<const double*>(recs + (size_t)s * kRecWords)[lane];
+  if (lane < kAccFloats || lane == 29) {
+    fold_column(reinterpret_cast<const double*>(recs) + lane, slices, colsum);
   } else if (lane == 27) {
-    for (int s = 0; s < slices; s++) isum += recs[(size_t)s * kRecWords + 54];
+    uint32_t n = 0;
+    fold_column(recs + 54, slices, n);   // n_valid <= level pixels < 2^32
+    isum = n;
   } else if (lane == 28) {
-    for (int s = 0; s < slices; s++) isum += reinterpret_cast<const long long*>(recs + (size_t)s * kRecWords)[28];
-  } else if (lane == 29) {
-    for (int s = 0; s < slices; s++) colsum += reinterpret_cast<const double*>(recs + (size_t)s * kRecWords)[29];
+    fold_column(reinterpret_cast<const long long*>(recs) + 28, slices, isum);
   }
 }
 
