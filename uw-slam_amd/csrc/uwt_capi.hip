@@ -358,7 +358,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats)
         const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
         ua.active = poll ? c->d_active : nullptr;
         if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_gn_update, dim3(n_pairs), dim3(64), 0, c->stream, ua);
+        hipLaunchKernelGGL(k_gn_update, dim3(n_pairs), dim3(kUpdateBlock), 0, c->stream, ua);
         HIPCHK(c, hipGetLastError());
         if (poll) {  // reference-mode early exit: stop launching once every pair has left this level
           HIPCHK(c, hipMemcpyAsync(c->h_active, c->d_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -1094,7 +1094,7 @@ int uwt_estimate_pose_points(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, con
       const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
       ua.active = poll ? c->d_active : nullptr;
       if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
-      hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(64), 0, c->stream, ua);
+      hipLaunchKernelGGL(k_gn_update, dim3(1), dim3(kUpdateBlock), 0, c->stream, ua);
       HIPCHK(c, hipGetLastError());
       if (poll) {
         HIPCHK(c, hipMemcpyAsync(c->h_active, c->d_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));

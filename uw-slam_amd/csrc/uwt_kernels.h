@@ -953,6 +953,8 @@ struct UpdateArgs {
 // Slice order is kept (the f64 sums are order-dependent in the last bit); the loads of kFoldBatch records are issued
 // together so that a level-0 fold (38 slices) costs a few memory round trips instead of one per slice.
 constexpr int kFoldBatch = 8;
+constexpr int kUpdateBlock = 256;   // threads of k_gn_update: four waves stage the records, wave 0 folds, lane 0 solves
+constexpr int kStageSlices = 160;   // 40 KB of LDS: a 1280x960 level 0 has 150 slices
 
 template <typename T>
 __device__ __forceinline__ void fold_column(const T* __restrict__ col, int slices, T& sum) {
@@ -990,10 +992,34 @@ __device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair
   __shared__ long long isums[2];
   PairState st = a.state[pair];
   const bool live = !(st.level_done || st.status);  // block-uniform
+  const uint32_t* recs = a.partials + (size_t)pair * a.slices * kRecWords;
+  // All waves of the block pull the pair's records into LDS with one batch of independent 16-byte loads (one memory
+  // round trip for a 640x480 level 0); the fold below then runs in the same slice order out of LDS.
+  __shared__ uint4 stage[kStageSlices * (kRecWords / 4)];
+  const bool staged = a.slices <= kStageSlices;  // block-uniform
+  if (live && staged) {
+    const int n16 = a.slices * (kRecWords / 4);
+    const uint4* g4 = reinterpret_cast<const uint4*>(recs);
+    for (int base = 0; base < n16; base += 4 * kUpdateBlock) {
+      uint4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = base + u * kUpdateBlock + lane;
+        if (i < n16) v[u] = g4[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = base + u * kUpdateBlock + lane;
+        if (i < n16) stage[i] = v[u];
+      }
+    }
+  }
+  __syncthreads();
   if (live && lane < 64) {
     double cs;
     long long is;
-    fold_partials(a.partials + (size_t)pair * a.slices * kRecWords, a.slices, lane, cs, is);
+    if (staged) fold_partials(reinterpret_cast<const uint32_t*>(stage), a.slices, lane, cs, is);
+    else fold_partials(recs, a.slices, lane, cs, is);
     if (lane < kAccFloats) sums[lane] = cs;
     else if (lane < 29) isums[lane - 27] = is;
     else if (lane == 29) sums[kAccFloats] = a.general ? cs : 0.0;
@@ -1048,7 +1074,7 @@ __device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair
   a.state[pair] = st;
 }
 
-__global__ __launch_bounds__(64) void k_gn_update(const UpdateArgs a) { update_block(a, (int)blockIdx.x + a.pair_base); }
+__global__ __launch_bounds__(kUpdateBlock) void k_gn_update(const UpdateArgs a) { update_block(a, (int)blockIdx.x + a.pair_base); }
 
 __global__ void k_set_pose(PairState* state, Pose pose, float initial_error) {
   if (threadIdx.x || blockIdx.x) return;
