@@ -13,6 +13,7 @@ round-robin (pair i -> rank i mod N), one RCCL all_gather of the solved poses pe
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import faulthandler
 import importlib
 import json
 import os
@@ -35,6 +36,8 @@ TRAFFIC_BYTES_PER_PAIR_LAUNCH = (2 * 409242.35 + 3328.0) * 1024.0 / 1024.0
 
 
 def main():
+    # A stalled run ends with every thread's Python traceback instead of sitting there until the caller's clock runs out.
+    faulthandler.dump_traceback_later(int(os.environ.get("UWT_BENCH_WATCHDOG_S", "1500")), exit=True)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)

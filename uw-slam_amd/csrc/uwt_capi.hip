@@ -43,6 +43,7 @@ struct uwt_ctx {
   unsigned int* hist = nullptr;         // general path: [pair][2][kHistBins]
   PairScale* scale = nullptr;           // general path: [pair]
   int* d_active = nullptr;              // early-exit polling counters
+  int target_blocks = 4096;             // blocks per residual launch the batch-dependent slicing aims at (UWT_TARGET_BLOCKS)
   int* h_active = nullptr;              // pinned
   void* scratch = nullptr;              // per-stage entry points
   size_t scratch_bytes = 0;
@@ -339,6 +340,18 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats)
     for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
       ResidualArgs ra = residual_args(c, lvl);
       UpdateArgs ua = update_args(c, lvl);
+      // Slicing follows the batch: the create-time slicing (kGroupsPerThread) gives a single pair enough blocks to spread
+      // over the chip; a batch that fills it alone runs fewer, longer blocks (less reduction overhead per pixel, fewer
+      // records to fold), still at least target_blocks per launch.
+      {
+        const int n_groups = c->lv[lvl].n / c->vec;
+        int want = (c->target_blocks + n_pairs - 1) / n_pairs;
+        want = std::max(1, std::min(want, c->slices[lvl]));
+        const int gpt = (n_groups + want * kBlock - 1) / (want * kBlock);
+        ra.groups_per_block = gpt * kBlock;
+        ra.slices = (n_groups + ra.groups_per_block - 1) / ra.groups_per_block;
+        ua.slices = ra.slices;
+      }
       int next_poll = 2;
       for (int k = 0; k < p.max_iters; k++) {
         size_t ev = 0;
@@ -525,6 +538,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_poses, sizeof(float) * 7 * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_stats, sizeof(StatsOut) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_active, sizeof(int)));
+  if (const char* e = std::getenv("UWT_TARGET_BLOCKS")) c->target_blocks = std::max(1, std::atoi(e));  // tuning experiments only
   if (p->sampler || p->weights) {
     CREATE_CHK(hipMalloc((void**)&c->hist, sizeof(unsigned int) * kHistBins * p->max_pairs));
     CREATE_CHK(hipMalloc((void**)&c->scale, sizeof(PairScale) * p->max_pairs));
