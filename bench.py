@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — frame-pair alignments/s of the MI355X direct SE(3) tracking path (BASELINE.json metric).
 
-One "step" = one pass of the whole hot path over one resident batch: pyramids of every frame of the batch +
-gradients + the full coarse-to-fine Gauss-Newton alignment of every pair (levels 3..0 of a 4-level pyramid,
+One "step" = one pass of the whole hot path over one resident batch: image pyramids of every frame of the batch, depth
+pyramids and gradients of the reference frames + the full coarse-to-fine Gauss-Newton alignment of every pair (levels 3..0 of a 4-level pyramid,
 10 iterations per level, no early exit), poses written to HBM.  N > 1: one process per GPU (torchrun), pairs sharded
 round-robin (pair i -> rank i mod N), one RCCL all_gather of the solved poses per step; weak scaling.
 
@@ -179,7 +179,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": ("synthetic %dx%d pairs, %s, "
-                         "dense points%s, %d pairs resident per GPU (%d distinct), pyramids+gradients+alignment per step"
+                         "dense points%s, %d pairs resident per GPU (%d distinct), image pyramids of both frames + depth pyramid and gradients of the reference frame + alignment per step"
                          % (w, h, "reference schedule: 5 pyramid levels, iterate 4..1, <= 50 iterations, early exit"
                             if args.reference_schedule else
                             "%d pyramid levels (0..%d), %d GN iterations/level, no early exit" % (args.levels, args.levels - 1, args.iters),

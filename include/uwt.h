@@ -137,7 +137,11 @@ int uwt_estimate_pose_batch(uwt_ctx* ctx, int32_t n_pairs, const int32_t* ref_sl
 
 /* Whole per-frame path for a resident batch: pyramids of slots [first_slot, first_slot+n_frames), gradients of
  * the same slots, then EstimatePose for the pairs — enqueued on the context stream, results written to DEVICE
- * memory (d_poses_out: n_pairs x 7 floats, d_stats_out_or_null: n_pairs uwt_stats).  uwt_sync() to wait. */
+ * memory (d_poses_out: n_pairs x 7 floats, d_stats_out_or_null: n_pairs uwt_stats).  uwt_sync() to wait.
+ * grad_refs_only != 0: the planes the tracker reads of the reference frame only — gradients (src/Tracker.cpp:407-408)
+ * and the depth pyramid levels 1.. (:1266-1272) — are built for the pairs' ref_slots alone (wherever they lie);
+ * the image pyramids still cover the whole slot range.  0 prepares every frame of the range fully, as
+ * System::AddFrame / System::Tracking do for each new frame. */
 int uwt_track_batch_async(uwt_ctx* ctx, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only,
                           int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
                           float* d_poses_out, uwt_stats* d_stats_out_or_null);

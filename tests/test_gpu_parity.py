@@ -408,10 +408,10 @@ def test_full_size_1280x960_5_levels(capi, O, synth):
 
 
 def test_track_batch_async_device_outputs_match_sync_path(capi, O, synth):
-    """uwt_track_batch_async (pyramids + reference-only gradients + alignment, poses/stats to device memory, sub-batches
-    on two streams) gives bit-identical poses to the step-by-step synchronous entry points and to the oracle."""
+    """uwt_track_batch_async (pyramids + reference-only gradients + alignment, poses/stats to device memory) gives
+    bit-identical poses to the step-by-step synchronous entry points and to the oracle."""
     import torch
-    w, h, n = 160, 96, 80   # n >= 64 so that the two-stream sub-batching is exercised
+    w, h, n = 160, 96, 80
     over = dict(n_levels=4, first_level=3, last_level=0, max_iters=5, early_exit=0)
     ctx = make_ctx(capi, w, h, MID, max_frames=2 * n, max_pairs=n, **over)
     frames = []
@@ -442,6 +442,40 @@ def test_track_batch_async_device_outputs_match_sync_path(capi, O, synth):
     bad_a = [i for i in range(n) if not np.array_equal(a[i], cpu[i])]
     bad_b = [i for i in range(n) if not np.array_equal(b[i], cpu[i])]
     assert bad_a == [] and bad_b == [], "async!=cpu %s ; sync!=cpu %s ; a==b %s" % (bad_a, bad_b, np.array_equal(a, b))
+
+
+def test_track_batch_async_depth_planes_for_reference_slots_only(capi, O, synth):
+    """grad_refs_only: the depth pyramid (levels 1..) and the gradients are built for the pairs' reference slots only —
+    the target's are never read (src/Tracker.cpp:407-408, 1266-1272) — and the poses equal the oracle's; with the flag off
+    every slot of the range gets them."""
+    import torch
+    w, h, n = 160, 96, 6
+    over = dict(n_levels=3, first_level=2, last_level=0, max_iters=4, early_exit=0, has_depth=1)
+    p = O.default_params(w, h, *MID, **over)
+    frames, depths, cpu = [], [], []
+    for s in range(n):
+        ref, tgt, dep, _, _ = synth.render_pair(w, h, *MID, seed=3300 + s, with_depth=True)
+        frames += [ref, tgt]
+        depths += [dep, (dep // 2 + 7).astype(np.uint16)]  # a different plane in the target slot: it must not matter
+        cpu.append(O.align_pair(p, ref, tgt, dep)[1])
+    ref_s, tgt_s = np.arange(n) * 2, np.arange(n) * 2 + 1
+    for refs_only in (True, False):
+        ctx = make_ctx(capi, w, h, MID, max_frames=2 * n, max_pairs=n, **over)
+        ctx.upload_frames(0, np.stack(frames), np.zeros((2 * n, h, w), np.uint16))
+        ctx.build_pyramids(0, 2 * n)       # every depth level of every slot is zero now
+        ctx.upload_frames(0, np.stack(frames), np.stack(depths))
+        d_poses = torch.zeros((n, 7), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        ctx.track_batch_async(0, 2 * n, ref_s, tgt_s, d_poses.data_ptr(), None, grad_refs_only=refs_only)
+        ctx.sync()
+        assert np.array_equal(d_poses.cpu().numpy(), np.stack(cpu))
+        assert np.array_equal(ctx.get_plane(2, 1, capi.PLANE_DEPTH), O.halve_u16(depths[2]))
+        tgt_l1 = ctx.get_plane(3, 1, capi.PLANE_DEPTH)
+        if refs_only:
+            assert not tgt_l1.any()   # still the zeros of the first build
+        else:
+            assert np.array_equal(tgt_l1, O.halve_u16(depths[3]))
+        assert np.array_equal(ctx.get_plane(3, 1, capi.PLANE_IMAGE), O.halve_u8(frames[3]))
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 33])

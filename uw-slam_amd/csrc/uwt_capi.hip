@@ -110,17 +110,19 @@ void init_levels(uwt_ctx* c) {
   }
 }
 
+// src/dst point at slot 0 of the level planes; the frames processed are slots[0..n) if given, else first_slot..+n
 template <typename T>
-int launch_halve(uwt_ctx* c, const T* src, T* dst, int w_out, int h_out, size_t sfs, size_t dfs, int n_frames) {
+int launch_halve(uwt_ctx* c, const T* src, T* dst, int w_out, int h_out, size_t sfs, size_t dfs, int n_frames,
+                 const int* d_slots = nullptr, int first_slot = 0) {
   if (n_frames == 0) return UWT_OK;
   if (w_out % 4 == 0) {
     const int groups = (w_out / 4) * h_out;
     hipLaunchKernelGGL((k_halve<T, 4>), dim3((groups + kBlock - 1) / kBlock, n_frames), dim3(kBlock), 0, c->stream, src,
-                       dst, w_out, h_out, sfs, dfs);
+                       dst, w_out, h_out, sfs, dfs, d_slots, first_slot);
   } else {
     const int groups = w_out * h_out;
     hipLaunchKernelGGL((k_halve<T, 1>), dim3((groups + kBlock - 1) / kBlock, n_frames), dim3(kBlock), 0, c->stream, src,
-                       dst, w_out, h_out, sfs, dfs);
+                       dst, w_out, h_out, sfs, dfs, d_slots, first_slot);
   }
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
@@ -131,9 +133,15 @@ int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int 
                   const int* d_slots = nullptr, int first_slot = 0) {
   if (n_frames == 0) return UWT_OK;
   if (w % 4 == 0) {
-    const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + kGradVH - 1) / kGradVH);
-    hipLaunchKernelGGL(k_scharr3_v4, dim3(tiles, n_frames), dim3(kBlock), 0, c->stream, src, gx, gy, w, h, fs, d_slots,
-                       first_slot);
+    if (h >= 8 * kGradVRows) {  // four rows per thread on the tall levels
+      const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + 4 * kGradVRows - 1) / (4 * kGradVRows));
+      hipLaunchKernelGGL(k_scharr3_v4<4>, dim3(tiles, n_frames), dim3(kBlock), 0, c->stream, src, gx, gy, w, h, fs, d_slots,
+                         first_slot);
+    } else {
+      const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + kGradVRows - 1) / kGradVRows);
+      hipLaunchKernelGGL(k_scharr3_v4<1>, dim3(tiles, n_frames), dim3(kBlock), 0, c->stream, src, gx, gy, w, h, fs, d_slots,
+                         first_slot);
+    }
   } else {
     if (d_slots) return fail(c, UWT_ERR_INVALID_ARG, "slot lists need level widths that are multiples of 4");
     const int tiles = ((w + kGradTW - 1) / kGradTW) * ((h + kGradTH - 1) / kGradTH);
@@ -673,13 +681,17 @@ int uwt_get_plane(uwt_ctx* c, int32_t slot, int32_t lvl, int32_t plane, void* ho
   return UWT_OK;
 }
 
-static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n) {
+// System::AddFrame's pyramid loop for slots first_slot..+n.  depth_slots (device list of n_depth slots), when given,
+// restricts the depth pyramids to those slots: only a pair's reference frame is ever read through its depth
+// (src/Tracker.cpp:1266-1272).
+static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n, const int* depth_slots = nullptr, int n_depth = 0) {
   for (int l = 1; l < c->p.n_levels; l++) {
     const size_t ns = c->lv[l - 1].n, nd = c->lv[l].n;
-    int st = launch_halve<uint8_t>(c, c->img[l - 1] + first_slot * ns, c->img[l] + first_slot * nd, c->lv[l].w, c->lv[l].h, ns, nd, n);
+    int st = launch_halve<uint8_t>(c, c->img[l - 1], c->img[l], c->lv[l].w, c->lv[l].h, ns, nd, n, nullptr, first_slot);
     if (st) return st;
     if (c->p.has_depth) {
-      st = launch_halve<uint16_t>(c, c->depth[l - 1] + first_slot * ns, c->depth[l] + first_slot * nd, c->lv[l].w, c->lv[l].h, ns, nd, n);
+      st = depth_slots ? launch_halve<uint16_t>(c, c->depth[l - 1], c->depth[l], c->lv[l].w, c->lv[l].h, ns, nd, n_depth, depth_slots)
+                       : launch_halve<uint16_t>(c, c->depth[l - 1], c->depth[l], c->lv[l].w, c->lv[l].h, ns, nd, n, nullptr, first_slot);
       if (st) return st;
     }
   }
@@ -746,15 +758,17 @@ int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int3
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_track_batch_async: bad argument");
   int st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
   if (st) return st;
-  st = enqueue_pyramids(c, first_slot, n_frames);
-  if (st) return st;
-  // The tracker only reads the previous frame's gradients (src/Tracker.cpp:407-408).  grad_refs_only computes them for
-  // the pairs' reference slots alone; otherwise every prepared frame gets them, as System::Tracking calls
-  // ApplyGradient on both frames (src/System.cpp:197-213).
-  if (grad_refs_only && c->vec == 4)
-    st = enqueue_gradients(c, 0, n_pairs, c->d_ref);
-  else
-    st = enqueue_gradients(c, first_slot, n_frames);
+  // The tracker reads gradients and depth of the previous (reference) frame only (src/Tracker.cpp:407-408, 1266-1272).
+  // grad_refs_only computes those planes — gradients of every level, depth levels 1.. — for the pairs' reference slots
+  // alone; otherwise every prepared frame gets them, as System::AddFrame / System::Tracking do for each new frame
+  // (src/System.cpp:246-251, 197-213).
+  if (grad_refs_only) {
+    st = enqueue_pyramids(c, first_slot, n_frames, c->d_ref, n_pairs);
+    if (!st) st = c->vec == 4 ? enqueue_gradients(c, 0, n_pairs, c->d_ref) : enqueue_gradients(c, first_slot, n_frames);
+  } else {
+    st = enqueue_pyramids(c, first_slot, n_frames);
+    if (!st) st = enqueue_gradients(c, first_slot, n_frames);
+  }
   if (st) return st;
   return enqueue_estimate(c, n_pairs, d_poses_out, reinterpret_cast<StatsOut*>(d_stats_out));
 }

@@ -45,15 +45,17 @@ struct PairState {
 // ------------------------------------------------------------------------------------------------------------
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void k_halve(const T* __restrict__ src, T* __restrict__ dst, int w_out, int h_out,
-                                                  size_t src_frame_stride, size_t dst_frame_stride) {
+                                                  size_t src_frame_stride, size_t dst_frame_stride,
+                                                  const int* __restrict__ slots, int first_slot) {
+  const size_t frame = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;  // src / dst point at slot 0
   const int groups_per_row = w_out / VEC;
   const int g = blockIdx.x * kBlock + threadIdx.x;
   if (g >= groups_per_row * h_out) return;
   const int y = g / groups_per_row;
   const int x = (g - y * groups_per_row) * VEC;
-  const T* s0 = src + (size_t)blockIdx.y * src_frame_stride + (size_t)(2 * y) * (2 * w_out) + 2 * x;
+  const T* s0 = src + frame * src_frame_stride + (size_t)(2 * y) * (2 * w_out) + 2 * x;
   const T* s1 = s0 + 2 * w_out;
-  T* d = dst + (size_t)blockIdx.y * dst_frame_stride + (size_t)y * w_out + x;
+  T* d = dst + frame * dst_frame_stride + (size_t)y * w_out + x;
   T a[2 * VEC], b[2 * VEC], o[VEC];
   if constexpr (VEC == 4 && sizeof(T) == 1) {
     *reinterpret_cast<uint2*>(a) = *reinterpret_cast<const uint2*>(s0);
@@ -123,58 +125,75 @@ __global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ 
   }
 }
 
-// Vector variant for level widths that are multiples of 4: a 128x8 output tile per block, the 130x10 source patch
-// staged in LDS with 4-byte loads, each thread produces 4 adjacent outputs from nine aligned LDS words and stores two
-// 8-byte vectors.  HBM-bound: 1 B read + 4 B written per pixel.  `slots` (optional) lists the frame slots to process.
-constexpr int kGradVW = 128, kGradVH = 8;
+// Vector variant for level widths that are multiples of 4: a 128 x (8·RPT) output tile per block, the source patch (tile
+// + 1-pixel ring) staged in LDS with 4-byte loads; a thread owns 4 adjacent columns and RPT consecutive rows, slides a
+// three-row window of LDS words down them and stores two 8-byte vectors per row.  HBM-bound: 1 B read + 4 B written per
+// pixel.  RPT = 4 on levels tall enough: fewer, longer blocks with 4-5 loads in flight per thread before the barrier.
+// `slots` (optional) lists the frame slots to process.
+constexpr int kGradVW = 128, kGradVRows = 8;  // columns per tile; thread rows per tile (x RPT output rows each)
 
+template <int RPT>
 __global__ __launch_bounds__(kBlock) void k_scharr3_v4(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
                                                        int16_t* __restrict__ gy, int w, int h, size_t frame_stride,
                                                        const int* __restrict__ slots, int first_slot) {
-  __shared__ uint32_t tile[kGradVH + 2][kGradVW / 4 + 2];  // word 0: left halo in its top byte; word 33: right halo in its low byte
+  constexpr int TH = kGradVRows * RPT;
+  __shared__ uint32_t tile[TH + 2][kGradVW / 4 + 2];  // word 0: left halo in its top byte; word 33: right halo in its low byte
   const int slot = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;
   const int tiles_x = (w + kGradVW - 1) / kGradVW;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int x0 = tx * kGradVW, y0 = ty * kGradVH;
+  const int x0 = tx * kGradVW, y0 = ty * TH;
   const uint8_t* img = src + (size_t)slot * frame_stride;
   const int tw = min(kGradVW, w - x0);  // valid width of this tile (multiple of 4)
-  for (int i = threadIdx.x; i < (kGradVH + 2) * (kGradVW / 4); i += kBlock) {
+  const int rows = min(TH, h - y0) + 2; // patch rows this tile needs
+#pragma unroll
+  for (int i0 = 0; i0 < (TH + 2) * (kGradVW / 4); i0 += kBlock) {
+    const int i = i0 + (int)threadIdx.x;
     const int r = i / (kGradVW / 4), c = i - r * (kGradVW / 4);
-    if (4 * c < tw) {
-      const int sy = reflect101(min(y0 + r - 1, h), h);
+    if (r < rows && 4 * c < tw) {
+      const int sy = reflect101(y0 + r - 1, h);
       tile[r][1 + c] = *reinterpret_cast<const uint32_t*>(img + (size_t)sy * w + x0 + 4 * c);
     }
   }
-  if (threadIdx.x < 2 * (kGradVH + 2)) {
+  if (threadIdx.x < 2 * (TH + 2)) {
     const int r = threadIdx.x >> 1, side = threadIdx.x & 1;
-    const int sy = reflect101(min(y0 + r - 1, h), h);
-    const int xs = reflect101(side ? x0 + tw : x0 - 1, w);
-    const uint32_t v = img[(size_t)sy * w + xs];
-    if (side) tile[r][1 + tw / 4] = v; else tile[r][0] = v << 24;
+    if (r < rows) {
+      const int sy = reflect101(y0 + r - 1, h);
+      const int xs = reflect101(side ? x0 + tw : x0 - 1, w);
+      const uint32_t v = img[(size_t)sy * w + xs];
+      if (side) tile[r][1 + tw / 4] = v; else tile[r][0] = v << 24;
+    }
   }
   __syncthreads();
   const int ly = threadIdx.x / (kGradVW / 4), c = threadIdx.x - ly * (kGradVW / 4);
-  const int x = x0 + 4 * c, y = y0 + ly;
-  if (4 * c < tw && y < h) {
-    int p[3][6];  // p[row][0..5] = pixels x-1 .. x+4
+  const int x = x0 + 4 * c, yb = y0 + ly * RPT;
+  if (4 * c >= tw || yb >= h) return;
+  int p[3][6];  // p[row][0..5] = pixels x-1 .. x+4 of the window rows
+  auto load_row = [&](int dst, int r) {
+    const uint32_t wl = tile[r][c], wc = tile[r][c + 1], wr = tile[r][c + 2];
+    p[dst][0] = wl >> 24;
+    p[dst][1] = wc & 0xff; p[dst][2] = (wc >> 8) & 0xff; p[dst][3] = (wc >> 16) & 0xff; p[dst][4] = wc >> 24;
+    p[dst][5] = wr & 0xff;
+  };
+  load_row(0, ly * RPT);
+  load_row(1, ly * RPT + 1);
 #pragma unroll
-    for (int r = 0; r < 3; r++) {
-      const uint32_t wl = tile[ly + r][c], wc = tile[ly + r][c + 1], wr = tile[ly + r][c + 2];
-      p[r][0] = wl >> 24;
-      p[r][1] = wc & 0xff; p[r][2] = (wc >> 8) & 0xff; p[r][3] = (wc >> 16) & 0xff; p[r][4] = wc >> 24;
-      p[r][5] = wr & 0xff;
-    }
-    int16_t ox[4], oy[4];
+  for (int k = 0; k < RPT; k++) {
+    if (yb + k < h) {
+      load_row(2, ly * RPT + k + 2);
+      int16_t ox[4], oy[4];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      const int sx = 3 * (3 * (p[0][j + 2] - p[0][j]) + 10 * (p[1][j + 2] - p[1][j]) + 3 * (p[2][j + 2] - p[2][j]));
-      const int sy = 3 * (3 * (p[2][j] - p[0][j]) + 10 * (p[2][j + 1] - p[0][j + 1]) + 3 * (p[2][j + 2] - p[0][j + 2]));
-      ox[j] = (int16_t)sx;
-      oy[j] = (int16_t)sy;
+      for (int j = 0; j < 4; j++) {
+        const int sx = 3 * (3 * (p[0][j + 2] - p[0][j]) + 10 * (p[1][j + 2] - p[1][j]) + 3 * (p[2][j + 2] - p[2][j]));
+        const int sy = 3 * (3 * (p[2][j] - p[0][j]) + 10 * (p[2][j + 1] - p[0][j + 1]) + 3 * (p[2][j + 2] - p[0][j + 2]));
+        ox[j] = (int16_t)sx;
+        oy[j] = (int16_t)sy;
+      }
+      const size_t o = (size_t)slot * frame_stride + (size_t)(yb + k) * w + x;
+      *reinterpret_cast<uint2*>(gx + o) = *reinterpret_cast<uint2*>(ox);
+      *reinterpret_cast<uint2*>(gy + o) = *reinterpret_cast<uint2*>(oy);
+#pragma unroll
+      for (int j = 0; j < 6; j++) { p[0][j] = p[1][j]; p[1][j] = p[2][j]; }
     }
-    const size_t o = (size_t)slot * frame_stride + (size_t)y * w + x;
-    *reinterpret_cast<uint2*>(gx + o) = *reinterpret_cast<uint2*>(ox);
-    *reinterpret_cast<uint2*>(gy + o) = *reinterpret_cast<uint2*>(oy);
   }
 }
 
