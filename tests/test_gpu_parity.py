@@ -481,7 +481,7 @@ def test_track_batch_async_depth_planes_for_reference_slots_only(capi, O, synth)
 @pytest.mark.parametrize("n", [1, 2, 3, 5, 33])
 @pytest.mark.parametrize("cfg", ["fixed_4lvl", "fixed_1lvl_1it", "fixed_top_only", "reference"])
 def test_batch_sizes_and_schedules_match_oracle(capi, O, synth, n, cfg):
-    """Odd / tiny batches through the pipelined half-batch schedule (and the reference schedule), every pose checked."""
+    """Odd / tiny batches through the fixed and the reference (early-exit, polled) schedules, every pose checked."""
     w, h = 64, 48
     over = dict(fixed_4lvl=dict(n_levels=3, first_level=2, last_level=0, max_iters=4, early_exit=0),
                 fixed_1lvl_1it=dict(n_levels=3, first_level=0, last_level=0, max_iters=1, early_exit=0),
@@ -504,7 +504,7 @@ def test_batch_sizes_and_schedules_match_oracle(capi, O, synth, n, cfg):
 
 
 def test_failing_pair_does_not_disturb_its_batch(capi, O, synth):
-    """One pair with no valid depth gets UWT_ERR_NO_VALID_POINTS; the other pairs of both half-batches are untouched."""
+    """One pair with no valid depth gets UWT_ERR_NO_VALID_POINTS; the other pairs of the batch are untouched."""
     w, h, n = 64, 48, 6
     over = dict(n_levels=3, first_level=2, last_level=0, max_iters=4, early_exit=0, has_depth=1)
     ctx = make_ctx(capi, w, h, SMALL, max_frames=2 * n, max_pairs=n, **over)

@@ -498,7 +498,7 @@ struct ResidualArgs {
   float zf, af;
   int groups_per_block;
   int slices;
-  int pair_base;            // first pair of this launch (sub-batches run on separate streams)
+  int pair_base;            // first pair of this launch (0 for a whole batch)
   uint32_t* partials;       // [pair][slice][kRecWords]
   const PairScale* scale;   // robust-weight scale per pair (WEIGHTS != 0)
   float gain;               // residual gain, applied inside the kernel on the weighted / bilinear path (src/Tracker.cpp:559)
@@ -1124,7 +1124,7 @@ __global__ void k_init_state(PairState* state, int n, float initial_error) {
 
 // end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
 __global__ void k_level_end(PairState* state, int n, int lvl, int scale_t, float initial_error) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // `state` is already offset to the sub-batch
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;  // `state` points at the first pair of the launch
   if (i >= n) return;
   PairState st = state[i];
   if (st.status == 0 && lvl != 0) {
