@@ -54,3 +54,31 @@ def test_shim_sequence_matches_oracle(O, synth, tmp_path):
     assert np.array_equal(np.array([float(v) for v in ft[1:8]], np.float32), pose_f)
     ls = lines[2].split()
     assert ls[0] == "LS" and float(ls[1]) == 1.0 and float(ls[2]) == -3.0 and float(ls[3]) == 2.0 and int(ls[4]) == 1
+
+
+BENCH = os.path.join(ROOT, "tools", "uwt_bench")
+
+
+def build_bench():
+    importlib.import_module("uw-slam_amd").build_native()
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools")])
+    return BENCH
+
+
+def test_native_bench_compiles_and_links():
+    assert os.path.exists(build_bench())
+
+
+@pytest.mark.gpu
+def test_native_bench_runs_without_python_in_the_loop():
+    """tools/uwt_bench: C++ generator + the C ABI only.  Poses finite, tiled copies of a pair bit-identical."""
+    import json
+    exe = BENCH if os.path.exists(BENCH) else build_bench()
+    out = subprocess.run([exe, "--pairs", "24", "--unique", "5", "--width", "160", "--height", "96", "--levels", "3", "--steps", "2",
+                          "--warmup", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["poses_finite"] and d["tiled_pairs_identical"] and d["value"] > 0 and 0 < d["max_translation_m"] < 0.1
+    out = subprocess.run([exe, "--pairs", "4", "--unique", "4", "--width", "160", "--height", "96", "--reference-schedule", "--no-depth",
+                          "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
