@@ -57,7 +57,8 @@ struct uwt_ctx {
 
 namespace {
 
-constexpr int kGroupsPerThread = 8;  // x VEC pixels per thread per launch (fixed ⇒ results independent of batch size)
+constexpr int kGroupsPerThread = 8;  // x VEC pixels per thread: the finest slicing (single pair); batches coarsen it in enqueue_estimate.
+                                     // The f64 partial sums then group differently — 1e-16 relative, far below the f32 rounding of A and b
 
 int fail(uwt_ctx* c, int code, const std::string& msg) {
   if (c) c->last_error = msg;
