@@ -701,7 +701,7 @@ struct GeneralArgs {
 
 // one pixel of the dense table: warp, validity, residual (either sampler)
 template <bool DEPTH>
-__device__ __forceinline__ bool general_pixel(const ResidualArgs& a, const LevelK& L, const WarpK& K, int sampler,
+__device__ __forceinline__ bool general_pixel(const LevelK& L, const WarpK& K, int sampler,
                                               const uint8_t* I1, const uint8_t* I2, const uint16_t* DP, uint32_t idx,
                                               float& x2, float& y2, float& iz, float& rf) {
   const uint32_t y = __umulhi(idx, L.magic), x = idx - y * L.w;
@@ -738,7 +738,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist(const ResidualArgs a, con
   const int p_begin = blockIdx.x * a.groups_per_block, p_end = min(p_begin + a.groups_per_block, L.n);
   for (int p = p_begin + (int)threadIdx.x; p < p_end; p += kBlock) {
     float x2, y2, iz, rf;
-    if (!general_pixel<DEPTH>(a, L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf)) continue;
+    if (!general_pixel<DEPTH>(L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf)) continue;
     const int q = (int)rintf(rf);   // saturate_cast<uchar> / lrint: round half to even; |q| <= 255
     atomicAdd(&h[q + 255], 1u);     // signed bins; integer atomics are order-independent
   }
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_general(const ResidualArgs 
   const int p_begin = blockIdx.x * a.groups_per_block, p_end = min(p_begin + a.groups_per_block, L.n);
   for (int p = p_begin + (int)threadIdx.x; p < p_end; p += kBlock) {
     float x2, y2, iz, rf;
-    const bool ok = general_pixel<DEPTH>(a, L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf);
+    const bool ok = general_pixel<DEPTH>(L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf);
     float J[6], w = 1.f;
     if (ok) {
       pixel_jacobian<UNIT_FACTORS, false, true>(L, a.zf, a.af, x2, y2, iz, (float)GX[p], (float)GY[p], J);
