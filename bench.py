@@ -28,6 +28,7 @@ if ROOT not in sys.path:
 
 ALG_BYTES_PER_PIXEL_ITER = 10          # I_ref 1 + gx 2 + gy 2 + z 4 + I_tgt 1
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0                  # MI355X_MICROARCH.md §Chip-level parameters: measured copy ceiling
 # HBM traffic of the residual kernel from rocprofv3 PMC passes (profiles/r01/pmc_summary_bench_default_p1024.csv, made by
 # tools/pmc_summary.py from one --pmc FETCH_SIZE and one --pmc WRITE_SIZE run of this file): per k_residual launch of
 # 1024 pairs, averaged over the four levels (levels 0 and 1 share a grid size in that table), 2 x FETCH_SIZE + WRITE_SIZE
@@ -196,6 +197,7 @@ def main():
                 "bound": "hbm", "kernel": "k_residual (fused warp+residual+Jacobian+reduction)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4),
                 "traffic": (int(TRAFFIC_BYTES_PER_PAIR_LAUNCH * res_pixels / res_launches / px_per_align * args.levels)
                             if (w, h, args.levels, has_depth) == (640, 480, 4, 1) else None),
                 "launches": int(res_launches), "avg_launch_ms": round(res_ms / res_launches, 5),
