@@ -566,7 +566,7 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   AccT acc[kAccFloats];
 #pragma unroll
   for (int i = 0; i < kAccFloats; i++) acc[i] = (AccT)0;
-  uint32_t sum_r2 = 0, n_valid = 0;
+  uint32_t sum_r2 = 0, n_valid_wave = 0;  // the valid count is kept per wave in a scalar register
   constexpr bool GENERAL = SAMPLER != 0 || WEIGHTS != 0;  // float residuals and/or robust weights
   AccT err = (AccT)0;                                      // Σ r·(r·w), the error numerator on the general path
   float inv_mad = 1.f;
@@ -652,7 +652,7 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
           ri = (int)rintf(rf);
         }
         sum_r2 += (uint32_t)(ri * ri);
-        n_valid += ok[jj] ? 1u : 0u;
+        n_valid_wave += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ok[jj]));  // scalar: the mask is in SGPRs already
         if constexpr (DUMP) {
           if (active) {
             const size_t p = (size_t)pair * L.n + idx + j;
@@ -665,6 +665,7 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
       }
     }
   }
+  const uint32_t n_valid = (threadIdx.x & 63) == 0 ? n_valid_wave : 0u;
   block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + slice) * kRecWords, err);
 #ifdef UWT_EXP_CLOCK
   if (threadIdx.x == 0) {  // diagnostic build only: shader-clock and 100 MHz real-time deltas of this block
