@@ -210,6 +210,9 @@ struct WarpK {
 // rcp / Newton / two-residual-correction sequence hipcc emits for an IEEE `a / b`, minus the div_scale / div_fixup
 // range handling.  Bit-identical to `a / b` for normal-range operands and quotients; a zero, infinite or NaN
 // denominator yields NaN or infinity here as there, and such a pixel fails the bounds test either way.
+// refined_rcp(d) itself equals the IEEE 1.0f / d for every one of the 2^23 mantissas (checked exhaustively at nine
+// exponents, both signs, by tools/ubench/rcp_check.hip on gfx950), so a reciprocal needs no further correction; a general
+// numerator does (Markstein: n * r can be 1.5 ulp off), hence the two residual corrections in div_by.
 __device__ __forceinline__ float refined_rcp(float d) {
   float r = __builtin_amdgcn_rcpf(d);
   const float e = __builtin_fmaf(-d, r, 1.0f);
@@ -248,7 +251,7 @@ __device__ __forceinline__ void warp_point(const LevelK& L, const WarpK& K, floa
   v = yp * L.fy;
   v = div_by(v, zp, r);
   v = v + L.cy;
-  iz = div_by(1.0f, zp, r);  // inv_z2 = 1 / z2 (src/Tracker.cpp:447)
+  iz = r;  // inv_z2 = 1 / z2 (src/Tracker.cpp:447): the refined reciprocal IS the correctly rounded quotient (see refined_rcp)
 }
 
 // C round() (half away from zero) for the x >= 0 this path produces: v_cvt_rpi_i32_f32 = floor(x + 0.5) evaluated
@@ -260,17 +263,39 @@ __device__ __forceinline__ int round_pos(float x) {
   return r;
 }
 
+// v ? x : 0 under a 64-lane mask held in an SGPR pair.  Written as the instruction so that the compiler keeps the
+// sanitising selects straight-line: left to itself it turns them into an exec-masked region per pixel and pays four
+// v_mov of zero, a saveexec and a branch for each.
+__device__ __forceinline__ float keep_f(float x, unsigned long long mask) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
+  return r;
+}
+__device__ __forceinline__ int keep_i(int x, unsigned long long mask) {
+  int r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
+  return r;
+}
+
 // Phase 1 of a pixel: warp, validity (src/Tracker.cpp:450-453) and the gather index of the nearest-neighbour sample
 // (:472).  Branch-free: an invalid pixel is sanitised (x2 = y2 = iz = 0) so that every later term is finite and its
 // Jacobian row comes out as exact zeros, which leave the accumulators unchanged.
-__device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, float xf, float yf, float z, bool ok_in,
-                                           float& x2, float& y2, float& iz, bool& ok, uint32_t& gidx) {
+// Validity is built as a 64-lane mask in scalar registers: every comparison writes an SGPR pair, the conjunction is
+// s_and_b64, nothing of it occupies the VALU beyond the compares themselves.  (LLVM FCmp / ICmp predicate codes.)
+constexpr int kFcmpOGT = 2, kFcmpOLT = 4, kFcmpUGE = 11, kFcmpUNE = 14, kIcmpSGT = 38, kIcmpSLT = 40;
+__device__ __forceinline__ bool lane_bit(unsigned long long mask) { return (mask >> (threadIdx.x & 63u)) & 1ull; }
+
+__device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, float xf, float yf, float z,
+                                           unsigned long long okin_mask, float& x2, float& y2, float& iz,
+                                           unsigned long long& okm, uint32_t& gidx) {
   float z2;
   warp_point(L, K, xf, yf, z, x2, y2, z2, iz);
-  ok = ok_in && (y2 > 0.f) && (y2 < (float)L.h) && (x2 > 0.f) && (x2 < (float)L.w) && (z2 != 0.f);
-  x2 = ok ? x2 : 0.f;
-  y2 = ok ? y2 : 0.f;
-  iz = (ok && !(iz < 0.f)) ? iz : 0.f;  // "if (inv_z2 < 0) inv_z2 = 0" (:452-453)
+  okm = okin_mask & __builtin_amdgcn_fcmpf(y2, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(y2, (float)L.h, kFcmpOLT) &
+        __builtin_amdgcn_fcmpf(x2, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(x2, (float)L.w, kFcmpOLT) &
+        __builtin_amdgcn_fcmpf(z2, 0.f, kFcmpUNE);
+  x2 = keep_f(x2, okm);
+  y2 = keep_f(y2, okm);
+  iz = keep_f(iz, okm & __builtin_amdgcn_fcmpf(iz, 0.f, kFcmpUGE));  // "if (inv_z2 < 0) inv_z2 = 0" (:452-453)
   int ix2 = round_pos(x2), iy2 = round_pos(y2);
   ix2 = min(ix2, L.w - 1);  // the reference reads one past the edge here (:450, :472); clamp
   iy2 = min(iy2, L.h - 1);
@@ -581,8 +606,17 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   RefGroup<VEC> nxt;
   int g = g_begin + (int)threadIdx.x;
   load_group<VEC, DEPTH>(nxt, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
+  // Pixel coordinates of the thread's group, as floats (small integers: exact).  One division up front, then each step
+  // of kBlock groups moves (x, y) by the level's fixed (step mod w, step / w) with at most one wrap.  Lanes past the end
+  // of the level run on with coordinates outside the image; they are inactive and every term of theirs is discarded.
+  const uint32_t idx0 = (uint32_t)g * VEC;
+  const uint32_t y0 = __umulhi(idx0, L.magic);
+  float yf = (float)y0, xf0 = (float)(idx0 - y0 * (uint32_t)L.w);
+  const uint32_t step_y = __umulhi((uint32_t)(kBlock * VEC), L.magic);
+  const float step_yf = (float)step_y, step_xf = (float)((uint32_t)(kBlock * VEC) - step_y * (uint32_t)L.w), wf = (float)L.w;
   for (int it = 0; it < iters; it++, g += kBlock) {
     const bool active = g < g_end;
+    const unsigned long long active_mask = __builtin_amdgcn_sicmp(g, g_end, kIcmpSLT);
     const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
 #ifdef UWT_EXP_NOPREFETCH
     RefGroup<VEC> cur;
@@ -591,10 +625,6 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
     const RefGroup<VEC> cur = nxt;
     if (it + 1 < iters) load_group<VEC, DEPTH>(nxt, I1, GX, GY, DP, (uint32_t)min(g + kBlock, n_groups - 1) * VEC);
 #endif
-    const uint32_t y = __umulhi(idx, L.magic);
-    const uint32_t x = idx - y * L.w;
-    const float yf = (float)y, xf0 = (float)x;
-
 #ifndef UWT_EXP_PHASE
     constexpr int PH = VEC;   // pixels in flight per phase (warp -> gather -> Jacobian -> accumulate)
 #else
@@ -603,19 +633,19 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
 #pragma unroll
     for (int j0 = 0; j0 < VEC; j0 += PH) {
       float x2[PH], y2[PH], iz[PH];
-      bool ok[PH];
+      unsigned long long okm[PH];  // validity as a wave mask (SGPR pair)
       uint32_t gidx[PH];
 #pragma unroll
       for (int jj = 0; jj < PH; jj++) {
         const int j = j0 + jj;
         float z = 1.0f;
-        bool okin = active;
+        unsigned long long okin = active_mask;
         if constexpr (DEPTH) {
           const int d = (int)(int16_t)cur.dp[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
-          okin = okin && d > 0;
+          okin &= __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
           z = (float)d * L.zscale;
         }
-        pixel_warp(L, K, xf0 + (float)j, yf, z, okin, x2[jj], y2[jj], iz[jj], ok[jj], gidx[jj]);
+        pixel_warp(L, K, xf0 + (float)j, yf, z, okin, x2[jj], y2[jj], iz[jj], okm[jj], gidx[jj]);
       }
       int i2[PH];
       float s2[PH];
@@ -632,8 +662,8 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
 #pragma unroll
       for (int jj = 0; jj < PH; jj++) {
         const int j = j0 + jj;
-        const float g0 = ok[jj] ? (float)cur.gx[j] : 0.f;
-        const float g1 = ok[jj] ? (float)cur.gy[j] : 0.f;
+        const float g0 = keep_f((float)cur.gx[j], okm[jj]);
+        const float g1 = keep_f((float)cur.gy[j], okm[jj]);
         pixel_jacobian<UNIT_FACTORS, SQUARE, DUMP>(L, a.zf, a.af, x2[jj], y2[jj], iz[jj], g0, g1, J[jj]);
       }
 #pragma unroll
@@ -641,22 +671,22 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
         const int j = j0 + jj;
         int ri = 0;
         if constexpr (!GENERAL) {
-          ri = ok[jj] ? i2[jj] - (int)cur.i1[j] : 0;
+          ri = keep_i(i2[jj] - (int)cur.i1[j], okm[jj]);
           accumulate(acc, J[jj], ri);
         } else {
           float rf;
-          if constexpr (SAMPLER == 0) rf = (float)(ok[jj] ? i2[jj] - (int)cur.i1[j] : 0);
-          else rf = ok[jj] ? s2[jj] - (float)cur.i1[j] : 0.f;
+          if constexpr (SAMPLER == 0) rf = (float)keep_i(i2[jj] - (int)cur.i1[j], okm[jj]);
+          else rf = keep_f(s2[jj] - (float)cur.i1[j], okm[jj]);
           const float w = robust_weight(WEIGHTS, rf, inv_mad);
           accumulate_weighted(acc, err, J[jj], rf, w, a.gain);
           ri = (int)rintf(rf);
         }
-        sum_r2 += (uint32_t)(ri * ri);
-        n_valid_wave += (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(ok[jj]));  // scalar: the mask is in SGPRs already
+        sum_r2 += (uint32_t)__mul24(ri, ri);  // |ri| <= 255
+        n_valid_wave += (uint32_t)__builtin_popcountll(okm[jj]);  // scalar
         if constexpr (DUMP) {
           if (active) {
             const size_t p = (size_t)pair * L.n + idx + j;
-            if (a.dumpV) a.dumpV[p] = ok[jj] ? 1 : 0;
+            if (a.dumpV) a.dumpV[p] = lane_bit(okm[jj]) ? 1 : 0;
             if (a.dumpR) a.dumpR[p] = (float)ri;
             if (a.dumpJ)
               for (int k = 0; k < 6; k++) a.dumpJ[p * 6 + k] = J[jj][k];
@@ -664,6 +694,11 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
         }
       }
     }
+    xf0 += step_xf;
+    yf += step_yf;
+    const bool wrap = xf0 >= wf;
+    xf0 -= wrap ? wf : 0.f;
+    yf += wrap ? 1.f : 0.f;
   }
   const uint32_t n_valid = (threadIdx.x & 63) == 0 ? n_valid_wave : 0u;
   block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + slice) * kRecWords, err);
@@ -715,7 +750,9 @@ __device__ __forceinline__ bool general_pixel(const LevelK& L, const WarpK& K, i
   }
   uint32_t gidx;
   bool valid;
-  pixel_warp(L, K, (float)x, (float)y, z, ok, x2, y2, iz, valid, gidx);
+  unsigned long long okm;
+  pixel_warp(L, K, (float)x, (float)y, z, __builtin_amdgcn_ballot_w64(ok), x2, y2, iz, okm, gidx);
+  valid = lane_bit(okm);
   const int i1 = I1[idx];
   rf = sampler ? sample_bilinear(I2, L, x2, y2) - (float)i1 : (float)((int)I2[gidx] - i1);
   return valid;
@@ -796,7 +833,9 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
         okin = d > 0;
         z = (float)d * L.zscale;
       }
-      pixel_warp(L, K, (float)x + (float)j, (float)y, z, okin, x2[j], y2[j], iz, ok[j], gidx[j]);
+      unsigned long long okm;
+      pixel_warp(L, K, (float)x + (float)j, (float)y, z, __builtin_amdgcn_ballot_w64(okin), x2[j], y2[j], iz, okm, gidx[j]);
+      ok[j] = lane_bit(okm);
     }
     float rf[VEC];
 #pragma unroll
