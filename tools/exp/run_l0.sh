@@ -1,7 +1,7 @@
 #!/bin/bash
 # usage: run_l0.sh <label> [env assignments...]   -- level-0-only residual timing via bench.py
 label=$1; shift
-out=$(env "$@" python bench.py --levels 1 --pairs 512 --steps 3 --warmup 1 --cpu-pairs 0 2>/dev/null | tail -1)
+out=$(env "$@" python bench.py --levels 1 --pairs 1024 --steps 3 --warmup 1 --cpu-pairs 0 2>/dev/null | tail -1)
 python - "$label" "$out" <<'PY'
 import sys, json
 d=json.loads(sys.argv[2]); r=d.get("roofline",{})
