@@ -32,10 +32,10 @@ HBM_COPY_GBS = 6290.0                  # MI355X_MICROARCH.md §Chip-level parame
 # HBM traffic of the residual kernel from rocprofv3 PMC passes (profiles/r01/pmc_summary_bench_default_p1024.csv, made by
 # tools/pmc_summary.py from one --pmc FETCH_SIZE and one --pmc WRITE_SIZE run of this file): per k_residual launch of
 # 1024 pairs, averaged over the four levels (levels 0 and 1 share a grid size in that table), 2 x FETCH_SIZE + WRITE_SIZE
-# = 2 x 408696.0 + 768.0 KiB (the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM; it reproduces the
+# = 2 x 408754.7 + 768.0 KiB (the x2 is the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md §HBM; it reproduces the
 # compulsory byte count of this access pattern, 8 B per pixel).  Only valid for the default workload (640x480, 4 levels,
 # u16 depth plane).
-TRAFFIC_BYTES_PER_PAIR_LAUNCH = (2 * 408696.0 + 768.0) * 1024.0 / 1024.0
+TRAFFIC_BYTES_PER_PAIR_LAUNCH = (2 * 408754.7 + 768.0) * 1024.0 / 1024.0
 
 
 def main():
