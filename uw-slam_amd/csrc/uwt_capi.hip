@@ -27,6 +27,11 @@ struct uwt_ctx {
   int slices[UWT_MAX_LEVELS];
   int groups_per_block[UWT_MAX_LEVELS];
   hipStream_t stream = nullptr;
+  // Side stream of uwt_track_batch_async: the gradients of the finer levels (HBM-bound) run beside the first, coarse
+  // iterations of the alignment (VALU-bound), which only read the coarsest iterated level.  UWT_OVERLAP_GRAD=0: off.
+  hipStream_t side = nullptr;
+  hipEvent_t ev_pyramids = nullptr, ev_side_done = nullptr, ev_level[UWT_MAX_LEVELS] = {};
+  bool overlap_gradients = true;
   uint8_t* img[UWT_MAX_LEVELS] = {};
   uint16_t* depth[UWT_MAX_LEVELS] = {};
   int16_t* gx[UWT_MAX_LEVELS] = {};
@@ -131,22 +136,23 @@ int launch_halve(uwt_ctx* c, const T* src, T* dst, int w_out, int h_out, size_t 
 
 // src/gx/gy point at slot 0 of the level planes; the frames processed are slots[0..n) if given, else first_slot..+n
 int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int w, int h, size_t fs, int n_frames,
-                  const int* d_slots = nullptr, int first_slot = 0) {
+                  const int* d_slots = nullptr, int first_slot = 0, hipStream_t on = nullptr) {
   if (n_frames == 0) return UWT_OK;
+  hipStream_t stream = on ? on : c->stream;
   if (w % 4 == 0) {
     if (h >= 8 * kGradVRows) {  // four rows per thread on the tall levels
       const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + 4 * kGradVRows - 1) / (4 * kGradVRows));
-      hipLaunchKernelGGL(k_scharr3_v4<4>, dim3(tiles, n_frames), dim3(kBlock), 0, c->stream, src, gx, gy, w, h, fs, d_slots,
+      hipLaunchKernelGGL(k_scharr3_v4<4>, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, fs, d_slots,
                          first_slot);
     } else {
       const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + kGradVRows - 1) / kGradVRows);
-      hipLaunchKernelGGL(k_scharr3_v4<1>, dim3(tiles, n_frames), dim3(kBlock), 0, c->stream, src, gx, gy, w, h, fs, d_slots,
+      hipLaunchKernelGGL(k_scharr3_v4<1>, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, fs, d_slots,
                          first_slot);
     }
   } else {
     if (d_slots) return fail(c, UWT_ERR_INVALID_ARG, "slot lists need level widths that are multiples of 4");
     const int tiles = ((w + kGradTW - 1) / kGradTW) * ((h + kGradTH - 1) / kGradTH);
-    hipLaunchKernelGGL(k_scharr3, dim3(tiles, n_frames), dim3(kBlock), 0, c->stream, src + first_slot * fs,
+    hipLaunchKernelGGL(k_scharr3, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src + first_slot * fs,
                        gx + first_slot * fs, gy + first_slot * fs, w, h, fs);
   }
   HIPCHK(c, hipGetLastError());
@@ -338,7 +344,7 @@ UpdateArgs update_args(uwt_ctx* c, int lvl) {
 }
 
 // Tracker::EstimatePose for a batch, enqueued on the context's stream (src/Tracker.cpp:362-597)
-int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats) {
+int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats, const hipEvent_t* level_ready = nullptr) {
   const uwt_params& p = c->p;
   const int tb = 128;
   hipLaunchKernelGGL(k_init_state, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs,
@@ -347,6 +353,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats)
   const bool general = p.sampler != 0 || p.weights != 0;
   {
     for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
+      if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(c->stream, level_ready[lvl], 0));  // its gradients
       ResidualArgs ra = residual_args(c, lvl);
       UpdateArgs ua = update_args(c, lvl);
       // Slicing follows the batch: the create-time slicing (kGroupsPerThread) gives a single pair enough blocks to spread
@@ -533,6 +540,11 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   } while (0)
   CREATE_CHK(hipSetDevice(p->device));
   CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  CREATE_CHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  CREATE_CHK(hipEventCreateWithFlags(&c->ev_pyramids, hipEventDisableTiming));
+  CREATE_CHK(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
+  for (int l = 0; l < UWT_MAX_LEVELS; l++) CREATE_CHK(hipEventCreateWithFlags(&c->ev_level[l], hipEventDisableTiming));
+  if (const char* e = std::getenv("UWT_OVERLAP_GRAD")) c->overlap_gradients = std::atoi(e) != 0;
   for (int l = 0; l < p->n_levels; l++) {
     const size_t n = (size_t)c->lv[l].n * p->max_frames;
     CREATE_CHK(hipMalloc((void**)&c->img[l], n));
@@ -583,6 +595,11 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->h_pairs) (void)hipHostFree(c->h_pairs);
   if (c->scratch) (void)hipFree(c->scratch);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->ev_pyramids) (void)hipEventDestroy(c->ev_pyramids);
+  if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
+  for (int l = 0; l < UWT_MAX_LEVELS; l++)
+    if (c->ev_level[l]) (void)hipEventDestroy(c->ev_level[l]);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   delete c;
   return UWT_OK;
@@ -699,9 +716,13 @@ static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n, const int* depth_
   return UWT_OK;
 }
 
+static int enqueue_gradient_level(uwt_ctx* c, int l, int first_slot, int n, const int* d_slots, hipStream_t on = nullptr) {
+  return launch_scharr(c, c->img[l], c->gx[l], c->gy[l], c->lv[l].w, c->lv[l].h, c->lv[l].n, n, d_slots, first_slot, on);
+}
+
 static int enqueue_gradients(uwt_ctx* c, int first_slot, int n, const int* d_slots = nullptr) {
   for (int l = 0; l < c->p.n_levels; l++) {
-    int st = launch_scharr(c, c->img[l], c->gx[l], c->gy[l], c->lv[l].w, c->lv[l].h, c->lv[l].n, n, d_slots, first_slot);
+    int st = enqueue_gradient_level(c, l, first_slot, n, d_slots);
     if (st) return st;
   }
   return UWT_OK;
@@ -763,15 +784,37 @@ int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int3
   // grad_refs_only computes those planes — gradients of every level, depth levels 1.. — for the pairs' reference slots
   // alone; otherwise every prepared frame gets them, as System::AddFrame / System::Tracking do for each new frame
   // (src/System.cpp:246-251, 197-213).
-  if (grad_refs_only) {
-    st = enqueue_pyramids(c, first_slot, n_frames, c->d_ref, n_pairs);
-    if (!st) st = c->vec == 4 ? enqueue_gradients(c, 0, n_pairs, c->d_ref) : enqueue_gradients(c, first_slot, n_frames);
-  } else {
-    st = enqueue_pyramids(c, first_slot, n_frames);
-    if (!st) st = enqueue_gradients(c, first_slot, n_frames);
-  }
+  const int* g_slots = (grad_refs_only && c->vec == 4) ? c->d_ref : nullptr;   // gradient frames: a slot list or the range
+  const int g_first = g_slots ? 0 : first_slot, g_n = g_slots ? n_pairs : n_frames;
+  st = grad_refs_only ? enqueue_pyramids(c, first_slot, n_frames, c->d_ref, n_pairs) : enqueue_pyramids(c, first_slot, n_frames);
   if (st) return st;
-  return enqueue_estimate(c, n_pairs, d_poses_out, reinterpret_cast<StatsOut*>(d_stats_out));
+  if (!c->overlap_gradients) {
+    st = enqueue_gradients(c, g_first, g_n, g_slots);
+    if (st) return st;
+    return enqueue_estimate(c, n_pairs, d_poses_out, reinterpret_cast<StatsOut*>(d_stats_out));
+  }
+  // The alignment starts at the coarsest iterated level and only then needs the finer gradients: the first level's are
+  // computed here, the others on the side stream, each level's event gating the iterations that read it.
+  HIPCHK(c, hipEventRecord(c->ev_pyramids, c->stream));
+  st = enqueue_gradient_level(c, c->p.first_level, g_first, g_n, g_slots);
+  if (st) return st;
+  HIPCHK(c, hipStreamWaitEvent(c->side, c->ev_pyramids, 0));
+  for (int l = c->p.first_level - 1; l >= 0; l--) {
+    st = enqueue_gradient_level(c, l, g_first, g_n, g_slots, c->side);
+    if (st) return st;
+    HIPCHK(c, hipEventRecord(c->ev_level[l], c->side));
+  }
+  for (int l = c->p.first_level + 1; l < c->p.n_levels; l++) {  // levels the solver never iterates: ApplyGradient still fills them
+    st = enqueue_gradient_level(c, l, g_first, g_n, g_slots, c->side);
+    if (st) return st;
+  }
+  HIPCHK(c, hipEventRecord(c->ev_side_done, c->side));
+  st = enqueue_estimate(c, n_pairs, d_poses_out, reinterpret_cast<StatsOut*>(d_stats_out), c->ev_level);
+  // whatever follows on the context stream (the next call's pyramids, a plane read-back) is ordered after the side work
+  const hipError_t e = hipStreamWaitEvent(c->stream, c->ev_side_done, 0);
+  if (st) return st;
+  if (e != hipSuccess) return fail(c, UWT_ERR_HIP, std::string("hipStreamWaitEvent: ") + hipGetErrorString(e));
+  return UWT_OK;
 }
 
 int uwt_sync(uwt_ctx* c) {
