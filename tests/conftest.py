@@ -13,6 +13,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A stalled test fails after 10 minutes instead of holding the run (pytest-timeout, when it is installed)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("timeout") is None:
+            item.add_marker(pytest.mark.timeout(600))
+
+
 @pytest.fixture(scope="session")
 def O():
     """The CPU oracle (test infrastructure)."""
