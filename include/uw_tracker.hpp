@@ -181,6 +181,25 @@ class Tracker {
   }
   // include/Tracker.h:224 / :235 — selects the weighting of the following EstimatePose calls (the reference switches by
   // commenting src/Tracker.cpp:495-496): 0 IdentityWeights, 1 TukeyFunctionWeights, 2 Huber (extension)
+  // include/Tracker.h:206-235 — the weights helpers on an explicit residual vector
+  float MedianMat(const std::vector<float>& _input) {
+    float med = 0.f;
+    check(uwt_robust_weights(ctx(), _input.data(), (int32_t)_input.size(), 0, nullptr, &med, nullptr), "MedianMat");
+    return med;
+  }
+  float MedianAbsoluteDeviation(const std::vector<float>& x) {
+    float mad = 0.f;
+    check(uwt_robust_weights(ctx(), x.data(), (int32_t)x.size(), 0, nullptr, nullptr, &mad), "MedianAbsoluteDeviation");
+    return mad;
+  }
+  std::vector<float> IdentityWeights(int _num_residuals) { return std::vector<float>((size_t)_num_residuals, 1.0f); }
+  std::vector<float> TukeyFunctionWeights(const std::vector<float>& _residuals) {
+    std::vector<float> w(_residuals.size());
+    check(uwt_robust_weights(ctx(), _residuals.data(), (int32_t)_residuals.size(), 1, w.data(), nullptr, nullptr),
+          "TukeyFunctionWeights");
+    return w;
+  }
+
   void SetWeights(int weights) {
     uwt_params p;
     check(uwt_get_params(ctx(), &p), "uwt_get_params");

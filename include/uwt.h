@@ -201,6 +201,15 @@ int uwt_solve_delta(uwt_ctx* ctx, const float A[36], const float b[6], float del
  * src/Tracker.cpp:634-640, 834, 856) this is the reference's live tracking call. */
 int uwt_estimate_pose_points(uwt_ctx* ctx, int32_t ref_slot, int32_t tgt_slot, const float* const* tables,
                              const int32_t* n_points, float pose_out[7], uwt_stats* stats_out_or_null);
+/* Tracker::MedianMat (src/Tracker.cpp:1571-1594), MedianAbsoluteDeviation (:1607-1619), IdentityWeights (:1621-1624) and
+ * TukeyFunctionWeights (:1626-1654) on an explicit N x 1 residual vector (host pointers).  kind: 0 identity, 1 Tukey.
+ * median_out = MedianMat(residuals) (256-bin histogram of the rounded values saturated to u8, first bin whose cumulative
+ * count exceeds float(n / 2)); mad_out = 1.4826 * MedianMat(|residuals - median|); weights_out (n floats, or NULL when
+ * only the statistics are wanted): ones, or (1 - (x / 4.6851)^2)^2 for |x| <= 4.6851 and 0 beyond, x = r / MAD (MAD = 1
+ * when it is 0). */
+int uwt_robust_weights(uwt_ctx* ctx, const float* residuals, int32_t n, int32_t kind, float* weights_out,
+                       float* median_out_or_null, float* mad_out_or_null);
+
 /* frame->gradient_[lvl] (src/Tracker.cpp:1136-1142): u8 plane copied to the host */
 int uwt_gradient_magnitude(uwt_ctx* ctx, int32_t slot, int32_t lvl, uint8_t* mag_out);
 /* Tracker::ObtainCandidatePoints for one level (src/Tracker.cpp:1314-1362): gradient_ > mean + threshold

@@ -153,3 +153,40 @@ def test_gpu_invalid_mode_combinations(capi):
         capi.Context(capi.default_params(160, 96, *MID, sampler=1, weights=1))   # reference Tukey medians need integer residuals
     with pytest.raises(capi.UwtError):
         capi.Context(capi.default_params(160, 96, *MID, weights=3))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["integers", "floats", "ties", "all_equal", "one", "negatives", "large"])
+def test_weights_helpers_on_explicit_vectors(capi, O, case):
+    """uwt_robust_weights = Tracker::MedianMat / MedianAbsoluteDeviation / IdentityWeights / TukeyFunctionWeights
+    (src/Tracker.cpp:1571-1654) on an N x 1 vector: medians, MAD and every weight bit-identical to the oracle."""
+    rng = np.random.default_rng(4242)
+    r = dict(integers=rng.integers(-255, 256, 20000).astype(np.float32),
+             floats=(rng.normal(0, 30, 30001) + 12.3).astype(np.float32),
+             ties=(rng.integers(0, 40, 4097) + 0.5).astype(np.float32),          # cvRound: half to even
+             all_equal=np.full(513, 7.0, np.float32),                           # MAD = 0 -> 1
+             one=np.array([3.25], np.float32),
+             negatives=-np.abs(rng.normal(0, 50, 999)).astype(np.float32),      # saturate to 0
+             large=(rng.normal(0, 400, 307200)).astype(np.float32))[case]       # saturate to 255; a full 640x480 level
+    ctx = capi.Context(capi.default_params(64, 48, 64.0, 64.0, 31.5, 23.5, max_frames=2, max_pairs=1, n_levels=1, first_level=0, last_level=0))
+    w, med, mad = ctx.robust_weights(r, kind=1)
+    assert med == O.median_mat(r) and mad == O.mad(r)
+    assert np.array_equal(w.view(np.uint32), O.tukey_weights(r).view(np.uint32))
+    w0, med0, mad0 = ctx.robust_weights(r, kind=0)
+    assert np.array_equal(w0, np.ones_like(r)) and (med0, mad0) == (med, mad)
+    none, med1, mad1 = ctx.robust_weights(r, kind=1, want_weights=False)
+    assert none is None and (med1, mad1) == (med, mad)
+    with pytest.raises(Exception):
+        ctx.robust_weights(r, kind=2)
+
+
+@pytest.mark.gpu
+def test_tracker_mirror_weight_helpers(O):
+    import importlib
+    tr = importlib.import_module("uw-slam_amd.tracker")
+    t = tr.Tracker(False, max_frames=2, n_levels=2, first_level=1, last_level=0)
+    t.InitializePyramid(64, 48, np.array([[64, 0, 31.5], [0, 64, 23.5], [0, 0, 1]], np.float32))
+    r = np.random.default_rng(9).normal(5, 20, 5000).astype(np.float32)
+    assert t.MedianMat(r) == O.median_mat(r) and t.MedianAbsoluteDeviation(r) == O.mad(r)
+    assert np.array_equal(t.TukeyFunctionWeights(r), O.tukey_weights(r))
+    assert np.array_equal(t.IdentityWeights(17), np.ones(17, np.float32))

@@ -52,7 +52,7 @@ SYMBOLS = [
     "uwt_residual_jacobian_weighted", "uwt_estimate_pose_points", "uwt_gradient_magnitude",
     "uwt_obtain_candidate_points", "uwt_obtain_patch_points",
     "uwt_ingest_create", "uwt_ingest_destroy", "uwt_ingest_maps", "uwt_ingest_undistort", "uwt_ingest_calculate_roi",
-    "uwt_ingest_frame", "uwt_update_params", "uwt_get_params", "uwt_ls_accumulate_sse",
+    "uwt_ingest_frame", "uwt_update_params", "uwt_get_params", "uwt_ls_accumulate_sse", "uwt_robust_weights",
 ]
 
 _lib = None
@@ -362,6 +362,16 @@ class Context:
         rc = lib().uwt_estimate_pose_points(self._h, ref_slot, tgt_slot, ptrs, counts, _p(pose, C.c_float), C.byref(st))
         self._chk(rc, allow=(ERR_PAIR_FAILED,))
         return pose, dict(status=st.status, iterations=st.iterations, n_valid=st.n_valid, error=st.error)
+
+    def robust_weights(self, residuals, kind=1, want_weights=True):
+        """MedianMat / MedianAbsoluteDeviation / IdentityWeights (kind 0) / TukeyFunctionWeights (kind 1) of an N x 1 vector.
+        Returns (weights or None, median, MAD)."""
+        r = np.ascontiguousarray(residuals, np.float32).reshape(-1)
+        w = np.empty(r.size, np.float32) if want_weights else None
+        med, mad = C.c_float(), C.c_float()
+        self._chk(lib().uwt_robust_weights(self._h, _p(r, C.c_float), r.size, int(kind), _p(w, C.c_float) if want_weights else None,
+                                           C.byref(med), C.byref(mad)))
+        return w, med.value, mad.value
 
     def gradient_magnitude(self, slot, lvl):
         L = self.level_info(lvl)

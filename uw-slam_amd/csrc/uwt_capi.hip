@@ -1204,6 +1204,29 @@ static int mag_to_scratch(uwt_ctx* c, int slot, int lvl, uint8_t** d_mag, unsign
   return UWT_OK;
 }
 
+int uwt_robust_weights(uwt_ctx* c, const float* residuals, int32_t n, int32_t kind, float* weights_out, float* median_out,
+                       float* mad_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
+  if (!c || !residuals || n < 1 || (kind != kWeightsIdentity && kind != kWeightsTukeyRef))
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_robust_weights: null residuals, n < 1, or a kind other than identity / Tukey");
+  const size_t bytes = sizeof(float) * (size_t)n;
+  int st = ensure_scratch(c, 2 * bytes + 64);
+  if (st) return st;
+  float* d_r = (float*)c->scratch;
+  float* d_w = d_r + n;
+  float* d_stats = d_w + n;
+  HIPCHK(c, hipMemcpyAsync(d_r, residuals, bytes, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_robust_weights, dim3(1), dim3(1024), 0, c->stream, d_r, n, kind, weights_out ? d_w : nullptr, d_stats);
+  HIPCHK(c, hipGetLastError());
+  float stats[2] = {0.f, 0.f};
+  if (weights_out) HIPCHK(c, hipMemcpyAsync(weights_out, d_w, bytes, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpyAsync(stats, d_stats, sizeof(stats), hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (median_out) *median_out = stats[0];
+  if (mad_out) *mad_out = stats[1];
+  return UWT_OK;
+}
+
 int uwt_gradient_magnitude(uwt_ctx* c, int32_t slot, int32_t lvl, uint8_t* mag_out) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !mag_out || !slot_range_ok(c, slot, 1) || lvl < 0 || lvl >= c->p.n_levels)

@@ -504,6 +504,48 @@ __device__ __forceinline__ float robust_weight(int mode, float rf, float inv_mad
 }
 
 
+// Tracker::MedianMat / MedianAbsoluteDeviation / IdentityWeights / TukeyFunctionWeights on an explicit N x 1 residual
+// vector (src/Tracker.cpp:1571-1654).  One block: a 256-bin LDS histogram of the saturated, rounded values gives the
+// median by the reference's rule (first bin whose cumulative count exceeds float(n / 2)), a second histogram of the
+// deviations gives the MAD, then the weights.  out_stats: [median, 1.4826 * median deviation].
+__global__ __launch_bounds__(1024) void k_robust_weights(const float* __restrict__ r, int n, int kind, float* __restrict__ w,
+                                                         float* __restrict__ out_stats) {
+  __shared__ unsigned int hist[256];
+  __shared__ float s_med, s_mad;
+  auto median_of_hist = [&]() {   // thread 0
+    const float m = (float)(n / 2);
+    unsigned int bin = 0;
+    float med = -1.0f;
+    for (int i = 0; i < 256 && med < 0.0f; ++i) {
+      bin += hist[i];
+      if ((float)bin > m) med = (float)i;
+    }
+    return med;
+  };
+  for (int pass = 0; pass < 2; pass++) {
+    for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+      const float v = pass == 0 ? r[i] : fabsf(r[i] - s_med);
+      int q = (int)rintf(v);   // cvRound: round half to even, then saturate_cast<uchar>
+      q = q < 0 ? 0 : (q > 255 ? 255 : q);
+      atomicAdd(&hist[q], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const float med = median_of_hist();
+      if (pass == 0) s_med = med; else s_mad = 1.4826f * med;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out_stats[0] = s_med; out_stats[1] = s_mad; }
+  if (!w) return;
+  float mad = s_mad;
+  if (mad == 0.0f) mad = 1.0f;
+  const float inv_mad = (float)(1.0 / (double)mad);
+  for (int i = threadIdx.x; i < n; i += blockDim.x) w[i] = robust_weight(kind, r[i], inv_mad);
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // k_residual: one launch = one Gauss-Newton residual evaluation of one pyramid level for a whole batch.
 // grid = (slices, pairs); each block walks `groups_per_block` groups of VEC consecutive pixels of its pair's

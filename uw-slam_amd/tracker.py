@@ -125,6 +125,22 @@ class Tracker:
         _previous_frame.rigid_transformation_ = pose
         return st
 
+    def MedianMat(self, _input):
+        """include/Tracker.h:206, src/Tracker.cpp:1571-1594."""
+        return self._ctx.robust_weights(_input, kind=0, want_weights=False)[1]
+
+    def MedianAbsoluteDeviation(self, x):
+        """include/Tracker.h:216, src/Tracker.cpp:1607-1619."""
+        return self._ctx.robust_weights(x, kind=0, want_weights=False)[2]
+
+    def IdentityWeights(self, _num_residuals):
+        """include/Tracker.h:224, src/Tracker.cpp:1621-1624."""
+        return self._ctx.robust_weights(np.zeros(int(_num_residuals), np.float32), kind=0)[0]
+
+    def TukeyFunctionWeights(self, _residuals):
+        """include/Tracker.h:235, src/Tracker.cpp:1626-1654."""
+        return self._ctx.robust_weights(_residuals, kind=1)[0]
+
     def GetFrameData(self, _frame, lvl, plane):
         return self._ctx.get_plane(self._bind(_frame), lvl, plane)
 
