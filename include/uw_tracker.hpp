@@ -181,6 +181,15 @@ class Tracker {
   }
   // include/Tracker.h:224 / :235 — selects the weighting of the following EstimatePose calls (the reference switches by
   // commenting src/Tracker.cpp:495-496): 0 IdentityWeights, 1 TukeyFunctionWeights, 2 Huber (extension)
+  // include/Tracker.h:197 — gradients of a tightly packed u8 image (3 x Scharr, CV_16S)
+  void ObtainGradientXY(const ImageView& _inputImage, std::vector<int16_t>& _gradientX, std::vector<int16_t>& _gradientY) {
+    if (_inputImage.step != (size_t)_inputImage.cols) throw std::runtime_error("ObtainGradientXY: image rows must be contiguous");
+    _gradientX.resize((size_t)_inputImage.rows * _inputImage.cols);
+    _gradientY.resize(_gradientX.size());
+    check(uwt_scharr3(ctx(), static_cast<const uint8_t*>(_inputImage.data), _inputImage.cols, _inputImage.rows, _gradientX.data(),
+                      _gradientY.data()), "ObtainGradientXY");
+  }
+
   // include/Tracker.h:206-235 — the weights helpers on an explicit residual vector
   float MedianMat(const std::vector<float>& _input) {
     float med = 0.f;

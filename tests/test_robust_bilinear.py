@@ -190,3 +190,7 @@ def test_tracker_mirror_weight_helpers(O):
     assert t.MedianMat(r) == O.median_mat(r) and t.MedianAbsoluteDeviation(r) == O.mad(r)
     assert np.array_equal(t.TukeyFunctionWeights(r), O.tukey_weights(r))
     assert np.array_equal(t.IdentityWeights(17), np.ones(17, np.float32))
+    img = np.random.default_rng(3).integers(0, 256, (48, 64), dtype=np.uint8)
+    gx, gy = t.ObtainGradientXY(img)
+    ox, oy = O.scharr3(img)
+    assert np.array_equal(gx, ox) and np.array_equal(gy, oy)

@@ -125,6 +125,10 @@ class Tracker:
         _previous_frame.rigid_transformation_ = pose
         return st
 
+    def ObtainGradientXY(self, _inputImage):
+        """include/Tracker.h:197 — (gradientX, gradientY) = 3 x Scharr of a u8 image, CV_16S (src/Tracker.cpp:1133-1134)."""
+        return self._ctx.scharr3(_inputImage)
+
     def MedianMat(self, _input):
         """include/Tracker.h:206, src/Tracker.cpp:1571-1594."""
         return self._ctx.robust_weights(_input, kind=0, want_weights=False)[1]
