@@ -576,6 +576,7 @@ int uwt_destroy(uwt_ctx* c) {
   if (!c) return UWT_ERR_INVALID_ARG;
   (void)hipSetDevice(c->p.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->side) (void)hipStreamSynchronize(c->side);  // an aborted uwt_track_batch_async may have left work there
   for (int l = 0; l < UWT_MAX_LEVELS; l++) {
     if (c->img[l]) (void)hipFree(c->img[l]);
     if (c->depth[l]) (void)hipFree(c->depth[l]);
