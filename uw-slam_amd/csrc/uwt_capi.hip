@@ -789,7 +789,7 @@ int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int3
   const int g_first = g_slots ? 0 : first_slot, g_n = g_slots ? n_pairs : n_frames;
   st = grad_refs_only ? enqueue_pyramids(c, first_slot, n_frames, c->d_ref, n_pairs) : enqueue_pyramids(c, first_slot, n_frames);
   if (st) return st;
-  if (!c->overlap_gradients) {
+  if (!c->overlap_gradients || c->profiling) {  // a profiled call times its kernels alone: nothing runs beside them
     st = enqueue_gradients(c, g_first, g_n, g_slots);
     if (st) return st;
     return enqueue_estimate(c, n_pairs, d_poses_out, reinterpret_cast<StatsOut*>(d_stats_out));
