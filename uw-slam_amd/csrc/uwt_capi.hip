@@ -789,7 +789,9 @@ int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int3
   const int g_first = g_slots ? 0 : first_slot, g_n = g_slots ? n_pairs : n_frames;
   st = grad_refs_only ? enqueue_pyramids(c, first_slot, n_frames, c->d_ref, n_pairs) : enqueue_pyramids(c, first_slot, n_frames);
   if (st) return st;
-  if (!c->overlap_gradients || c->profiling) {  // a profiled call times its kernels alone: nothing runs beside them
+  // The side stream pays from ~768 pairs on (+1.7 % at 1024); below, its events cost more than the overlap returns
+  // (one pair: +14 % latency).  A profiled call times its kernels alone: nothing runs beside them.
+  if (!c->overlap_gradients || c->profiling || n_pairs < 768) {
     st = enqueue_gradients(c, g_first, g_n, g_slots);
     if (st) return st;
     return enqueue_estimate(c, n_pairs, d_poses_out, reinterpret_cast<StatsOut*>(d_stats_out));

@@ -1126,7 +1126,7 @@ __device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair
     else if (lane == 29) sums[kAccFloats] = a.general ? cs : 0.0;
   }
   __syncthreads();
-  if (lane != 0) return;
+  if (lane >= 64) return;   // wave 0 runs the tail together on the same (uniform) values; lane 0 stores the result
   if (live) {
     const int n = (int)isums[0];
     const long long sr2 = isums[1];
@@ -1151,28 +1151,19 @@ __device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair
       }
     }
     if (update) {
-      float A[36], b[6], delta[6];
-      int s = 0;
-#pragma unroll
-      for (int i = 0; i < 6; i++)
-#pragma unroll
-        for (int j = i; j < 6; j++, s++) {
-          const float v = (float)sums[s];
-          A[6 * i + j] = v;
-          A[6 * j + i] = v;
-        }
+      float b[6], delta[6];
 #pragma unroll
       for (int i = 0; i < 6; i++)
         b[i] = a.general ? (float)(-sums[21 + i]) : (float)(-((double)a.gain * sums[21 + i]));  // :559-561
-      solve_delta(A, b, delta, nullptr);                                              // :564
+      solve_delta_wave(sums, b, delta);                                                // :554-564, A = (float)sums[0..20]
       Pose d, np;
       se3_exp(delta, d);                                                              // :574
       se3_mul(st.pose, d, np);
       st.pose = np;
-      if (a.active) atomicAdd(a.active, 1);
+      if (a.active && lane == 0) atomicAdd(a.active, 1);
     }
   }
-  a.state[pair] = st;
+  if (lane == 0) a.state[pair] = st;
 }
 
 __global__ __launch_bounds__(kUpdateBlock) void k_gn_update(const UpdateArgs a) { update_block(a, (int)blockIdx.x + a.pair_base); }

@@ -216,4 +216,80 @@ __device__ inline bool solve_delta(const float A[36], const float b[6], float de
   return ok;
 }
 
+// The same A.inv() * b with the 12 columns of [A | X] spread over 12 lanes of a wave (lane c < 6 owns column c of A,
+// lane 6 + j column j of X = I; every lane of the wave must be active and hold the same `sums` / `b`).  Each element goes
+// through exactly the operations of inv6_lu — the elimination updates every column of a row alike — so the result is
+// bit-identical; what changes is that a row operation is one instruction instead of twelve, and the pivot, the
+// multipliers and the upper triangle travel through v_readlane.  Entries the serial code never reads again (below the
+// diagonal of eliminated columns) are left with other junk here.
+__device__ __forceinline__ float lane_f(float v, int lane) {
+  return __uint_as_float((unsigned)__builtin_amdgcn_readlane((int)__float_as_uint(v), lane));
+}
+
+// sums: the 21 upper-triangle entries of A in row-major order (as accumulated); returns false when singular (delta = 0)
+__device__ inline bool solve_delta_wave(const double* sums, const float b[6], float delta[6]) {
+  const int lane = (int)(threadIdx.x & 63u);
+  const int c = lane < 12 ? lane : 11;  // lanes >= 12 shadow lane 11
+  float col[6];
+#pragma unroll
+  for (int r = 0; r < 6; r++) {
+    const int i = r < c ? r : c, j = r < c ? c : r;          // (min, max) of (r, c) for the A lanes
+    const int idx = i * 6 - (i * (i - 1)) / 2 + (j - i);
+    const float a_rc = (float)sums[c < 6 ? idx : 0];
+    col[r] = c < 6 ? a_rc : (r == c - 6 ? 1.f : 0.f);
+  }
+  const float eps = 1.1920929e-07f * 10;
+  bool singular = false;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    int k = i;
+    float best = fabsf(col[i]);
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) {
+      const float v = fabsf(col[j]);
+      if (v > best) { best = v; k = j; }  // "abs(A[j][i]) > abs(A[k][i])": the first maximum wins
+    }
+    k = __builtin_amdgcn_readlane(k, i);          // lane i owns column i
+    best = lane_f(best, i);
+    if (best < eps) { singular = true; break; }   // wave-uniform
+#pragma unroll
+    for (int j = i + 1; j < 6; j++)
+      if (k == j) { const float t = col[i]; col[i] = col[j]; col[j] = t; }   // wave-uniform branch
+    const float d = lane_f(-1.f / col[i], i);
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) {
+      const float alpha = lane_f(col[j] * d, i);
+      col[j] = col[j] + alpha * col[i];
+    }
+    if (lane == i) col[i] = -d;
+  }
+  if (singular) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) delta[i] = 0.f;   // cv::Mat::inv() returns zeros, zeros * b = 0
+    return false;
+  }
+  // the upper triangle and the (inverted) diagonal, out of the A lanes before the X lanes' columns are overwritten
+  float U[6][6];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int q = i; q < 6; q++) U[i][q] = lane_f(col[i], q);
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float sacc = col[i];
+#pragma unroll
+    for (int q = i + 1; q < 6; q++) sacc = sacc - U[i][q] * col[q];
+    col[i] = sacc * U[i][i];
+  }
+  // delta = X * b, f64 accumulation in column order, rounded once (X[i][j] lives in lane 6 + j)
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) acc += (double)lane_f(col[i], 6 + j) * (double)b[j];
+    delta[i] = (float)acc;
+  }
+  return true;
+}
+
 }  // namespace uwt
