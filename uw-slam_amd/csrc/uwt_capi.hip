@@ -62,8 +62,11 @@ struct uwt_ctx {
 
 namespace {
 
-constexpr int kGroupsPerThread = 8;  // x VEC pixels per thread: the finest slicing (single pair); batches coarsen it in enqueue_estimate.
-                                     // The f64 partial sums then group differently — 1e-16 relative, far below the f32 rounding of A and b
+// x VEC pixels per thread at the finest slicing, the one a single pair runs with: short blocks, as many as the fold of
+// k_gn_update stages in LDS (kStageSlices).  One pair at 640x480: 150 level-0 blocks of 8 pixels per thread — 0.60 ms per
+// 4 x 10 alignment against 0.75 ms with 8 groups per thread; batches coarsen the slicing in enqueue_estimate.  The f64
+// partial sums group differently with the slicing — 1e-16 relative, far below the f32 rounding of A and b.
+constexpr int kGroupsPerThread = 2;
 
 int fail(uwt_ctx* c, int code, const std::string& msg) {
   if (c) c->last_error = msg;
@@ -521,7 +524,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   size_t max_slices = 1;
   for (int l = 0; l < p->n_levels; l++) {
     const int n_groups = c->lv[l].n / c->vec;
-    int gpt = kGroupsPerThread;
+    int gpt = std::max(kGroupsPerThread, (n_groups + kStageSlices * kBlock - 1) / (kStageSlices * kBlock));
     if (const char* e = std::getenv("UWT_GROUPS_PER_THREAD")) gpt = std::max(1, std::atoi(e));  // tuning experiments only
     c->groups_per_block[l] = kBlock * gpt;
     c->slices[l] = (n_groups + c->groups_per_block[l] - 1) / c->groups_per_block[l];
