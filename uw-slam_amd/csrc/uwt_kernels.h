@@ -591,10 +591,13 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
   return;
 #endif
   if constexpr (VEC == 4) {
+    // byte offsets in 32 bits (a level plane of one frame is < 2^31 bytes): uniform base + 32-bit lane offset addressing,
+    // no 64-bit address arithmetic per load
+    const uint32_t o2 = idx * 2u;
     *reinterpret_cast<uint32_t*>(r.i1) = *reinterpret_cast<const uint32_t*>(I1 + idx);
-    *reinterpret_cast<uint2*>(r.gx) = *reinterpret_cast<const uint2*>(GX + idx);
-    *reinterpret_cast<uint2*>(r.gy) = *reinterpret_cast<const uint2*>(GY + idx);
-    if constexpr (DEPTH) *reinterpret_cast<uint2*>(r.dp) = *reinterpret_cast<const uint2*>(DP + idx);
+    *reinterpret_cast<uint2*>(r.gx) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(GX) + o2);
+    *reinterpret_cast<uint2*>(r.gy) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(GY) + o2);
+    if constexpr (DEPTH) *reinterpret_cast<uint2*>(r.dp) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(DP) + o2);
   } else {
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
