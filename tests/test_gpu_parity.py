@@ -653,3 +653,35 @@ def test_fuzz_whole_alignment_bit_identical(capi, O, synth, seed):
         if cpu[i][0] == 0:
             assert stats[i]["iterations"] == len(cpu[i][2]), (over, i)
             assert np.array_equal(poses[i], cpu[i][1]), (over, i, poses[i], cpu[i][1])
+
+
+def test_large_batch_takes_the_overlapped_gradient_path(capi, O, synth):
+    """From 768 pairs up uwt_track_batch_async computes the finer levels' gradients on a side stream beside the coarse
+    iterations.  800 pairs (8 distinct, tiled, with depth): every copy bit-identical to the oracle, twice in a row."""
+    import torch
+    w, h, n, u = 64, 48, 800, 8
+    over = dict(n_levels=3, first_level=2, last_level=0, max_iters=4, early_exit=0, has_depth=1)
+    p = O.default_params(w, h, *SMALL, **over)
+    refs, tgts, deps, cpu = [], [], [], []
+    for s in range(u):
+        ref, tgt, dep, _, _ = synth.render_pair(w, h, *SMALL, seed=8800 + s, with_depth=True, max_t=0.02, max_deg=1.0)
+        refs.append(ref); tgts.append(tgt); deps.append(dep)
+        cpu.append(O.align_pair(p, ref, tgt, dep)[1])
+    idx = np.arange(n) % u
+    frames = np.empty((2 * n, h, w), np.uint8)
+    frames[0::2] = np.stack(refs)[idx]
+    frames[1::2] = np.stack(tgts)[idx]
+    depth = np.empty((2 * n, h, w), np.uint16)
+    depth[0::2] = np.stack(deps)[idx]
+    depth[1::2] = depth[0::2]
+    ctx = make_ctx(capi, w, h, SMALL, max_frames=2 * n, max_pairs=n, **over)
+    ctx.upload_frames(0, frames, depth)
+    d_poses = torch.zeros((n, 7), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    expect = np.stack(cpu)[idx]
+    for _ in range(2):
+        ctx.track_batch_async(0, 2 * n, np.arange(n) * 2, np.arange(n) * 2 + 1, d_poses.data_ptr())
+        ctx.sync()
+        assert np.array_equal(d_poses.cpu().numpy(), expect)
+        d_poses.zero_()
+        torch.cuda.synchronize()
