@@ -130,11 +130,15 @@ def main():
     poses = torch.empty((P, 7), dtype=torch.float32, device=dev)
     gathered = torch.empty((world * P, 7), dtype=torch.float32, device=dev) if use_dist else None
 
+    # torch sees the context's HIP stream as an external stream: the RCCL gather is enqueued behind the alignment on that
+    # stream (no host synchronisation per step), and the next step's kernels queue behind the gather.
+    ctx_stream = torch.cuda.ExternalStream(ctx.stream(), device=dev) if use_dist else None
+
     def step():
         ctx.track_batch_async(0, 2 * P, ref_slots, tgt_slots, poses.data_ptr())
         if use_dist:
-            ctx.sync()                                     # the context stream is not torch's stream
-            dist.all_gather_into_tensor(gathered, poses)   # RCCL gather of the solved poses over xGMI
+            with torch.cuda.stream(ctx_stream):
+                dist.all_gather_into_tensor(gathered, poses)   # RCCL gather of the solved poses over xGMI
 
     def fence():
         ctx.sync()
