@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "uwt_math.h"
 
 namespace uwt {
@@ -206,51 +208,73 @@ struct WarpK {
   float T[12];
 };
 
+// Packed f32.  On gfx950 a plain f32 multiply / add / fma issues in 2 cycles per wave only while every operand is a VGPR,
+// an inline constant or a literal; with a scalar-register operand (the rigid matrix, the intrinsics) it takes 4, like
+// every compare, select, conversion and integer op (tools/ubench/valu_classes*.hip).  v_pk_{mul,add,fma}_f32 take 4
+// cycles for TWO pixels with or without a scalar operand, so the per-pixel float sequence is written over pairs of
+// adjacent pixels: the block-uniform operands stay in SGPRs (no VGPR cost, 4 waves/SIMD kept) and cost nothing extra.
+// Each component sees exactly the scalar IEEE operation (same rounding, no contraction), so results are bit-identical
+// to the one-pixel form, which the VEC = 1 fallback and the per-stage kernels still use (F = float).
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <typename F> struct lanes { static constexpr int n = 1; };
+template <> struct lanes<v2f> { static constexpr int n = 2; };
+template <typename F> __device__ __forceinline__ F bc(float s) { return (F)(s); }   // broadcast a (uniform) scalar
+__device__ __forceinline__ float get(float v, int) { return v; }
+__device__ __forceinline__ float get(v2f v, int i) { return i ? v.y : v.x; }
+__device__ __forceinline__ void put(float& v, int, float s) { v = s; }
+__device__ __forceinline__ void put(v2f& v, int i, float s) { if (i) v.y = s; else v.x = s; }
+template <typename F> __device__ __forceinline__ F fma_(F a, F b, F c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ float rcp_(float d) { return __builtin_amdgcn_rcpf(d); }
+__device__ __forceinline__ v2f rcp_(v2f d) { return (v2f){__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)}; }
+
 // Correctly rounded f32 quotients sharing one refined reciprocal of the common denominator: the same
 // rcp / Newton / two-residual-correction sequence hipcc emits for an IEEE `a / b`, minus the div_scale / div_fixup
 // range handling.  Bit-identical to `a / b` for normal-range operands and quotients; a zero, infinite or NaN
-// denominator yields NaN or infinity here as there, and such a pixel fails the bounds test either way.
+// denominator yields NaN here (IEEE: NaN or infinity), and such a pixel fails the bounds test either way.
 // refined_rcp(d) itself equals the IEEE 1.0f / d for every one of the 2^23 mantissas (checked exhaustively at nine
 // exponents, both signs, by tools/ubench/rcp_check.hip on gfx950), so a reciprocal needs no further correction; a general
 // numerator does (Markstein: n * r can be 1.5 ulp off), hence the two residual corrections in div_by.
-__device__ __forceinline__ float refined_rcp(float d) {
-  float r = __builtin_amdgcn_rcpf(d);
-  const float e = __builtin_fmaf(-d, r, 1.0f);
-  return __builtin_fmaf(e, r, r);
+template <typename F>
+__device__ __forceinline__ F refined_rcp(F d) {
+  F r = rcp_(d);
+  const F e = fma_(-d, r, bc<F>(1.0f));
+  return fma_(e, r, r);
 }
-__device__ __forceinline__ float div_by(float n, float d, float r) {
-  float q = n * r;
-  float e = __builtin_fmaf(-d, q, n);
-  q = __builtin_fmaf(e, r, q);
-  e = __builtin_fmaf(-d, q, n);
-  return __builtin_fmaf(e, r, q);
+template <typename F>
+__device__ __forceinline__ F div_by(F n, F d, F r) {
+  F q = n * r;
+  F e = fma_(-d, q, n);
+  q = fma_(e, r, q);
+  e = fma_(-d, q, n);
+  return fma_(e, r, q);
 }
 
-__device__ __forceinline__ void warp_point(const LevelK& L, const WarpK& K, float xf, float yf, float z, float& u,
-                                           float& v, float& zp, float& iz) {
-  float X = (xf - L.cx) * L.invfx;
+template <typename F>
+__device__ __forceinline__ void warp_point(const LevelK& L, const WarpK& K, F xf, F yf, F z, F& u, F& v, F& zp, F& iz) {
+  F X = (xf - bc<F>(L.cx)) * bc<F>(L.invfx);
   X = X * z;
-  float Y = (yf - L.cy) * L.invfy;
+  F Y = (yf - bc<F>(L.cy)) * bc<F>(L.invfy);
   Y = Y * z;
-  float xp = K.T[0] * X;
-  xp = __builtin_fmaf(K.T[1], Y, xp);
-  xp = __builtin_fmaf(K.T[2], z, xp);
-  xp = xp + K.T[3];  // fma(T03, w = 1, xp)
-  float yp = K.T[4] * X;
-  yp = __builtin_fmaf(K.T[5], Y, yp);
-  yp = __builtin_fmaf(K.T[6], z, yp);
-  yp = yp + K.T[7];
-  zp = K.T[8] * X;
-  zp = __builtin_fmaf(K.T[9], Y, zp);
-  zp = __builtin_fmaf(K.T[10], z, zp);
-  zp = zp + K.T[11];
-  const float r = refined_rcp(zp);
-  u = xp * L.fx;
+  F xp = bc<F>(K.T[0]) * X;
+  xp = fma_(bc<F>(K.T[1]), Y, xp);
+  xp = fma_(bc<F>(K.T[2]), z, xp);
+  xp = xp + bc<F>(K.T[3]);  // fma(T03, w = 1, xp)
+  F yp = bc<F>(K.T[4]) * X;
+  yp = fma_(bc<F>(K.T[5]), Y, yp);
+  yp = fma_(bc<F>(K.T[6]), z, yp);
+  yp = yp + bc<F>(K.T[7]);
+  zp = bc<F>(K.T[8]) * X;
+  zp = fma_(bc<F>(K.T[9]), Y, zp);
+  zp = fma_(bc<F>(K.T[10]), z, zp);
+  zp = zp + bc<F>(K.T[11]);
+  const F r = refined_rcp(zp);
+  u = xp * bc<F>(L.fx);
   u = div_by(u, zp, r);
-  u = u + L.cx;
-  v = yp * L.fy;
+  u = u + bc<F>(L.cx);
+  v = yp * bc<F>(L.fy);
   v = div_by(v, zp, r);
-  v = v + L.cy;
+  v = v + bc<F>(L.cy);
   iz = r;  // inv_z2 = 1 / z2 (src/Tracker.cpp:447): the refined reciprocal IS the correctly rounded quotient (see refined_rcp)
 }
 
@@ -266,40 +290,70 @@ __device__ __forceinline__ int round_pos(float x) {
 // v ? x : 0 under a 64-lane mask held in an SGPR pair.  Written as the instruction so that the compiler keeps the
 // sanitising selects straight-line: left to itself it turns them into an exec-masked region per pixel and pays four
 // v_mov of zero, a saveexec and a branch for each.
+// (In place: a select that sits in a conditional region then needs no copy where the paths meet.)
 __device__ __forceinline__ float keep_f(float x, unsigned long long mask) {
-  float r;
-  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
-  return r;
+  asm("v_cndmask_b32_e64 %0, 0, %0, %1" : "+v"(x) : "s"(mask));
+  return x;
 }
 __device__ __forceinline__ int keep_i(int x, unsigned long long mask) {
-  int r;
-  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
-  return r;
+  asm("v_cndmask_b32_e64 %0, 0, %0, %1" : "+v"(x) : "s"(mask));
+  return x;
 }
 
-// Phase 1 of a pixel: warp, validity (src/Tracker.cpp:450-453) and the gather index of the nearest-neighbour sample
-// (:472).  Branch-free: an invalid pixel is sanitised (x2 = y2 = iz = 0) so that every later term is finite and its
-// Jacobian row comes out as exact zeros, which leave the accumulators unchanged.
+// Phase 1 of a pixel (F = float) or of two adjacent pixels (F = v2f): warp, validity (src/Tracker.cpp:450-453) and the
+// gather index of the nearest-neighbour sample (:472).  Branch-free: an invalid pixel is sanitised (x2 = y2 = iz = 0) so
+// that every later term is finite and its Jacobian row comes out as exact zeros, which leave the accumulators unchanged.
 // Validity is built as a 64-lane mask in scalar registers: every comparison writes an SGPR pair, the conjunction is
 // s_and_b64, nothing of it occupies the VALU beyond the compares themselves.  (LLVM FCmp / ICmp predicate codes.)
+// The reference's fifth condition, z2 != 0 (:451), needs no compare of its own: a zero z2 makes the reciprocal infinite,
+// refined_rcp turns that into NaN (0 * inf), x2 and y2 come out NaN and fail x2 > 0 — exactly as the IEEE quotient by
+// zero (infinite or NaN) fails one of the reference's four bounds tests before z2 != 0 is looked at.
 constexpr int kFcmpOGT = 2, kFcmpOLT = 4, kFcmpUGE = 11, kFcmpUNE = 14, kIcmpSGT = 38, kIcmpSLT = 40;
 __device__ __forceinline__ bool lane_bit(unsigned long long mask) { return (mask >> (threadIdx.x & 63u)) & 1ull; }
 
-__device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, float xf, float yf, float z,
-                                           unsigned long long okin_mask, float& x2, float& y2, float& iz,
-                                           unsigned long long& okm, uint32_t& gidx) {
-  float z2;
+// 1a: warp and validity masks; x2, y2, iz come back raw (possibly NaN / out of range where the mask is clear)
+template <typename F>
+__device__ __forceinline__ void pixel_warp_raw(const LevelK& L, const WarpK& K, F xf, F yf, F z,
+                                               const unsigned long long* okin_mask, F& x2, F& y2, F& iz,
+                                               unsigned long long* okm) {
+  F z2;
   warp_point(L, K, xf, yf, z, x2, y2, z2, iz);
-  okm = okin_mask & __builtin_amdgcn_fcmpf(y2, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(y2, (float)L.h, kFcmpOLT) &
-        __builtin_amdgcn_fcmpf(x2, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(x2, (float)L.w, kFcmpOLT) &
-        __builtin_amdgcn_fcmpf(z2, 0.f, kFcmpUNE);
-  x2 = keep_f(x2, okm);
-  y2 = keep_f(y2, okm);
-  iz = keep_f(iz, okm & __builtin_amdgcn_fcmpf(iz, 0.f, kFcmpUGE));  // "if (inv_z2 < 0) inv_z2 = 0" (:452-453)
-  int ix2 = round_pos(x2), iy2 = round_pos(y2);
-  ix2 = min(ix2, L.w - 1);  // the reference reads one past the edge here (:450, :472); clamp
-  iy2 = min(iy2, L.h - 1);
-  gidx = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;  // 24-bit multiply-add: one full-rate op (dims < 2^24)
+#pragma unroll
+  for (int c = 0; c < lanes<F>::n; c++) {
+    const float uc = get(x2, c), vc = get(y2, c);
+    okm[c] = okin_mask[c] & __builtin_amdgcn_fcmpf(vc, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(vc, (float)L.h, kFcmpOLT) &
+             __builtin_amdgcn_fcmpf(uc, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(uc, (float)L.w, kFcmpOLT);
+  }
+}
+// 1b: sanitise invalid pixels, clamp a negative reciprocal: "if (inv_z2 < 0) inv_z2 = 0" (:452-453)
+template <typename F>
+__device__ __forceinline__ void pixel_sanitize(F& x2, F& y2, F& iz, const unsigned long long* okm) {
+#pragma unroll
+  for (int c = 0; c < lanes<F>::n; c++) {
+    const float rc = get(iz, c);
+    put(x2, c, keep_f(get(x2, c), okm[c]));
+    put(y2, c, keep_f(get(y2, c), okm[c]));
+    put(iz, c, keep_f(rc, okm[c] & __builtin_amdgcn_fcmpf(rc, 0.f, kFcmpUGE)));
+  }
+}
+// 1c: index of the nearest-neighbour sample of (sanitised, or valid) x2, y2
+template <typename F>
+__device__ __forceinline__ void pixel_gather_index(const LevelK& L, F x2, F y2, uint32_t* gidx) {
+#pragma unroll
+  for (int c = 0; c < lanes<F>::n; c++) {
+    int ix2 = round_pos(get(x2, c)), iy2 = round_pos(get(y2, c));
+    ix2 = min(ix2, L.w - 1);  // the reference reads one past the edge here (:450, :472); clamp
+    iy2 = min(iy2, L.h - 1);
+    gidx[c] = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;  // 24-bit multiply-add: one op (dims < 2^24)
+  }
+}
+template <typename F>
+__device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, F xf, F yf, F z,
+                                           const unsigned long long* okin_mask, F& x2, F& y2, F& iz,
+                                           unsigned long long* okm, uint32_t* gidx) {
+  pixel_warp_raw(L, K, xf, yf, z, okin_mask, x2, y2, iz, okm);
+  pixel_sanitize(x2, y2, iz, okm);
+  pixel_gather_index(L, x2, y2, gidx);
 }
 
 // Phase 2: Jw (src/Tracker.cpp:455-467) and Jacobian_row = Jl * Jw (:476-479), reference operation order.
@@ -308,20 +362,19 @@ __device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, floa
 // SIGNED_ZEROS (the per-stage dump entry points): keep the reference's fma with the structural zero of Jw, which decides
 // the sign of a zero J[0] / J[1] (g0 * a0 = -0, g1 * 0 = +0 -> +0).  The sums never see the difference (x + -0 = x,
 // +0 + -0 = +0), so the solver path drops the two operations.
-template <bool UNIT_FACTORS, bool SQUARE = false, bool SIGNED_ZEROS = false>
-__device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf, float af, float x2, float y2, float iz, float g0,
-                                               float g1, float J[6]) {
-  const float fx = L.fx, fy = L.fy;
-  float a0, a2, a3, a5, b1, b2, b4, b5;
+template <bool UNIT_FACTORS, bool SQUARE = false, bool SIGNED_ZEROS = false, typename F = float>
+__device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf_, float af_, F x2, F y2, F iz, F g0, F g1, F J[6]) {
+  const F fx = bc<F>(L.fx), fy = bc<F>(L.fy), one = bc<F>(1.0f), zero = bc<F>(0.0f);
+  F a0, a2, a3, a5, b1, b2, b4, b5;
   if constexpr (SQUARE) {
-    const float fx2 = fx * x2, fy2 = fx * y2;
+    const F fx2 = fx * x2, fy2 = fx * y2;
     a0 = fx * iz;
     b1 = a0;
     b5 = fx2 * iz;                      // (fy*x2)*iz
     a2 = -(b5 * iz);                    // -(((fx*x2)*iz)*iz)
     b4 = ((fx2 * y2) * iz) * iz;        // (((fy*x2)*y2)*iz)*iz
     a3 = -b4;                           // -((((fx*x2)*y2)*iz)*iz)
-    const float t = fy2 * iz;           // (fy*y2)*iz
+    const F t = fy2 * iz;               // (fy*y2)*iz
     a5 = -t;                            // ((-fx)*y2)*iz
     b2 = -(t * iz);                     // -(((fy*y2)*iz)*iz)
   } else {
@@ -334,23 +387,24 @@ __device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf, float 
     b4 = (((fy * x2) * y2) * iz) * iz;
     b5 = (fy * x2) * iz;
   }
-  float a4 = fx * (1.0f + ((x2 * x2) * iz) * iz);
-  float b3 = -(fy * (1.0f + ((y2 * y2) * iz) * iz));
+  F a4 = fx * (one + ((x2 * x2) * iz) * iz);
+  F b3 = -(fy * (one + ((y2 * y2) * iz) * iz));
   if constexpr (!UNIT_FACTORS) {
+    const F zf = bc<F>(zf_), af = bc<F>(af_);
     a2 = a2 * zf; a3 = a3 * af; a4 = a4 * af; a5 = a5 * af;
     b2 = b2 * zf; b3 = b3 * af; b4 = b4 * af; b5 = b5 * af;
   }
   if constexpr (SIGNED_ZEROS) {
-    J[0] = __builtin_fmaf(g1, 0.0f, g0 * a0);
-    J[1] = __builtin_fmaf(g1, b1, g0 * 0.0f);
+    J[0] = fma_(g1, zero, g0 * a0);
+    J[1] = fma_(g1, b1, g0 * zero);
   } else {
     J[0] = g0 * a0;
     J[1] = g1 * b1;
   }
-  J[2] = __builtin_fmaf(g1, b2, g0 * a2);
-  J[3] = __builtin_fmaf(g1, b3, g0 * a3);
-  J[4] = __builtin_fmaf(g1, b4, g0 * a4);
-  J[5] = __builtin_fmaf(g1, b5, g0 * a5);
+  J[2] = fma_(g1, b2, g0 * a2);
+  J[3] = fma_(g1, b3, g0 * a3);
+  J[4] = fma_(g1, b4, g0 * a4);
+  J[5] = fma_(g1, b5, g0 * a5);
 }
 
 // Accumulator type: double reproduces the reference's double-accumulating gemm (src/Tracker.cpp:560-561) to the
@@ -675,22 +729,34 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
 #else
     constexpr int PH = (UWT_EXP_PHASE < VEC) ? UWT_EXP_PHASE : VEC;
 #endif
+    // Pixels are processed in units of N adjacent ones (N = 2: the packed-f32 form, see v2f above), PH pixels in flight
+    // per phase (warp -> gather -> Jacobian -> accumulate).
+    constexpr int N = (VEC % 2 == 0) ? 2 : 1;
+    using F = typename std::conditional<N == 2, v2f, float>::type;
+    constexpr int NU = PH / N;
 #pragma unroll
     for (int j0 = 0; j0 < VEC; j0 += PH) {
-      float x2[PH], y2[PH], iz[PH];
+      F x2[NU], y2[NU], iz[NU];
       unsigned long long okm[PH];  // validity as a wave mask (SGPR pair)
       uint32_t gidx[PH];
 #pragma unroll
-      for (int jj = 0; jj < PH; jj++) {
-        const int j = j0 + jj;
-        float z = 1.0f;
-        unsigned long long okin = active_mask;
-        if constexpr (DEPTH) {
-          const int d = (int)(int16_t)cur.dp[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
-          okin &= __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
-          z = (float)d * L.zscale;
+      for (int u = 0; u < NU; u++) {
+        F z = bc<F>(1.0f), xf;
+        unsigned long long okin[N];
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+          const int j = j0 + u * N + c;
+          okin[c] = active_mask;
+          if constexpr (DEPTH) {
+            const int d = (int)(int16_t)cur.dp[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
+            okin[c] &= __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
+            put(z, c, (float)d);
+          }
+          put(xf, c, (float)j);
         }
-        pixel_warp(L, K, xf0 + (float)j, yf, z, okin, x2[jj], y2[jj], iz[jj], okm[jj], gidx[jj]);
+        if constexpr (DEPTH) z = z * bc<F>(L.zscale);
+        xf = bc<F>(xf0) + xf;
+        pixel_warp<F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N], &gidx[u * N]);
       }
       int i2[PH];
       float s2[PH];
@@ -700,30 +766,37 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
         i2[jj] = (int)cur.i1[j0 + jj] + (int)(gidx[jj] & 1);
 #else
         if constexpr (SAMPLER == 0) i2[jj] = I2[gidx[jj]];   // nearest-neighbour gather of the target level (:472)
-        else s2[jj] = sample_bilinear(I2, L, x2[jj], y2[jj]);  // EXTENSION; x2 = y2 = 0 for sanitised invalid pixels
+        else s2[jj] = sample_bilinear(I2, L, get(x2[jj / N], jj % N), get(y2[jj / N], jj % N));  // EXTENSION; x2 = y2 = 0 for sanitised invalid pixels
 #endif
       }
-      float J[PH][6];
+      F J[NU][6];
 #pragma unroll
-      for (int jj = 0; jj < PH; jj++) {
-        const int j = j0 + jj;
-        const float g0 = keep_f((float)cur.gx[j], okm[jj]);
-        const float g1 = keep_f((float)cur.gy[j], okm[jj]);
-        pixel_jacobian<UNIT_FACTORS, SQUARE, DUMP>(L, a.zf, a.af, x2[jj], y2[jj], iz[jj], g0, g1, J[jj]);
+      for (int u = 0; u < NU; u++) {
+        F g0, g1;
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+          const int j = j0 + u * N + c;
+          put(g0, c, keep_f((float)cur.gx[j], okm[u * N + c]));
+          put(g1, c, keep_f((float)cur.gy[j], okm[u * N + c]));
+        }
+        pixel_jacobian<UNIT_FACTORS, SQUARE, DUMP, F>(L, a.zf, a.af, x2[u], y2[u], iz[u], g0, g1, J[u]);
       }
 #pragma unroll
       for (int jj = 0; jj < PH; jj++) {
         const int j = j0 + jj;
+        float Jp[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) Jp[k] = get(J[jj / N][k], jj % N);
         int ri = 0;
         if constexpr (!GENERAL) {
           ri = keep_i(i2[jj] - (int)cur.i1[j], okm[jj]);
-          accumulate(acc, J[jj], ri);
+          accumulate(acc, Jp, ri);
         } else {
           float rf;
           if constexpr (SAMPLER == 0) rf = (float)keep_i(i2[jj] - (int)cur.i1[j], okm[jj]);
           else rf = keep_f(s2[jj] - (float)cur.i1[j], okm[jj]);
           const float w = robust_weight(WEIGHTS, rf, inv_mad);
-          accumulate_weighted(acc, err, J[jj], rf, w, a.gain);
+          accumulate_weighted(acc, err, Jp, rf, w, a.gain);
           ri = (int)rintf(rf);
         }
         sum_r2 += (uint32_t)__mul24(ri, ri);  // |ri| <= 255
@@ -734,7 +807,7 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
             if (a.dumpV) a.dumpV[p] = lane_bit(okm[jj]) ? 1 : 0;
             if (a.dumpR) a.dumpR[p] = (float)ri;
             if (a.dumpJ)
-              for (int k = 0; k < 6; k++) a.dumpJ[p * 6 + k] = J[jj][k];
+              for (int k = 0; k < 6; k++) a.dumpJ[p * 6 + k] = Jp[k];
           }
         }
       }
@@ -796,7 +869,8 @@ __device__ __forceinline__ bool general_pixel(const LevelK& L, const WarpK& K, i
   uint32_t gidx;
   bool valid;
   unsigned long long okm;
-  pixel_warp(L, K, (float)x, (float)y, z, __builtin_amdgcn_ballot_w64(ok), x2, y2, iz, okm, gidx);
+  const unsigned long long okin = __builtin_amdgcn_ballot_w64(ok);
+  pixel_warp<float>(L, K, (float)x, (float)y, z, &okin, x2, y2, iz, &okm, &gidx);
   valid = lane_bit(okm);
   const int i1 = I1[idx];
   rf = sampler ? sample_bilinear(I2, L, x2, y2) - (float)i1 : (float)((int)I2[gidx] - i1);
@@ -879,7 +953,8 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
         z = (float)d * L.zscale;
       }
       unsigned long long okm;
-      pixel_warp(L, K, (float)x + (float)j, (float)y, z, __builtin_amdgcn_ballot_w64(okin), x2[j], y2[j], iz, okm, gidx[j]);
+      const unsigned long long okin_m = __builtin_amdgcn_ballot_w64(okin);
+      pixel_warp<float>(L, K, (float)x + (float)j, (float)y, z, &okin_m, x2[j], y2[j], iz, &okm, &gidx[j]);
       ok[j] = lane_bit(okm);
     }
     float rf[VEC];
