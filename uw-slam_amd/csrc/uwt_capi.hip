@@ -550,7 +550,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   if (const char* e = std::getenv("UWT_OVERLAP_GRAD")) c->overlap_gradients = std::atoi(e) != 0;
   for (int l = 0; l < p->n_levels; l++) {
     const size_t n = (size_t)c->lv[l].n * p->max_frames;
-    CREATE_CHK(hipMalloc((void**)&c->img[l], n));
+    CREATE_CHK(hipMalloc((void**)&c->img[l], n + 4096));
     CREATE_CHK(hipMalloc((void**)&c->gx[l], n * 2));
     CREATE_CHK(hipMalloc((void**)&c->gy[l], n * 2));
     if (p->has_depth) CREATE_CHK(hipMalloc((void**)&c->depth[l], n * 2));

@@ -701,10 +701,14 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   const int g_end = min(g_begin + a.groups_per_block, n_groups);
   const int iters = (g_end - g_begin + kBlock - 1) / kBlock;  // block-uniform trip count
 
-  // software pipeline: the reference planes of group it+1 are in flight while group it is processed
-  RefGroup<VEC> nxt;
+  // Software pipeline over groups.  `rg` holds the reference planes of the group being processed and is re-requested IN
+  // PLACE for the thread's next group as soon as its last value has been consumed — after this group's gathers have been
+  // issued, not before: vmcnt retires in order, so a wait for the gathered bytes would otherwise also wait for the plane
+  // loads requested ahead of them, which always come cold from HBM.  Only the reference intensities are copied out (they
+  // are needed last, for the residuals).
+  RefGroup<VEC> rg;
   int g = g_begin + (int)threadIdx.x;
-  load_group<VEC, DEPTH>(nxt, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
+  load_group<VEC, DEPTH>(rg, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
   // Pixel coordinates of the thread's group, as floats (small integers: exact).  One division up front, then each step
   // of kBlock groups moves (x, y) by the level's fixed (step mod w, step / w) with at most one wrap.  Lanes past the end
   // of the level run on with coordinates outside the image; they are inactive and every term of theirs is discarded.
@@ -713,102 +717,100 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   float yf = (float)y0, xf0 = (float)(idx0 - y0 * (uint32_t)L.w);
   const uint32_t step_y = __umulhi((uint32_t)(kBlock * VEC), L.magic);
   const float step_yf = (float)step_y, step_xf = (float)((uint32_t)(kBlock * VEC) - step_y * (uint32_t)L.w), wf = (float)L.w;
+  // Pixels are processed in units of N adjacent ones (N = 2: the packed-f32 form, see v2f above), all VEC pixels of the
+  // group in flight through four phases: warp + validity + gather index, gather, Jacobian, residual + accumulation.
+  constexpr int N = (VEC % 2 == 0) ? 2 : 1;
+  using F = typename std::conditional<N == 2, v2f, float>::type;
+  constexpr int NU = VEC / N;
   for (int it = 0; it < iters; it++, g += kBlock) {
     const bool active = g < g_end;
     const unsigned long long active_mask = __builtin_amdgcn_sicmp(g, g_end, kIcmpSLT);
     const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
-#ifdef UWT_EXP_NOPREFETCH
-    RefGroup<VEC> cur;
-    load_group<VEC, DEPTH>(cur, I1, GX, GY, DP, idx);
-#else
-    const RefGroup<VEC> cur = nxt;
-    if (it + 1 < iters) load_group<VEC, DEPTH>(nxt, I1, GX, GY, DP, (uint32_t)min(g + kBlock, n_groups - 1) * VEC);
-#endif
-#ifndef UWT_EXP_PHASE
-    constexpr int PH = VEC;   // pixels in flight per phase (warp -> gather -> Jacobian -> accumulate)
-#else
-    constexpr int PH = (UWT_EXP_PHASE < VEC) ? UWT_EXP_PHASE : VEC;
-#endif
-    // Pixels are processed in units of N adjacent ones (N = 2: the packed-f32 form, see v2f above), PH pixels in flight
-    // per phase (warp -> gather -> Jacobian -> accumulate).
-    constexpr int N = (VEC % 2 == 0) ? 2 : 1;
-    using F = typename std::conditional<N == 2, v2f, float>::type;
-    constexpr int NU = PH / N;
+    uint8_t i1[VEC];
 #pragma unroll
-    for (int j0 = 0; j0 < VEC; j0 += PH) {
-      F x2[NU], y2[NU], iz[NU];
-      unsigned long long okm[PH];  // validity as a wave mask (SGPR pair)
-      uint32_t gidx[PH];
+    for (int j = 0; j < VEC; j++) i1[j] = rg.i1[j];
+    // phase 1: warp, validity, gather index
+    F x2[NU], y2[NU], iz[NU];
+    unsigned long long okm[VEC];  // validity as a wave mask (SGPR pair)
+    uint32_t gidx[VEC];
 #pragma unroll
-      for (int u = 0; u < NU; u++) {
-        F z = bc<F>(1.0f), xf;
-        unsigned long long okin[N];
+    for (int u = 0; u < NU; u++) {
+      F z = bc<F>(1.0f), xf;
+      unsigned long long okin[N];
 #pragma unroll
-        for (int c = 0; c < N; c++) {
-          const int j = j0 + u * N + c;
-          okin[c] = active_mask;
-          if constexpr (DEPTH) {
-            const int d = (int)(int16_t)cur.dp[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
-            okin[c] &= __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
-            put(z, c, (float)d);
-          }
-          put(xf, c, (float)j);
+      for (int c = 0; c < N; c++) {
+        const int j = u * N + c;
+        okin[c] = active_mask;
+        if constexpr (DEPTH) {
+          const int d = (int)(int16_t)rg.dp[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
+          okin[c] &= __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
+          put(z, c, (float)d);
         }
-        if constexpr (DEPTH) z = z * bc<F>(L.zscale);
-        xf = bc<F>(xf0) + xf;
-        pixel_warp<F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N], &gidx[u * N]);
+        put(xf, c, (float)j);
       }
-      int i2[PH];
-      float s2[PH];
+      if constexpr (DEPTH) z = z * bc<F>(L.zscale);
+      xf = bc<F>(xf0) + xf;
+      pixel_warp<F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N], &gidx[u * N]);
+    }
+    // phase 2: the samples of the target level
+    int i2[VEC];
+    float s2[VEC];
 #pragma unroll
-      for (int jj = 0; jj < PH; jj++) {
+    for (int j = 0; j < VEC; j++) {
 #if defined(UWT_EXP_NOGATHER) || defined(UWT_EXP_NOMEM)
-        i2[jj] = (int)cur.i1[j0 + jj] + (int)(gidx[jj] & 1);
+      i2[j] = (int)i1[j] + (int)(gidx[j] & 1);
 #else
-        if constexpr (SAMPLER == 0) i2[jj] = I2[gidx[jj]];   // nearest-neighbour gather of the target level (:472)
-        else s2[jj] = sample_bilinear(I2, L, get(x2[jj / N], jj % N), get(y2[jj / N], jj % N));  // EXTENSION; x2 = y2 = 0 for sanitised invalid pixels
+      if constexpr (SAMPLER == 0) i2[j] = I2[gidx[j]];   // nearest-neighbour gather of the target level (:472)
+      else s2[j] = sample_bilinear(I2, L, get(x2[j / N], j % N), get(y2[j / N], j % N));  // EXTENSION; x2 = y2 = 0 for sanitised invalid pixels
 #endif
+    }
+    // the gradients leave rg here, so that it can be re-requested
+    F g0[NU], g1[NU];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      put(g0[j / N], j % N, keep_f((float)rg.gx[j], okm[j]));
+      put(g1[j / N], j % N, keep_f((float)rg.gy[j], okm[j]));
+    }
+    // The scheduling fences keep the requests where they are written: left alone the scheduler sinks them to the end of
+    // the body (shorter live ranges), and the residual subtractions — the first use of the gathered bytes — rise to just
+    // behind the gathers.  The request is unconditional (the index is clamped): inside a branch, the compiler's wait for
+    // the gathers would have to assume the branch not taken and count the plane loads in.
+    __builtin_amdgcn_sched_barrier(0);
+    load_group<VEC, DEPTH>(rg, I1, GX, GY, DP, (uint32_t)min(g + kBlock, n_groups - 1) * VEC);
+    __builtin_amdgcn_sched_barrier(0);
+    // phase 3: Jacobians (cover the gather latency)
+    F J[NU][6];
+#pragma unroll
+    for (int u = 0; u < NU; u++)
+      pixel_jacobian<UNIT_FACTORS, SQUARE, DUMP, F>(L, a.zf, a.af, x2[u], y2[u], iz[u], g0[u], g1[u], J[u]);
+    __builtin_amdgcn_sched_barrier(0);
+    // phase 4: residuals and accumulation
+#pragma unroll
+    for (int j = 0; j < VEC; j++) {
+      float Jp[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) Jp[k] = get(J[j / N][k], j % N);
+      int ri = 0;
+      if constexpr (!GENERAL) {
+        ri = keep_i(i2[j] - (int)i1[j], okm[j]);
+        accumulate(acc, Jp, ri);
+      } else {
+        float rf;
+        if constexpr (SAMPLER == 0) rf = (float)keep_i(i2[j] - (int)i1[j], okm[j]);
+        else rf = keep_f(s2[j] - (float)i1[j], okm[j]);
+        const float w = robust_weight(WEIGHTS, rf, inv_mad);
+        accumulate_weighted(acc, err, Jp, rf, w, a.gain);
+        ri = (int)rintf(rf);
       }
-      F J[NU][6];
-#pragma unroll
-      for (int u = 0; u < NU; u++) {
-        F g0, g1;
-#pragma unroll
-        for (int c = 0; c < N; c++) {
-          const int j = j0 + u * N + c;
-          put(g0, c, keep_f((float)cur.gx[j], okm[u * N + c]));
-          put(g1, c, keep_f((float)cur.gy[j], okm[u * N + c]));
-        }
-        pixel_jacobian<UNIT_FACTORS, SQUARE, DUMP, F>(L, a.zf, a.af, x2[u], y2[u], iz[u], g0, g1, J[u]);
-      }
-#pragma unroll
-      for (int jj = 0; jj < PH; jj++) {
-        const int j = j0 + jj;
-        float Jp[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) Jp[k] = get(J[jj / N][k], jj % N);
-        int ri = 0;
-        if constexpr (!GENERAL) {
-          ri = keep_i(i2[jj] - (int)cur.i1[j], okm[jj]);
-          accumulate(acc, Jp, ri);
-        } else {
-          float rf;
-          if constexpr (SAMPLER == 0) rf = (float)keep_i(i2[jj] - (int)cur.i1[j], okm[jj]);
-          else rf = keep_f(s2[jj] - (float)cur.i1[j], okm[jj]);
-          const float w = robust_weight(WEIGHTS, rf, inv_mad);
-          accumulate_weighted(acc, err, Jp, rf, w, a.gain);
-          ri = (int)rintf(rf);
-        }
-        sum_r2 += (uint32_t)__mul24(ri, ri);  // |ri| <= 255
-        n_valid_wave += (uint32_t)__builtin_popcountll(okm[jj]);  // scalar
-        if constexpr (DUMP) {
-          if (active) {
-            const size_t p = (size_t)pair * L.n + idx + j;
-            if (a.dumpV) a.dumpV[p] = lane_bit(okm[jj]) ? 1 : 0;
-            if (a.dumpR) a.dumpR[p] = (float)ri;
-            if (a.dumpJ)
-              for (int k = 0; k < 6; k++) a.dumpJ[p * 6 + k] = Jp[k];
-          }
+      sum_r2 += (uint32_t)__mul24(ri, ri);  // |ri| <= 255
+      n_valid_wave += (uint32_t)__builtin_popcountll(okm[j]);  // scalar
+      if constexpr (DUMP) {
+        if (active) {
+          const size_t p = (size_t)pair * L.n + idx + j;
+          if (a.dumpV) a.dumpV[p] = lane_bit(okm[j]) ? 1 : 0;
+          if (a.dumpR) a.dumpR[p] = (float)ri;
+          if (a.dumpJ)
+            for (int k = 0; k < 6; k++) a.dumpJ[p * 6 + k] = Jp[k];
         }
       }
     }
