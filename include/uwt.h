@@ -117,6 +117,16 @@ int uwt_set_frame(uwt_ctx* ctx, int32_t slot, const uint8_t* gray, size_t row_st
                   const uint16_t* depth_or_null, size_t depth_row_stride);
 /* n tightly packed frames (w*h elements each) into slots first_slot .. first_slot+n-1 */
 int uwt_upload_frames(uwt_ctx* ctx, int32_t first_slot, int32_t n, const uint8_t* gray, const uint16_t* depth_or_null);
+/* The same copy, asynchronous, on the context's copy stream: the per-frame ingest of System::AddFrame
+ * (src/System.cpp:225-251) overlapped with the tracking of the frames already on the device.  `gray` / `depth` must be
+ * page-locked (uwt_host_alloc) and stay untouched until a later uwt_sync, or until the tracker call that consumes these
+ * slots has been followed by a uwt_sync.  The context orders the copy behind the tracker work still in flight on the
+ * same slots and every later tracker call on these slots behind the copy; nothing else waits.  depth may be null even
+ * on a context with a depth plane (the tracker reads depth of reference frames only, src/Tracker.cpp:1266-1272). */
+int uwt_upload_frames_async(uwt_ctx* ctx, int32_t first_slot, int32_t n, const uint8_t* gray, const uint16_t* depth_or_null);
+/* page-locked host memory for uwt_upload_frames_async (hipHostMalloc / hipHostFree) */
+int uwt_host_alloc(size_t bytes, void** out);
+int uwt_host_free(void* p);
 /* device pointer of a plane of a slot (so a producer can write level-0 frames in place, inputs resident in HBM) */
 int uwt_plane_device_ptr(uwt_ctx* ctx, int32_t slot, int32_t lvl, int32_t plane, void** out);
 /* copy one plane of one slot back to the host (tight rows) */
@@ -145,13 +155,28 @@ int uwt_estimate_pose_batch(uwt_ctx* ctx, int32_t n_pairs, const int32_t* ref_sl
 int uwt_track_batch_async(uwt_ctx* ctx, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only,
                           int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
                           float* d_poses_out, uwt_stats* d_stats_out_or_null);
+/* The same call with the results copied behind it into host buffers (page-locked: uwt_host_alloc) and a ticket to wait
+ * on: the streaming form — while this batch is aligned the caller uploads the next one into other slots
+ * (uwt_upload_frames_async) and only waits for the batch before. */
+int uwt_track_batch_host_async(uwt_ctx* ctx, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only,
+                               int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
+                               float* h_poses_out, uwt_stats* h_stats_out_or_null, int64_t* ticket_out);
+/* blocks until the call that returned `ticket` (and its result copy) has completed; later calls keep running */
+int uwt_wait_ticket(uwt_ctx* ctx, int64_t ticket);
 int uwt_sync(uwt_ctx* ctx);
 /* the HIP stream (hipStream_t) the context launches on, for event timing by the caller */
 int uwt_stream(uwt_ctx* ctx, void** out);
 /* average device time in ms of the residual/Jacobian/reduction kernel launches and their count since the last
- * reset (HIP events on the context stream; only recorded while profiling is enabled) */
+ * reset (HIP events on the context stream; only recorded while profiling is enabled).
+ * `on` is a bit mask: 1 = record the events; 2 (diagnostic) = the dense residual launches run their compute-only twin —
+ * the same instruction stream with every memory operation of the loop replaced by register arithmetic.  Poses computed
+ * with bit 2 set are meaningless; the launch durations are the kernel's own instruction-issue floor (bench.py's
+ * roofline.valu).  0 switches both off. */
 int uwt_profile_enable(uwt_ctx* ctx, int32_t on);
 int uwt_profile_read(uwt_ctx* ctx, double* residual_ms_total, int64_t* residual_launches, int64_t* residual_pixels);
+/* Shader clock (GHz) the chip held inside the last profiled k_residual launch: blocks of a profiled launch leave their
+ * s_memtime (shader cycles) and s_memrealtime (100 MHz) deltas in their records.  Diagnostic; synchronises. */
+int uwt_profile_clock(uwt_ctx* ctx, double* shader_ghz);
 
 /* ---- per-stage entry points (each kernel parity-testable alone; host buffers, synchronous) ------------------ */
 

@@ -1,0 +1,196 @@
+"""GPU tests at BASELINE.json's sizes, through the instantiations and launch paths the bench times:
+
+* the production residual kernel (VEC = 4, packed pairs, SQUARE shortcut, f64 accumulation, no per-pixel dumps) checked
+  per term: A, J^T r, sum r^2 and N of every level, bitwise after the single f32 rounding, against the oracle's sequential
+  f64 sums — 640x480 / 4 levels and 1280x960 / 5 levels, depth plane present;
+* BASELINE config 3 as stated: 1280x960, 5 levels, depth, 256 resident pairs;
+* robust weights (Tukey, Huber) and the bilinear sampler at 640x480 with depth (BASELINE config 5's shape);
+* the multi-process launch paths of bench.py on a one-GPU box: RCCL with a world of one, a refused --gpus 2, strong scaling.
+"""
+import importlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TUM = (525.0, 525.0, 319.5, 239.5)
+BIG = (1050.0, 1050.0, 639.5, 479.5)
+
+
+@pytest.fixture(scope="module")
+def capi():
+    m = importlib.import_module("uw-slam_amd.capi")
+    m.lib()  # raises if libuwt_hip.so is missing: no fallback
+    return m
+
+
+def _track_batch(ctx, n_frames, ref_s, tgt_s):
+    """The bench's launch path: uwt_track_batch_async (pyramids, reference-only gradients, alignment) into device memory."""
+    import torch
+    n = len(ref_s)
+    d_poses = torch.zeros((n, 7), dtype=torch.float32, device="cuda")
+    d_stats = torch.zeros((n, 4), dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()  # torch's fill kernels run on torch's stream, not on the context's
+    ctx.track_batch_async(0, n_frames, ref_s, tgt_s, d_poses.data_ptr(), d_stats.data_ptr(), grad_refs_only=True)
+    ctx.sync()
+    st = d_stats.cpu().numpy()
+    stats = [dict(status=int(r[0]), iterations=int(r[1]), n_valid=int(r[2])) for r in st]
+    return d_poses.cpu().numpy(), stats
+
+
+def _upload_pair(ctx, ref, tgt, dep):
+    ctx.upload_frames(0, np.stack([ref, tgt]), np.stack([dep, dep]))
+    ctx.build_pyramids(0, 2)
+    ctx.apply_gradient(0, 2)
+
+
+@pytest.mark.parametrize("shape", ["640x480x4", "1280x960x5"])
+def test_production_instantiation_sums_bitwise_per_level(capi, O, synth, shape):
+    w, h, levels = (640, 480, 4) if shape.startswith("640") else (1280, 960, 5)
+    intr = TUM if w == 640 else BIG
+    over = dict(n_levels=levels, first_level=levels - 1, last_level=0, max_iters=10, early_exit=0, has_depth=1)
+    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, **over))
+    ref, tgt, dep, _, _ = synth.render_pair(w, h, *intr, seed=1200 + w, z=0.9, with_depth=True)
+    _upload_pair(ctx, ref, tgt, dep)
+    p = O.default_params(w, h, *intr, **over)
+    rng = np.random.default_rng(w)
+    a_img, b_img, dp = ref, tgt, dep
+    for lvl in range(levels):
+        if lvl:
+            a_img, b_img, dp = O.halve_u8(a_img), O.halve_u8(b_img), O.halve_u16(dp)
+        L = O.level_intrinsics(p, lvl)
+        gx, gy = O.scharr3(a_img)
+        pts = O.dense_points(dp, L.w, L.h, lvl)
+        for k in range(2):   # identity (the first evaluation of every alignment) and a small random motion
+            xi = np.zeros(6, np.float32) if k == 0 else (rng.normal(0, 1, 6) * [0.01, 0.01, 0.005, 0.003, 0.003, 0.005]).astype(np.float32)
+            pose = O.se3_exp(xi)
+            wp = O.warp(pts, pose, L)
+            J, r, idx = O.residual_jacobian(a_img, b_img, gx, gy, pts, wp, L, p.z_factor, p.angle_factor)
+            A_ref, b_ref = O.normal_equations(J, r, None, 1.0)       # sequential f64 sums, rounded to f32 once
+            out = ctx.residual_jacobian(0, 1, lvl, pose, dump=False)  # the instantiation the alignment loop launches
+            assert out["n_valid"] == len(idx) and 0 < len(idx) <= L.w * L.h
+            assert k == 0 or lvl > 1 or len(idx) < L.w * L.h   # the moved pose leaves part of the finer levels outside
+            assert out["sum_r2"] == int((r.astype(np.int64) ** 2).sum())
+            assert np.array_equal(out["A"].astype(np.float32).view(np.uint32), A_ref.view(np.uint32)), (lvl, k)
+            assert np.array_equal((-out["jtr"]).astype(np.float32).view(np.uint32), b_ref.view(np.uint32)), (lvl, k)
+            # and the dump-capable twin (scalar Jacobian form, signed zeros kept) agrees with it per pixel and in the sums
+            full = ctx.residual_jacobian(0, 1, lvl, pose, dump=True)
+            valid = np.zeros(L.w * L.h, np.uint8)
+            valid[idx] = 1
+            assert np.array_equal(full["valid"], valid)
+            assert np.array_equal(full["r"][idx], r)
+            assert np.array_equal(full["J"][idx].view(np.uint32), J.view(np.uint32))
+            assert np.array_equal(full["A"].astype(np.float32), A_ref) and full["n_valid"] == out["n_valid"]
+    ctx.close()
+
+
+def test_config3_1280x960_5_levels_256_resident_pairs_with_depth(capi, O, synth):
+    """BASELINE config 3: synthetic 1280x960 random-texture pairs, 5 pyramid levels, batch = 256 resident."""
+    w, h, n, distinct = 1280, 960, 256, 4
+    over = dict(n_levels=5, first_level=4, last_level=0, max_iters=10, early_exit=0, has_depth=1)
+    ctx = capi.Context(capi.default_params(w, h, *BIG, max_frames=2 * n, max_pairs=n, **over))
+    pairs = [synth.render_pair(w, h, *BIG, seed=3000 + s, z=0.85 + 0.1 * s, with_depth=True)[:3] for s in range(distinct)]
+    for i in range(n):     # slot 2i = reference, 2i + 1 = target; uploaded pair by pair (the host never holds the batch)
+        ref, tgt, dep = pairs[i % distinct]
+        ctx.upload_frames(2 * i, np.stack([ref, tgt]), np.stack([dep, dep]))
+    ref_s = np.arange(n, dtype=np.int32) * 2
+    poses, stats = _track_batch(ctx, 2 * n, ref_s, ref_s + 1)
+    assert all(s["status"] == 0 and s["iterations"] == 50 for s in stats)
+    for i in range(distinct, n):   # every tiled copy bit-identical to its original
+        assert np.array_equal(poses[i].view(np.uint32), poses[i % distinct].view(np.uint32)), i
+    po = O.default_params(w, h, *BIG, **over)
+    for s in range(distinct):
+        st, pose_cpu, _ = O.align_pair(po, pairs[s][0], pairs[s][1], pairs[s][2])
+        assert st == 0
+        assert np.array_equal(poses[s].view(np.uint32), pose_cpu.view(np.uint32)), (s, poses[s], pose_cpu)
+    ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["tukey", "huber", "bilinear_huber"])
+def test_robust_weights_at_640x480_with_depth(capi, O, synth, mode):
+    """BASELINE config 5's shape (640x480 + robust weighting), synthetic stand-in for the TUM sequence."""
+    w, h = 640, 480
+    over = dict(n_levels=4, first_level=3, last_level=0, max_iters=10, early_exit=0, has_depth=1)
+    over.update(dict(tukey=dict(weights=1), huber=dict(weights=2), bilinear_huber=dict(sampler=1, weights=2))[mode])
+    n = 3
+    ctx = capi.Context(capi.default_params(w, h, *TUM, max_frames=2 * n, max_pairs=n, **over))
+    pairs = [synth.render_pair(w, h, *TUM, seed=4100 + s, z=0.9 + 0.1 * s, with_depth=True)[:3] for s in range(n)]
+    for i, (ref, tgt, dep) in enumerate(pairs):
+        ctx.upload_frames(2 * i, np.stack([ref, tgt]), np.stack([dep, dep]))
+    ref_s = np.arange(n, dtype=np.int32) * 2
+    poses, stats = _track_batch(ctx, 2 * n, ref_s, ref_s + 1)
+    po = O.default_params(w, h, *TUM, **over)
+    for s in range(n):
+        st, pose_cpu, _ = O.align_pair(po, *pairs[s])
+        assert st == 0 and stats[s]["status"] == 0
+        assert np.array_equal(poses[s].view(np.uint32), pose_cpu.view(np.uint32)), (mode, s, poses[s], pose_cpu)
+    ctx.close()
+
+
+# ------------------------------------------------------------------ launch paths of bench.py
+
+def _run(cmd, extra_env=None, timeout=540):
+    env = dict(os.environ)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(extra_env or {})
+    return subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+
+
+SMALL_BENCH = ["--width", "160", "--height", "96", "--steps", "2", "--warmup", "1", "--unique", "4", "--cpu-pairs", "0"]
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    import torch
+    have = torch.cuda.device_count()
+    r = _run([sys.executable, "bench.py", "--gpus", str(have + 1), "--pairs", "8"] + SMALL_BENCH)
+    assert r.returncode != 0 and not r.stdout.strip()
+    assert b"GPU(s) visible" in r.stderr
+
+
+def test_bench_strong_scaling_mode_single_gpu():
+    r = _run([sys.executable, "bench.py", "--gpus", "1", "--total-pairs", "24"] + SMALL_BENCH)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["total_pairs"] == 24
+    assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["valu"]["valu_issue_frac"] <= 1.05
+    assert d["roofline"]["valu"]["shader_clock_GHz"] > 0.5
+
+
+def test_bench_rccl_world_of_one_gathers_on_the_context_stream():
+    """Under a launcher (RANK set) the RCCL path runs even with one rank: nccl process group, all_gather and the
+    permutation to global order enqueued on the context's stream, the gathered tensor checked on rank 0."""
+    r = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+              "--master-port", "29611", "bench.py", "--gpus", "1", "--pairs", "12"] + SMALL_BENCH)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and "RCCL" in d["config"]["sharding"]
+
+
+def test_pose_gatherer_nccl_world_one_in_process_stream_order():
+    """PoseGatherer with the nccl backend (world 1) on a side stream behind a kernel that writes the poses."""
+    code = r'''
+import os, importlib, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29612", RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)
+d = importlib.import_module("uw-slam_amd.dist")
+g = d.PoseGatherer(37, dev)
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    local = torch.arange(37 * 7, dtype=torch.float32, device=dev).reshape(37, 7) * 2.0
+    out = g.gather(local)
+s.synchronize()
+assert torch.equal(out, local)
+dist.destroy_process_group()
+print("ok")
+'''
+    r = _run([sys.executable, "-c", code])
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]

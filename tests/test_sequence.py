@@ -66,3 +66,28 @@ def test_sequence_tracking_equals_pairwise_and_oracle(tmp_path, synth, O):
     est, _ = T.read_reference_csv(tmp_path / "out.csv")
     assert np.allclose(est, ref)
     trk.close()
+
+
+@pytest.mark.gpu
+def test_streaming_many_chunks_every_pair_against_the_oracle(synth, O):
+    """More chunks than the context's dependency rings hold (8): slot ranges and staging blocks are reused many times while
+    copies and alignments overlap; every pose must still be the oracle's."""
+    S = importlib.import_module("uw-slam_amd.sequence")
+    w, h, n = 160, 96, 90
+    intr = (131.25, 131.25, 79.5, 47.5)
+    base = synth.texture(w + 2 * n + 8, h + n // 2 + 8, seed=11)
+    frames = [np.ascontiguousarray(base[4 + i // 2: 4 + i // 2 + h, 2 * i: 2 * i + w]) for i in range(n)]
+    depths = [np.full((h, w), 4000 + 25 * i, np.uint16) for i in range(n)]
+    for d in depths:
+        d[::7, ::5] = 0                                             # invalid-depth holes
+    trk = S.SequenceTracker(w, h, *intr, depth=True, chunk=4)        # 89 pairs: 22 chunks of 4 and one of 1
+    poses, stats = trk.track(frames, depths)
+    again, _ = trk.track(frames, depths)                             # the same context, ranges dirty from the first pass
+    assert np.array_equal(poses.view(np.uint32), again.view(np.uint32))
+    p = O.default_params(w, h, *intr, has_depth=1)
+    for i in range(n - 1):
+        st, pose_cpu, _ = O.align_pair(p, frames[i], frames[i + 1], depths[i])
+        assert st == stats[i]["status"]
+        if st == 0:
+            assert np.array_equal(poses[i].view(np.uint32), pose_cpu.view(np.uint32)), i
+    trk.close()

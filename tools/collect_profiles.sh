@@ -1,0 +1,37 @@
+#!/bin/bash
+# Collect the round's profiles on the GPU box (run from the repo root through gpurun):
+#   tools/collect_profiles.sh <out dir under gpurun_out>
+# kernel-trace statistics and the bench line of the default workload and of the other quoted configurations, HBM
+# traffic counters (separate --pmc passes, never together with other trace domains), SQ counters of the residual kernel.
+set -u
+R=$(pwd)
+out=$R/gpurun_out/${1:-prof_r02}
+mkdir -p $out
+cd /tmp && export TMPDIR=/tmp
+stats() {  # name, bench args...
+  name=$1; shift
+  (cd $R && rocprofv3 --kernel-trace --stats -d $out/stats_$name --output-format csv -- python3 bench.py "$@" > $out/bench_$name.json 2> $out/bench_$name.err)
+}
+stats default_p1024
+stats cfg3_1280x960_l5_p256 --width 1280 --height 960 --levels 5 --pairs 256 --cpu-pairs 8 --unique 8
+stats refsched_p1024 --reference-schedule --cpu-pairs 32
+stats tukey_p256 --weights tukey --pairs 256 --cpu-pairs 8 --unique 8
+stats huber_p256 --weights huber --pairs 256 --cpu-pairs 8 --unique 8
+stats bilinear_p256 --bilinear --pairs 256 --cpu-pairs 8 --unique 8
+stats nodepth_p1024 --no-depth --cpu-pairs 16
+for c in FETCH_SIZE WRITE_SIZE; do
+  (cd $R && rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c --output-format csv -- python3 bench.py --cpu-pairs 0 --steps 2 --warmup 1 --no-profile > $out/pmc_$c.log 2>&1)
+done
+i=0
+for set in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_VALU" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY" "SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU_FMA_F64" "GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES SQ_IFETCH SQ_INSTS_BRANCH"; do
+  i=$((i+1))
+  (cd $R && rocprofv3 --kernel-trace --pmc $set -d $out/sq/pass$i --output-format csv -- python3 bench.py --levels 1 --steps 1 --warmup 1 --cpu-pairs 0 --no-profile > $out/sq_pass$i.log 2>&1)
+done
+cd $R
+python3 tools/pmc_summary.py $out/pmc_FETCH_SIZE $out/pmc_fetch.csv
+python3 tools/pmc_summary.py $out/pmc_WRITE_SIZE $out/pmc_write.csv
+python3 tools/sq_summary.py $out/sq k_residual $((1024*640*480)) $out/sq_counters_k_residual_level0_p1024.csv
+# keep what travels back small: the statistics tables, not the raw traces
+find $out -name "*kernel_trace.csv" -size +20M -delete
+find $out -name "*counter_collection.csv" -size +20M -delete
+du -sh $out

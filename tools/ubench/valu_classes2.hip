@@ -6,8 +6,9 @@
 constexpr int ITERS = 1024;
 #define REP8(x) x x x x x x x x
 #define KERNEL(name, body)                                                             \
-  __global__ __launch_bounds__(256) void name(float* out, float seed, int si) {        \
+  __global__ __launch_bounds__(256) void name(float* out, float seed, int si, unsigned long long* clk) { \
     __shared__ float4 lds4[256];                                                        \
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();                         \
     lds4[threadIdx.x] = make_float4(seed, seed + 1, seed + 2, seed + 3);                \
     __syncthreads();                                                                    \
     const unsigned lds_addr = (threadIdx.x & 63) * 16;                                  \
@@ -18,6 +19,7 @@ constexpr int ITERS = 1024;
     int ia = (int)a, ib = (int)b, ic = threadIdx.x * 3, id = threadIdx.x * 7;           \
     double sseed = __builtin_bit_cast(double, ((unsigned long long)__float_as_uint(seed) << 32) | __float_as_uint(seed)); \
     for (int it = 0; it < ITERS; it++) { REP8(body) }                                   \
+    if ((threadIdx.x & 63) == 0) clk[blockIdx.x * 4 + (threadIdx.x >> 6)] = __builtin_amdgcn_s_memtime() - t0; \
     out[blockIdx.x * 256 + threadIdx.x] = a + b + c + d + e + f + g + h + (float)(da + db + dc + dd) + ia + ib + ic + id + q0.x + q1.y + (float)sseed + lds_addr; \
   }
 // reference points
@@ -60,19 +62,38 @@ KERNEL(k_fma_only4, asm volatile("v_fmac_f32 %0, %4, %0\n v_fmac_f32 %1, %4, %1\
 KERNEL(k_ds_only, asm volatile("ds_read_b128 %0, %2\n ds_read_b128 %1, %2\n ds_read_b128 %0, %2\n ds_read_b128 %1, %2\n s_waitcnt lgkmcnt(0)" : "=&v"(q0), "=&v"(q1) : "v"(lds_addr));)
 // mixes as in the kernel: 1 f64 fma + 2 f32 (all-vgpr) ; 1 cndmask + 2 f32
 KERNEL(k_mix_f64_2f32, asm volatile("v_fmac_f64 %4, %6, %7\n v_fmac_f32 %0, %8, %0\n v_fmac_f32 %1, %8, %1\n v_fmac_f64 %5, %6, %7\n v_fmac_f32 %2, %8, %2\n v_fmac_f32 %3, %8, %3" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(da), "+v"(db) : "v"(dc), "v"(dd), "v"(e));)
+// the remaining instruction forms of k_residual's loop (as in valu_classes.hip), so that one table covers the kernel
+KERNEL(k_cmp_sgpr, asm volatile("v_cmp_lt_f32_e64 s[20:21], %0, %1\n v_cmp_lt_f32_e64 s[22:23], %2, %3\n v_cmp_lt_f32_e64 s[20:21], %1, %2\n v_cmp_lt_f32_e64 s[22:23], %3, %0" : : "v"(a), "v"(b), "v"(c), "v"(d) : "s20", "s21", "s22", "s23");)
+KERNEL(k_cndmask, asm volatile("s_mov_b64 s[20:21], 0x5555\n v_cndmask_b32_e64 %0, 0, %0, s[20:21]\n v_cndmask_b32_e64 %1, 0, %1, s[20:21]\n v_cndmask_b32_e64 %2, 0, %2, s[20:21]\n v_cndmask_b32_e64 %3, 0, %3, s[20:21]" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "s20", "s21");)
+KERNEL(k_cvt_sdwa, asm volatile("v_cvt_f32_i32_sdwa %0, sext(%4) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_i32_sdwa %1, sext(%4) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1\n v_cvt_f32_i32_sdwa %2, sext(%5) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0\n v_cvt_f32_i32_sdwa %3, sext(%5) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(a), "=v"(b), "=v"(c), "=v"(d) : "v"(ia), "v"(ib));)
+KERNEL(k_sub_sdwa, asm volatile("v_sub_u32_sdwa %0, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0\n v_sub_u32_sdwa %1, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1\n v_sub_u32_sdwa %2, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2\n v_sub_u32_sdwa %3, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(ia), "=v"(ib), "=v"(ic), "=v"(id) : "v"(ia), "v"(ib));)
+KERNEL(k_mad24, asm volatile("v_mad_u32_u24 %0, %0, %4, %1\n v_mad_u32_u24 %1, %1, %4, %2\n v_mad_u32_u24 %2, %2, %4, %3\n v_mad_u32_u24 %3, %3, %4, %0" : "+v"(ia), "+v"(ib), "+v"(ic), "+v"(id) : "s"(si));)
+KERNEL(k_mul_i24, asm volatile("v_mul_i32_i24 %0, %0, %1\n v_mul_i32_i24 %1, %1, %2\n v_mul_i32_i24 %2, %2, %3\n v_mul_i32_i24 %3, %3, %0" : "+v"(ia), "+v"(ib), "+v"(ic), "+v"(id));)
+KERNEL(k_min_i32, asm volatile("v_min_i32 %0, %4, %0\n v_min_i32 %1, %4, %1\n v_min_i32 %2, %4, %2\n v_min_i32 %3, %4, %3" : "+v"(ia), "+v"(ib), "+v"(ic), "+v"(id) : "s"(si));)
+KERNEL(k_cvt_rpi, asm volatile("v_cvt_rpi_i32_f32 %0, %4\n v_cvt_rpi_i32_f32 %1, %5\n v_cvt_rpi_i32_f32 %2, %6\n v_cvt_rpi_i32_f32 %3, %7" : "=v"(ia), "=v"(ib), "=v"(ic), "=v"(id) : "v"(a), "v"(b), "v"(c), "v"(d));)
+KERNEL(k_cvt_f64_i32, asm volatile("v_cvt_f64_i32 %0, %4\n v_cvt_f64_i32 %1, %5\n v_cvt_f64_i32 %2, %6\n v_cvt_f64_i32 %3, %7" : "=v"(da), "=v"(db), "=v"(dc), "=v"(dd) : "v"(ia), "v"(ib), "v"(ic), "v"(id));)
+KERNEL(k_rcp, asm volatile("v_rcp_f32 %0, %4\n v_rcp_f32 %1, %5\n v_rcp_f32 %2, %6\n v_rcp_f32 %3, %7" : "=v"(e), "=v"(f), "=v"(g), "=v"(h) : "v"(a), "v"(b), "v"(c), "v"(d));)
+KERNEL(k_mov64, asm volatile("v_mov_b64 %0, %4\n v_mov_b64 %1, %4\n v_mov_b64 %2, %4\n v_mov_b64 %3, %4" : "=v"(da), "=v"(db), "=v"(dc), "=v"(dd) : "v"(sseed));)
 template <typename K> void run(const char* name, K kern, int per_body) {
   printf("%-26s ", name); fflush(stdout);
   float* out; (void)hipMalloc(&out, 256 * 4096 * 4);
+  unsigned long long* clk; (void)hipMalloc(&clk, 256 * 8 * 4 * 8);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   const int blocks = 256 * 8;  // 8 blocks per CU = 8 waves per SIMD resident
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 1.5f, 3);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 1.5f, 3, clk);
   (void)hipEventRecord(e0);
-  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 1.5f, 3);
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), 0, 0, out, 1.5f, 3, clk);
   (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
   float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+  static unsigned long long h[256 * 8 * 4];
+  (void)hipMemcpy(h, clk, sizeof(h), hipMemcpyDeviceToHost);
+  double mean = 0; for (auto v : h) mean += (double)v; mean /= (256 * 8 * 4);
   const double instr_per_simd = (double)blocks / 256 * ITERS * 8 * per_body;
-  printf("%.3f ms  %.2f cycles(@2.4GHz)/instr/SIMD\n", ms, ms * 1e-3 * 2.4e9 / instr_per_simd); fflush(stdout);
-  (void)hipFree(out);
+  // s_memtime ticks at the shader clock: a wave's own start-to-end delta while 8 waves share its SIMD, over the
+  // instructions the 8 of them issue = true issue cycles per instruction, whatever clock the chip holds
+  printf("%.3f ms  %.2f cycles(@2.4GHz nominal)  %.2f shader cycles/instr/SIMD (s_memtime)  [clock ~%.2f GHz]\n", ms,
+         ms * 1e-3 * 2.4e9 / instr_per_simd, mean / (8.0 * ITERS * 8 * per_body), mean / (ms * 1e-3) / 1e9); fflush(stdout);
+  (void)hipFree(out); (void)hipFree(clk);
 }
 int main() {
   run("v_mul_f32 vgpr", k_mul_vgpr, 4); run("v_mul_f32 sgpr", k_mul_sgpr, 4);
@@ -88,5 +109,8 @@ int main() {
   run("v_fmac_f64", k_fma64, 4); run("v_mul_f64", k_mul64, 4); run("v_add_f64", k_add64, 4); run("v_cvt_f64_f32", k_cvt_f64_f32, 4);
   run("4 fmac + ds_read_b128 (/5)", k_fma_plus_ds, 5); run("4 fmac alone", k_fma_only4, 4); run("ds_read_b128 x4", k_ds_only, 4);
   run("2 f64 + 4 f32 mix (/6)", k_mix_f64_2f32, 6);
+  run("v_cmp_lt_f32_e64 -> sgpr", k_cmp_sgpr, 4); run("v_cndmask_b32_e64 (sgpr)", k_cndmask, 4); run("v_cvt_f32_i32_sdwa", k_cvt_sdwa, 4);
+  run("v_sub_u32_sdwa", k_sub_sdwa, 4); run("v_mad_u32_u24", k_mad24, 4); run("v_mul_i32_i24", k_mul_i24, 4); run("v_min_i32", k_min_i32, 4);
+  run("v_cvt_rpi_i32_f32", k_cvt_rpi, 4); run("v_cvt_f64_i32", k_cvt_f64_i32, 4); run("v_rcp_f32", k_rcp, 4); run("v_mov_b64", k_mov64, 4);
   return 0;
 }

@@ -44,9 +44,9 @@ class Accum(C.Structure):
 # every symbol include/uwt.h declares (tests check the library exports all of them)
 SYMBOLS = [
     "uwt_abi_version", "uwt_status_string", "uwt_last_error", "uwt_default_params", "uwt_create", "uwt_destroy",
-    "uwt_level_info", "uwt_set_frame", "uwt_upload_frames", "uwt_plane_device_ptr", "uwt_get_plane",
-    "uwt_build_pyramids", "uwt_apply_gradient", "uwt_estimate_pose_batch", "uwt_track_batch_async", "uwt_sync",
-    "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
+    "uwt_level_info", "uwt_set_frame", "uwt_upload_frames", "uwt_upload_frames_async", "uwt_host_alloc", "uwt_host_free", "uwt_plane_device_ptr", "uwt_get_plane",
+    "uwt_build_pyramids", "uwt_apply_gradient", "uwt_estimate_pose_batch", "uwt_track_batch_async", "uwt_track_batch_host_async", "uwt_wait_ticket", "uwt_sync",
+    "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_profile_clock", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
     "uwt_warp", "uwt_residual_jacobian", "uwt_ls_accumulate", "uwt_se3_exp", "uwt_se3_mul", "uwt_se3_matrix",
     "uwt_se3_handoff", "uwt_solve_delta", "uwt_accumulate_trajectory",
     "uwt_residual_jacobian_weighted", "uwt_estimate_pose_points", "uwt_gradient_magnitude",
@@ -108,6 +108,45 @@ def default_params(width, height, fx, fy, cx, cy, **over):
             raise AttributeError(k)
         setattr(p, k, v)
     return p
+
+
+class _Pinned:
+    """Owner of one uwt_host_alloc block; the numpy view below keeps it alive."""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        st = lib().uwt_host_alloc(C.c_size_t(nbytes), C.byref(self.ptr))
+        if st:
+            raise UwtError(st, "uwt_host_alloc(%d)" % nbytes)
+
+    def __del__(self):
+        try:
+            lib().uwt_host_free(self.ptr)
+        except Exception:
+            pass
+
+
+class _PinnedArray(np.ndarray):
+    """ndarray view that keeps its page-locked block alive (views and slices inherit the reference)."""
+
+    def __new__(cls, arr, owner):
+        obj = arr.view(cls)
+        obj._owner = owner
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._owner = getattr(obj, "_owner", None)
+
+
+def pinned_empty(shape, dtype):
+    """Page-locked numpy array (hipHostMalloc through the C ABI) for upload_frames_async."""
+    dtype = np.dtype(dtype)
+    count = int(np.prod(shape))
+    nbytes = max(count * dtype.itemsize, 1)
+    owner = _Pinned(nbytes)
+    buf = (C.c_uint8 * nbytes).from_address(owner.ptr.value)
+    arr = np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+    return _PinnedArray(arr, owner)
 
 
 class Context:
@@ -175,6 +214,14 @@ class Context:
             dp = _p(depth, C.c_uint16)
         self._chk(lib().uwt_upload_frames(self._h, first_slot, n, _p(gray, C.c_uint8), dp))
 
+    def upload_frames_async(self, first_slot, gray, depth=None):
+        """gray / depth: page-locked arrays (pinned_empty) that stay untouched until the next sync()."""
+        assert gray.flags["C_CONTIGUOUS"] and gray.dtype == np.uint8
+        if depth is not None:
+            assert depth.flags["C_CONTIGUOUS"] and depth.dtype == np.uint16
+        self._chk(lib().uwt_upload_frames_async(self._h, first_slot, gray.shape[0], _p(gray, C.c_uint8),
+                                                _p(depth, C.c_uint16) if depth is not None else None))
+
     def plane_device_ptr(self, slot, lvl, plane):
         out = C.c_void_p()
         self._chk(lib().uwt_plane_device_ptr(self._h, slot, lvl, plane, C.byref(out)))
@@ -211,6 +258,20 @@ class Context:
                                               _p(tgt, C.c_int32), C.c_void_p(d_poses_ptr),
                                               C.c_void_p(d_stats_ptr) if d_stats_ptr else None))
 
+    def track_batch_host_async(self, first_slot, n_frames, ref_slots, tgt_slots, h_poses, h_stats=None, grad_refs_only=True):
+        """h_poses: pinned float32 [n, 7]; h_stats: pinned int32 [n, 4] or None.  Returns the ticket for wait_ticket()."""
+        ref = np.ascontiguousarray(ref_slots, np.int32)
+        tgt = np.ascontiguousarray(tgt_slots, np.int32)
+        t = C.c_int64()
+        self._chk(lib().uwt_track_batch_host_async(self._h, first_slot, n_frames, int(grad_refs_only), ref.size, _p(ref, C.c_int32),
+                                                   _p(tgt, C.c_int32), _p(h_poses, C.c_float),
+                                                   h_stats.ctypes.data_as(C.c_void_p) if h_stats is not None else None,
+                                                   C.byref(t)))
+        return t.value
+
+    def wait_ticket(self, ticket):
+        self._chk(lib().uwt_wait_ticket(self._h, C.c_int64(ticket)))
+
     def sync(self):
         self._chk(lib().uwt_sync(self._h))
 
@@ -226,6 +287,12 @@ class Context:
         ms, n, px = C.c_double(), C.c_int64(), C.c_int64()
         self._chk(lib().uwt_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(px)))
         return ms.value, n.value, px.value
+
+    def profile_clock(self):
+        """Shader clock (GHz) inside the last profiled residual launch."""
+        ghz = C.c_double()
+        self._chk(lib().uwt_profile_clock(self._h, C.byref(ghz)))
+        return ghz.value
 
     # -- per-stage entry points
     def halve_u8(self, img):

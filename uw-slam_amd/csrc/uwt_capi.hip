@@ -39,8 +39,25 @@ struct uwt_ctx {
   PairState* state = nullptr;
   int* d_ref = nullptr;
   int* d_tgt = nullptr;
-  int* h_pairs = nullptr;               // pinned staging: [ref(max_pairs) | tgt(max_pairs)], also the cache of what is on the device
+  // pinned staging of the pair lists, a ring of kPairStages [ref(max_pairs) | tgt(max_pairs)] blocks: a new list is
+  // written to the next block while the asynchronous copy of the previous one may still be reading its own
+  static constexpr int kPairStages = 4;
+  int* h_pairs = nullptr;
+  hipEvent_t ev_pairs[kPairStages] = {};
+  int pair_stage = 0;                   // block holding the lists that are on the device
   int n_pairs_cached = 0;
+  // Copy stream + slot-range dependencies (uwt_upload_frames_async): `busy` = compute work enqueued on `stream` that
+  // reads or writes a slot range, `fresh` = uploads enqueued on `copy` into a slot range.  An upload waits for the busy
+  // entries it overlaps, a compute call for the fresh ones; both rings are in stream order, so once an entry has been
+  // dropped the oldest survivor stands for everything before it.
+  struct SlotDep { int first = 0, n = 0; hipEvent_t ev = nullptr; bool used = false; };
+  static constexpr int kDeps = 8;
+  hipStream_t copy = nullptr;
+  SlotDep busy[kDeps], fresh[kDeps];
+  int busy_next = 0, fresh_next = 0;
+  long long ticket_seq = 0;              // compute calls noted so far; busy_seq[i] = the call ring entry i stands for
+  long long busy_seq[kDeps] = {};
+  bool busy_dropped = false, fresh_dropped = false;
   uint32_t* partials = nullptr;
   size_t partial_records = 0;
   float* d_poses = nullptr;
@@ -53,10 +70,12 @@ struct uwt_ctx {
   void* scratch = nullptr;              // per-stage entry points
   size_t scratch_bytes = 0;
   bool profiling = false;
+  bool compute_only = false;            // uwt_profile_enable(ctx, 2): residual launches run their no-memory diagnostic twin
   std::vector<hipEvent_t> ev_pool;      // start/stop pairs
   size_t ev_used = 0;
   double prof_ms = 0.0;
   long long prof_launches = 0, prof_pixels = 0;
+  int prof_slices = 0, prof_pairs = 0;   // slicing of the last profiled residual launch (uwt_profile_clock)
   std::string last_error;
 };
 
@@ -163,7 +182,13 @@ int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int 
 }
 
 template <int VEC, bool DEPTH, bool UNIT, bool DUMP>
-void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64) {
+void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64, bool compute_only) {
+  if constexpr (VEC == 4 && UNIT && !DUMP) {
+    if (compute_only && acc64 && a.L.fx == a.L.fy) {  // diagnostic twin of the production instantiation
+      hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+      return;
+    }
+  }
   if (acc64 && UNIT && VEC == 4 && !DUMP && a.L.fx == a.L.fy)
     hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, double, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
   else if (acc64)
@@ -178,23 +203,24 @@ int launch_residual(uwt_ctx* c, const ResidualArgs& a, int n_pairs, bool dump) {
   const int key = (c->vec == 4 ? 8 : 0) | (depth ? 4 : 0) | (unit ? 2 : 0) | (dump ? 1 : 0);
   hipStream_t s = c->stream;
   const bool acc64 = c->p.accumulate_f64 != 0;
+  const bool co = c->compute_only && !dump;
   switch (key) {
-    case 0: launch_residual_t<1, false, false, false>(s, a, n_pairs, acc64); break;
-    case 1: launch_residual_t<1, false, false, true>(s, a, n_pairs, acc64); break;
-    case 2: launch_residual_t<1, false, true, false>(s, a, n_pairs, acc64); break;
-    case 3: launch_residual_t<1, false, true, true>(s, a, n_pairs, acc64); break;
-    case 4: launch_residual_t<1, true, false, false>(s, a, n_pairs, acc64); break;
-    case 5: launch_residual_t<1, true, false, true>(s, a, n_pairs, acc64); break;
-    case 6: launch_residual_t<1, true, true, false>(s, a, n_pairs, acc64); break;
-    case 7: launch_residual_t<1, true, true, true>(s, a, n_pairs, acc64); break;
-    case 8: launch_residual_t<4, false, false, false>(s, a, n_pairs, acc64); break;
-    case 9: launch_residual_t<4, false, false, true>(s, a, n_pairs, acc64); break;
-    case 10: launch_residual_t<4, false, true, false>(s, a, n_pairs, acc64); break;
-    case 11: launch_residual_t<4, false, true, true>(s, a, n_pairs, acc64); break;
-    case 12: launch_residual_t<4, true, false, false>(s, a, n_pairs, acc64); break;
-    case 13: launch_residual_t<4, true, false, true>(s, a, n_pairs, acc64); break;
-    case 14: launch_residual_t<4, true, true, false>(s, a, n_pairs, acc64); break;
-    default: launch_residual_t<4, true, true, true>(s, a, n_pairs, acc64); break;
+    case 0: launch_residual_t<1, false, false, false>(s, a, n_pairs, acc64, co); break;
+    case 1: launch_residual_t<1, false, false, true>(s, a, n_pairs, acc64, co); break;
+    case 2: launch_residual_t<1, false, true, false>(s, a, n_pairs, acc64, co); break;
+    case 3: launch_residual_t<1, false, true, true>(s, a, n_pairs, acc64, co); break;
+    case 4: launch_residual_t<1, true, false, false>(s, a, n_pairs, acc64, co); break;
+    case 5: launch_residual_t<1, true, false, true>(s, a, n_pairs, acc64, co); break;
+    case 6: launch_residual_t<1, true, true, false>(s, a, n_pairs, acc64, co); break;
+    case 7: launch_residual_t<1, true, true, true>(s, a, n_pairs, acc64, co); break;
+    case 8: launch_residual_t<4, false, false, false>(s, a, n_pairs, acc64, co); break;
+    case 9: launch_residual_t<4, false, false, true>(s, a, n_pairs, acc64, co); break;
+    case 10: launch_residual_t<4, false, true, false>(s, a, n_pairs, acc64, co); break;
+    case 11: launch_residual_t<4, false, true, true>(s, a, n_pairs, acc64, co); break;
+    case 12: launch_residual_t<4, true, false, false>(s, a, n_pairs, acc64, co); break;
+    case 13: launch_residual_t<4, true, false, true>(s, a, n_pairs, acc64, co); break;
+    case 14: launch_residual_t<4, true, true, false>(s, a, n_pairs, acc64, co); break;
+    default: launch_residual_t<4, true, true, true>(s, a, n_pairs, acc64, co); break;
   }
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
@@ -377,6 +403,9 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         if (c->profiling) {
           int st = prof_begin(c, &ev);
           if (st) return st;
+          ra.probe = 1;
+          c->prof_slices = ra.slices;
+          c->prof_pairs = n_pairs;
         }
         int st = general ? launch_general(c, ra, n_pairs) : launch_residual(c, ra, n_pairs, false);
         if (st) return st;
@@ -410,6 +439,31 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   return UWT_OK;
 }
 
+// ---- slot-range dependencies between the context stream and the copy stream --------------------------------------
+int dep_note(uwt_ctx* c, uwt_ctx::SlotDep* ring, int& next, bool& dropped, hipStream_t on, int first, int n) {
+  uwt_ctx::SlotDep& d = ring[next];
+  if (d.used) dropped = true;
+  d.first = first; d.n = n; d.used = true;
+  HIPCHK(c, hipEventRecord(d.ev, on));
+  next = (next + 1) % uwt_ctx::kDeps;
+  return UWT_OK;
+}
+int dep_wait(uwt_ctx* c, const uwt_ctx::SlotDep* ring, int next, bool dropped, hipStream_t waiter, int first, int n) {
+  for (int i = 0; i < uwt_ctx::kDeps; i++) {
+    const uwt_ctx::SlotDep& d = ring[i];
+    const bool oldest = dropped && i == next;   // ring[next] is the oldest survivor once the ring has wrapped
+    if (d.used && (oldest || (d.first < first + n && first < d.first + d.n))) HIPCHK(c, hipStreamWaitEvent(waiter, d.ev, 0));
+  }
+  return UWT_OK;
+}
+// a compute call on slots [first, first + n): ordered behind the uploads into them ...
+int compute_begin(uwt_ctx* c, int first, int n) { return dep_wait(c, c->fresh, c->fresh_next, c->fresh_dropped, c->stream, first, n); }
+// ... and remembered, so that a later upload into them waits for it
+int compute_end(uwt_ctx* c, int first, int n) {
+  c->busy_seq[c->busy_next] = ++c->ticket_seq;
+  return dep_note(c, c->busy, c->busy_next, c->busy_dropped, c->stream, first, n);
+}
+
 // The caller's lists are copied before this returns (they may be temporaries): into a pinned staging buffer, then
 // asynchronously to the device.  Unchanged lists (the steady state of a resident batch) are not re-sent.
 int upload_pairs(uwt_ctx* c, int n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots) {
@@ -418,17 +472,25 @@ int upload_pairs(uwt_ctx* c, int n_pairs, const int32_t* ref_slots, const int32_
   for (int i = 0; i < n_pairs; i++)
     if (ref_slots[i] < 0 || ref_slots[i] >= c->p.max_frames || tgt_slots[i] < 0 || tgt_slots[i] >= c->p.max_frames)
       return fail(c, UWT_ERR_INVALID_ARG, "pair slot out of range");
-  int* h_ref = c->h_pairs;
-  int* h_tgt = c->h_pairs + c->p.max_pairs;
-  if (n_pairs == c->n_pairs_cached && !std::memcmp(h_ref, ref_slots, sizeof(int) * n_pairs) &&
-      !std::memcmp(h_tgt, tgt_slots, sizeof(int) * n_pairs))
-    return UWT_OK;
-  HIPCHK(c, hipStreamSynchronize(c->stream));  // an earlier async copy may still be reading the staging buffer
+  const size_t block = 2 * (size_t)c->p.max_pairs;
+  {
+    const int* h_ref = c->h_pairs + c->pair_stage * block;
+    const int* h_tgt = h_ref + c->p.max_pairs;
+    if (n_pairs == c->n_pairs_cached && !std::memcmp(h_ref, ref_slots, sizeof(int) * n_pairs) &&
+        !std::memcmp(h_tgt, tgt_slots, sizeof(int) * n_pairs))
+      return UWT_OK;
+  }
+  const int stage = (c->pair_stage + 1) % uwt_ctx::kPairStages;
+  HIPCHK(c, hipEventSynchronize(c->ev_pairs[stage]));  // the copy that last read this block (kPairStages lists ago)
+  int* h_ref = c->h_pairs + stage * block;
+  int* h_tgt = h_ref + c->p.max_pairs;
   std::memcpy(h_ref, ref_slots, sizeof(int) * n_pairs);
   std::memcpy(h_tgt, tgt_slots, sizeof(int) * n_pairs);
+  c->pair_stage = stage;
   c->n_pairs_cached = n_pairs;
   HIPCHK(c, hipMemcpyAsync(c->d_ref, h_ref, sizeof(int) * n_pairs, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipMemcpyAsync(c->d_tgt, h_tgt, sizeof(int) * n_pairs, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_pairs[stage], c->stream));
   return UWT_OK;
 }
 
@@ -544,6 +606,12 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipSetDevice(p->device));
   CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CREATE_CHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  CREATE_CHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
+  for (int i = 0; i < uwt_ctx::kDeps; i++) {
+    CREATE_CHK(hipEventCreateWithFlags(&c->busy[i].ev, hipEventDisableTiming));
+    CREATE_CHK(hipEventCreateWithFlags(&c->fresh[i].ev, hipEventDisableTiming));
+  }
+  for (int i = 0; i < uwt_ctx::kPairStages; i++) CREATE_CHK(hipEventCreateWithFlags(&c->ev_pairs[i], hipEventDisableTiming));
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_pyramids, hipEventDisableTiming));
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
   for (int l = 0; l < UWT_MAX_LEVELS; l++) CREATE_CHK(hipEventCreateWithFlags(&c->ev_level[l], hipEventDisableTiming));
@@ -569,7 +637,8 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
     CREATE_CHK(hipMemset(c->scale, 0, sizeof(PairScale) * p->max_pairs));
   }
   CREATE_CHK(hipHostMalloc((void**)&c->h_active, sizeof(int)));
-  CREATE_CHK(hipHostMalloc((void**)&c->h_pairs, sizeof(int) * 2 * p->max_pairs));
+  CREATE_CHK(hipHostMalloc((void**)&c->h_pairs, sizeof(int) * 2 * p->max_pairs * uwt_ctx::kPairStages));
+  std::memset(c->h_pairs, 0xff, sizeof(int) * 2 * p->max_pairs * uwt_ctx::kPairStages);
 #undef CREATE_CHK
   *out = c;
   return UWT_OK;
@@ -580,6 +649,7 @@ int uwt_destroy(uwt_ctx* c) {
   (void)hipSetDevice(c->p.device);
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->side) (void)hipStreamSynchronize(c->side);  // an aborted uwt_track_batch_async may have left work there
+  if (c->copy) (void)hipStreamSynchronize(c->copy);
   for (int l = 0; l < UWT_MAX_LEVELS; l++) {
     if (c->img[l]) (void)hipFree(c->img[l]);
     if (c->depth[l]) (void)hipFree(c->depth[l]);
@@ -600,6 +670,13 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->scratch) (void)hipFree(c->scratch);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->copy) (void)hipStreamDestroy(c->copy);
+  for (int i = 0; i < uwt_ctx::kDeps; i++) {
+    if (c->busy[i].ev) (void)hipEventDestroy(c->busy[i].ev);
+    if (c->fresh[i].ev) (void)hipEventDestroy(c->fresh[i].ev);
+  }
+  for (int i = 0; i < uwt_ctx::kPairStages; i++)
+    if (c->ev_pairs[i]) (void)hipEventDestroy(c->ev_pairs[i]);
   if (c->ev_pyramids) (void)hipEventDestroy(c->ev_pyramids);
   if (c->ev_side_done) (void)hipEventDestroy(c->ev_side_done);
   for (int l = 0; l < UWT_MAX_LEVELS; l++)
@@ -648,6 +725,8 @@ int uwt_set_frame(uwt_ctx* c, int32_t slot, const uint8_t* gray, size_t row_stri
   if (!c || !gray || !slot_range_ok(c, slot, 1)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: bad slot/pointer");
   const int w = c->p.width, h = c->p.height;
   if (row_stride < (size_t)w) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: row stride < width");
+  int st0 = compute_begin(c, slot, 1);
+  if (st0) return st0;
   HIPCHK(c, hipMemcpy2DAsync(c->img[0] + (size_t)slot * w * h, w, gray, row_stride, w, h, hipMemcpyHostToDevice, c->stream));
   if (c->p.has_depth) {
     if (!depth || depth_row_stride < (size_t)w * 2) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: depth required");
@@ -658,9 +737,33 @@ int uwt_set_frame(uwt_ctx* c, int32_t slot, const uint8_t* gray, size_t row_stri
   return UWT_OK;
 }
 
+int uwt_host_alloc(size_t bytes, void** out) {
+  if (!out || !bytes) return UWT_ERR_INVALID_ARG;
+  *out = nullptr;
+  return hipHostMalloc(out, bytes) == hipSuccess ? UWT_OK : UWT_ERR_HIP;
+}
+
+int uwt_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? UWT_OK : UWT_ERR_HIP; }
+
+int uwt_upload_frames_async(uwt_ctx* c, int32_t first_slot, int32_t n, const uint8_t* gray, const uint16_t* depth) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
+  if (!c || !gray || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_upload_frames_async: bad range");
+  if (n == 0) return UWT_OK;
+  // behind the compute work that still reads or writes these slots, beside everything else on the context stream
+  int st = dep_wait(c, c->busy, c->busy_next, c->busy_dropped, c->copy, first_slot, n);
+  if (st) return st;
+  const size_t px = (size_t)c->p.width * c->p.height;
+  HIPCHK(c, hipMemcpyAsync(c->img[0] + first_slot * px, gray, px * n, hipMemcpyHostToDevice, c->copy));
+  if (c->p.has_depth && depth)
+    HIPCHK(c, hipMemcpyAsync(c->depth[0] + first_slot * px, depth, px * n * 2, hipMemcpyHostToDevice, c->copy));
+  return dep_note(c, c->fresh, c->fresh_next, c->fresh_dropped, c->copy, first_slot, n);
+}
+
 int uwt_upload_frames(uwt_ctx* c, int32_t first_slot, int32_t n, const uint8_t* gray, const uint16_t* depth) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !gray || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_upload_frames: bad range");
+  int st0 = compute_begin(c, first_slot, n);   // on the context stream: behind asynchronous uploads into the same slots
+  if (st0) return st0;
   const size_t px = (size_t)c->p.width * c->p.height;
   HIPCHK(c, hipMemcpyAsync(c->img[0] + first_slot * px, gray, px * n, hipMemcpyHostToDevice, c->stream));
   if (c->p.has_depth) {
@@ -735,7 +838,9 @@ static int enqueue_gradients(uwt_ctx* c, int first_slot, int n, const int* d_slo
 int uwt_build_pyramids(uwt_ctx* c, int32_t first_slot, int32_t n) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_build_pyramids: bad range");
-  int st = enqueue_pyramids(c, first_slot, n);
+  int st = compute_begin(c, first_slot, n);
+  if (st) return st;
+  st = enqueue_pyramids(c, first_slot, n);
   if (st) return st;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
@@ -744,7 +849,9 @@ int uwt_build_pyramids(uwt_ctx* c, int32_t first_slot, int32_t n) {
 int uwt_apply_gradient(uwt_ctx* c, int32_t first_slot, int32_t n) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_apply_gradient: bad range");
-  int st = enqueue_gradients(c, first_slot, n);
+  int st = compute_begin(c, first_slot, n);
+  if (st) return st;
+  st = enqueue_gradients(c, first_slot, n);
   if (st) return st;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
@@ -755,6 +862,8 @@ int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slot
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !poses_out) return fail(c, UWT_ERR_INVALID_ARG, "uwt_estimate_pose_batch: null argument");
   int st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
+  if (st) return st;
+  st = compute_begin(c, 0, c->p.max_frames);
   if (st) return st;
   st = enqueue_estimate(c, n_pairs, c->d_poses, c->d_stats);
   if (st) return st;
@@ -777,12 +886,14 @@ int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slot
   return UWT_OK;
 }
 
-int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only, int32_t n_pairs,
-                          const int32_t* ref_slots, const int32_t* tgt_slots, float* d_poses_out, uwt_stats* d_stats_out) {
+static int track_batch_enqueue(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only, int32_t n_pairs,
+                               const int32_t* ref_slots, const int32_t* tgt_slots, float* d_poses_out, uwt_stats* d_stats_out) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !d_poses_out || !slot_range_ok(c, first_slot, n_frames))
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_track_batch_async: bad argument");
   int st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
+  if (st) return st;
+  st = compute_begin(c, first_slot, n_frames);   // behind the asynchronous uploads into these slots
   if (st) return st;
   // The tracker reads gradients and depth of the previous (reference) frame only (src/Tracker.cpp:407-408, 1266-1272).
   // grad_refs_only computes those planes — gradients of every level, depth levels 1.. — for the pairs' reference slots
@@ -823,9 +934,50 @@ int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int3
   return UWT_OK;
 }
 
+int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only, int32_t n_pairs,
+                          const int32_t* ref_slots, const int32_t* tgt_slots, float* d_poses_out, uwt_stats* d_stats_out) {
+  int st = track_batch_enqueue(c, first_slot, n_frames, grad_refs_only, n_pairs, ref_slots, tgt_slots, d_poses_out, d_stats_out);
+  if (st) return st;
+  return compute_end(c, first_slot, n_frames);
+}
+
+int uwt_track_batch_host_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only, int32_t n_pairs,
+                               const int32_t* ref_slots, const int32_t* tgt_slots, float* h_poses_out, uwt_stats* h_stats_out,
+                               int64_t* ticket_out) {
+  if (!c || !h_poses_out || !ticket_out) return fail(c, UWT_ERR_INVALID_ARG, "uwt_track_batch_host_async: null argument");
+  int st = track_batch_enqueue(c, first_slot, n_frames, grad_refs_only, n_pairs, ref_slots, tgt_slots, c->d_poses,
+                               reinterpret_cast<uwt_stats*>(c->d_stats));
+  if (st) return st;
+  // results follow the alignment on the context stream into the caller's (page-locked) buffers; the context's own device
+  // buffers are free again before the next call's write-out because the stream is in order
+  HIPCHK(c, hipMemcpyAsync(h_poses_out, c->d_poses, sizeof(float) * 7 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+  if (h_stats_out)
+    HIPCHK(c, hipMemcpyAsync(h_stats_out, c->d_stats, sizeof(uwt_stats) * n_pairs, hipMemcpyDeviceToHost, c->stream));
+  st = compute_end(c, first_slot, n_frames);
+  if (st) return st;
+  *ticket_out = c->ticket_seq;
+  return UWT_OK;
+}
+
+int uwt_wait_ticket(uwt_ctx* c, int64_t ticket) {
+  if (!c) return UWT_ERR_INVALID_ARG;
+  (void)hipSetDevice(c->p.device);
+  if (ticket < 1 || ticket > c->ticket_seq) return fail(c, UWT_ERR_INVALID_ARG, "uwt_wait_ticket: unknown ticket");
+  for (int i = 0; i < uwt_ctx::kDeps; i++)
+    if (c->busy[i].used && c->busy_seq[i] == ticket) {
+      HIPCHK(c, hipEventSynchronize(c->busy[i].ev));
+      return UWT_OK;
+    }
+  // older than the ring: everything recorded before the oldest surviving entry is complete when that entry is
+  HIPCHK(c, hipEventSynchronize(c->busy[c->busy_next].ev));
+  return UWT_OK;
+}
+
+
 int uwt_sync(uwt_ctx* c) {
   if (!c) return UWT_ERR_INVALID_ARG;
   (void)hipSetDevice(c->p.device);
+  HIPCHK(c, hipStreamSynchronize(c->copy));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   if (c->profiling) return prof_collect(c);
   return UWT_OK;
@@ -842,7 +994,8 @@ int uwt_profile_enable(uwt_ctx* c, int32_t on) {
   if (!c) return UWT_ERR_INVALID_ARG;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->ev_used = 0;
-  c->profiling = on != 0;
+  c->profiling = (on & 1) != 0;
+  c->compute_only = (on & 2) != 0;
   c->prof_ms = 0.0;
   c->prof_launches = 0;
   c->prof_pixels = 0;
@@ -854,6 +1007,24 @@ int uwt_profile_read(uwt_ctx* c, double* ms_total, int64_t* launches, int64_t* p
   if (ms_total) *ms_total = c->prof_ms;
   if (launches) *launches = c->prof_launches;
   if (pixels) *pixels = c->prof_pixels;
+  return UWT_OK;
+}
+
+int uwt_profile_clock(uwt_ctx* c, double* shader_ghz) {
+  if (c) (void)hipSetDevice(c->p.device);
+  if (!c || !shader_ghz) return UWT_ERR_INVALID_ARG;
+  *shader_ghz = 0.0;
+  if (!c->prof_slices || !c->prof_pairs) return fail(c, UWT_ERR_INVALID_ARG, "no profiled residual launch yet");
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  const int n = std::min(c->prof_pairs, 64);
+  double cyc = 0.0, sec = 0.0;
+  for (int p = 0; p < n; p++) {  // slice 0 of the first pairs of the last profiled launch
+    uint32_t w[2];
+    HIPCHK(c, hipMemcpy(w, c->partials + ((size_t)p * c->prof_slices) * kRecWords + 60, sizeof(w), hipMemcpyDeviceToHost));
+    cyc += (double)w[0];
+    sec += (double)w[1] * 1e-8;  // s_memrealtime: 100 MHz
+  }
+  if (sec > 0.0) *shader_ghz = cyc / sec * 1e-9;
   return UWT_OK;
 }
 
@@ -1495,7 +1666,14 @@ int uwt_ingest_frame(uwt_ingest* g, uwt_ctx* c, int32_t slot, const uint8_t* raw
   const int cw = c->p.width, ch = c->p.height;
   if (x0 < 0 || y0 < 0 || x0 + cw > g->out_w || y0 + ch > g->out_h || g->device != c->p.device)
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_ingest_frame: crop window outside the undistorted frame");
-  int st = ingest_remap(g, raw, stride, x0, y0, cw, ch, c->img[0] + (size_t)slot * cw * ch);
+  // The remap runs on the ingest object's stream and writes straight into the tracker's slot: it is ordered behind the
+  // tracker work still in flight on that slot (uwt_track_batch_async returns with its kernels queued), and this call
+  // returns only when the slot is written, so whatever the tracker enqueues next sees the new frame.
+  int st = dep_wait(c, c->busy, c->busy_next, c->busy_dropped, g->stream, slot, 1);
+  if (st) return st;
+  st = dep_wait(c, c->fresh, c->fresh_next, c->fresh_dropped, g->stream, slot, 1);
+  if (st) return st;
+  st = ingest_remap(g, raw, stride, x0, y0, cw, ch, c->img[0] + (size_t)slot * cw * ch);
   if (st) return st;
   ING_CHK(hipStreamSynchronize(g->stream));
   return UWT_OK;
@@ -1522,13 +1700,5 @@ int uwt_accumulate_trajectory(uwt_ctx* c, const float* poses, int32_t n, const f
   return UWT_OK;
 }
 
-#ifdef UWT_EXP_CLOCK
-int uwt_debug_read_record(uwt_ctx* c, int32_t pair, int32_t slice, int32_t lvl, uint32_t out[64]) {
-  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  HIPCHK(c, hipMemcpy(out, c->partials + ((size_t)pair * c->slices[lvl] + slice) * kRecWords, 256, hipMemcpyDeviceToHost));
-  return UWT_OK;
-}
-#endif
 
 }  // extern "C"

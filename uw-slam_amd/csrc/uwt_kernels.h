@@ -627,6 +627,8 @@ struct ResidualArgs {
   float* dumpR;
   uint8_t* dumpV;
   float* dumpW;             // per-pixel robust weights (general path only)
+  int probe;                // 1: thread 0 of every block leaves its shader-clock / 100 MHz real-time deltas in words 60, 61
+                            // of the block's record (uwt_profile_clock: the clock the chip holds under this kernel)
 };
 
 // reference planes of one group of VEC pixels, as loaded (one vector load per plane)
@@ -637,13 +639,14 @@ struct RefGroup {
   uint16_t dp[VEC];
 };
 
-template <int VEC, bool DEPTH>
+template <int VEC, bool DEPTH, bool COMPUTE_ONLY = false>
 __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __restrict__ I1, const int16_t* __restrict__ GX,
                                            const int16_t* __restrict__ GY, const uint16_t* __restrict__ DP, uint32_t idx) {
-#ifdef UWT_EXP_NOMEM
-  for (int j = 0; j < VEC; j++) { r.i1[j] = (uint8_t)(idx + j); r.gx[j] = (int16_t)(idx * 3 + j); r.gy[j] = (int16_t)(idx * 5 - j); r.dp[j] = (uint16_t)(4000 + (idx & 255)); }
-  return;
-#endif
+  if constexpr (COMPUTE_ONLY) {  // diagnostic instantiation: plane values made up from the index, no memory operation
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { r.i1[j] = (uint8_t)(idx + j); r.gx[j] = (int16_t)(idx * 3 + j); r.gy[j] = (int16_t)(idx * 5 - j); r.dp[j] = (uint16_t)(4000 + (idx & 255)); }
+    return;
+  }
   if constexpr (VEC == 4) {
     // byte offsets in 32 bits (a level plane of one frame is < 2^31 bytes): uniform base + 32-bit lane offset addressing,
     // no 64-bit address arithmetic per load
@@ -661,10 +664,15 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
   }
 }
 
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0>
+// COMPUTE_ONLY (diagnostic, uwt_profile_enable(ctx, 2)): the same instruction stream with every load of the loop replaced
+// by register arithmetic — results are meaningless, its duration is the kernel's own instruction-issue floor.
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
+          bool COMPUTE_ONLY = false>
 __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int pair, const int slice) {
   Pose pose;
-  if (a.state) {
+  if constexpr (COMPUTE_ONLY) {
+    pose_identity(pose);   // never skips a pair, never follows the (meaningless) updates: every launch does the full work
+  } else if (a.state) {
     const PairState st = a.state[pair];
     if (st.level_done || st.status) return;
     pose = st.pose;
@@ -684,9 +692,11 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   const int16_t* __restrict__ GY = a.gy + ref_off;
   const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
 
-#ifdef UWT_EXP_CLOCK
-  const unsigned long long clk0 = __builtin_amdgcn_s_memtime(), rt0 = __builtin_amdgcn_s_memrealtime();
-#endif
+  unsigned long long clk0 = 0, rt0 = 0;
+  if (a.probe) {
+    clk0 = __builtin_amdgcn_s_memtime();
+    rt0 = __builtin_amdgcn_s_memrealtime();
+  }
   AccT acc[kAccFloats];
 #pragma unroll
   for (int i = 0; i < kAccFloats; i++) acc[i] = (AccT)0;
@@ -708,7 +718,7 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   // are needed last, for the residuals).
   RefGroup<VEC> rg;
   int g = g_begin + (int)threadIdx.x;
-  load_group<VEC, DEPTH>(rg, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
+  load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
   // Pixel coordinates of the thread's group, as floats (small integers: exact).  One division up front, then each step
   // of kBlock groups moves (x, y) by the level's fixed (step mod w, step / w) with at most one wrap.  Lanes past the end
   // of the level run on with coordinates outside the image; they are inactive and every term of theirs is discarded.
@@ -757,12 +767,9 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
     float s2[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-#if defined(UWT_EXP_NOGATHER) || defined(UWT_EXP_NOMEM)
-      i2[j] = (int)i1[j] + (int)(gidx[j] & 1);
-#else
-      if constexpr (SAMPLER == 0) i2[j] = I2[gidx[j]];   // nearest-neighbour gather of the target level (:472)
+      if constexpr (COMPUTE_ONLY) i2[j] = (int)i1[j] + (int)(gidx[j] & 1);
+      else if constexpr (SAMPLER == 0) i2[j] = I2[gidx[j]];   // nearest-neighbour gather of the target level (:472)
       else s2[j] = sample_bilinear(I2, L, get(x2[j / N], j % N), get(y2[j / N], j % N));  // EXTENSION; x2 = y2 = 0 for sanitised invalid pixels
-#endif
     }
     // the gradients leave rg here, so that it can be re-requested
     F g0[NU], g1[NU];
@@ -776,7 +783,7 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
     // behind the gathers.  The request is unconditional (the index is clamped): inside a branch, the compiler's wait for
     // the gathers would have to assume the branch not taken and count the plane loads in.
     __builtin_amdgcn_sched_barrier(0);
-    load_group<VEC, DEPTH>(rg, I1, GX, GY, DP, (uint32_t)min(g + kBlock, n_groups - 1) * VEC);
+    load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, I1, GX, GY, DP, (uint32_t)min(g + kBlock, n_groups - 1) * VEC);
     __builtin_amdgcn_sched_barrier(0);
     // phase 3: Jacobians (cover the gather latency)
     F J[NU][6];
@@ -822,13 +829,11 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   }
   const uint32_t n_valid = (threadIdx.x & 63) == 0 ? n_valid_wave : 0u;
   block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + slice) * kRecWords, err);
-#ifdef UWT_EXP_CLOCK
-  if (threadIdx.x == 0) {  // diagnostic build only: shader-clock and 100 MHz real-time deltas of this block
-    unsigned long long* dbg = reinterpret_cast<unsigned long long*>(a.partials + ((size_t)pair * a.slices + slice) * kRecWords) + 30;
-    dbg[0] = __builtin_amdgcn_s_memtime() - clk0;
-    dbg[1] = __builtin_amdgcn_s_memrealtime() - rt0;
+  if (a.probe && threadIdx.x == 0) {
+    uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
+    rec[60] = (uint32_t)(__builtin_amdgcn_s_memtime() - clk0);
+    rec[61] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt0);
   }
-#endif
 }
 
 #ifndef UWT_EXP_WAVES
@@ -836,9 +841,10 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
 #else
 #define UWT_RESIDUAL_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(UWT_EXP_WAVES, UWT_EXP_WAVES)))
 #endif
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0>
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
+          bool COMPUTE_ONLY = false>
 __global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
-  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
+  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -42,34 +42,68 @@ def centre_crop(img, w, h):
 
 
 class SequenceTracker:
-    """Tracks consecutive frame pairs of a sequence in chunks of `chunk` pairs resident on the GPU."""
+    """Tracks consecutive frame pairs of a sequence in chunks of `chunk` pairs, streamed: two slot ranges on the device
+    and two page-locked staging blocks on the host alternate, so that chunk k + 1 is staged and crosses PCIe
+    (uwt_upload_frames_async, copy stream) while chunk k is aligned (uwt_track_batch_host_async, context stream) — the
+    per-frame flow of System::AddFrame + System::Tracking (src/System.cpp:225-251, 193-223) with the upload overlapped.
+    The frame shared by two chunks is uploaded with both."""
 
     def __init__(self, width, height, fx, fy, cx, cy, depth=False, chunk=256, device=0, **params):
         self.w, self.h, self.depth, self.chunk = width, height, depth, chunk
-        over = dict(max_frames=chunk + 1, max_pairs=chunk, has_depth=int(depth), device=device)
+        over = dict(max_frames=2 * (chunk + 1), max_pairs=chunk, has_depth=int(depth), device=device)
         over.update(params)
         self.ctx = capi.Context(capi.default_params(width, height, fx, fy, cx, cy, **over))
+        self._gray = [capi.pinned_empty((chunk + 1, height, width), np.uint8) for _ in range(2)]
+        self._depth = [capi.pinned_empty((chunk + 1, height, width), np.uint16) for _ in range(2)] if depth else [None, None]
+        self._poses = [capi.pinned_empty((chunk, 7), np.float32) for _ in range(2)]
+        self._stats = [capi.pinned_empty((chunk, 4), np.int32) for _ in range(2)]
+
+    def _stage_and_upload(self, k, frames, depths, start, m):
+        b = k % 2
+        for i in range(m + 1):                                  # into page-locked memory, straight from the reader's arrays
+            self._gray[b][i] = frames[start + i]
+            if self.depth:
+                self._depth[b][i] = depths[start + i]
+        self.ctx.upload_frames_async(b * (self.chunk + 1), self._gray[b][:m + 1],
+                                     self._depth[b][:m + 1] if self.depth else None)
 
     def track(self, frames, depths=None):
-        """frames: iterable of h x w uint8 arrays (depths: matching uint16).  Returns (poses [n-1, 7], stats list):
+        """frames: sequence of h x w uint8 arrays (depths: matching uint16).  Returns (poses [n-1, 7], stats list):
         pose i is previous_frame->rigid_transformation_ for the pair (frame i, frame i+1)."""
         frames = list(frames)
         depths = list(depths) if depths is not None else None
         n = len(frames)
-        poses, stats = [], []
+        chunks = []                                             # (first frame, pairs)
         start = 0
         while start < n - 1:
-            m = min(self.chunk, n - 1 - start)                 # pairs in this chunk use frames start .. start+m
-            block = np.stack(frames[start:start + m + 1])
-            dblock = np.stack(depths[start:start + m + 1]) if self.depth else None
-            self.ctx.upload_frames(0, block, dblock)
-            self.ctx.build_pyramids(0, m + 1)
-            self.ctx.apply_gradient(0, m)                      # reference frames only (src/Tracker.cpp:407-408)
-            p, s = self.ctx.estimate_pose_batch(np.arange(m), np.arange(m) + 1)
-            poses.append(p)
-            stats += s
+            m = min(self.chunk, n - 1 - start)                  # pairs of this chunk use frames start .. start + m
+            chunks.append((start, m))
             start += m
-        return (np.concatenate(poses) if poses else np.zeros((0, 7), np.float32)), stats
+        poses = np.zeros((max(n - 1, 0), 7), np.float32)
+        stats = []
+        tickets = {}
+
+        def collect(k):
+            self.ctx.wait_ticket(tickets.pop(k))
+            s0, m = chunks[k]
+            poses[s0:s0 + m] = self._poses[k % 2][:m]
+            for r in self._stats[k % 2][:m]:
+                stats.append(dict(status=int(r[0]), iterations=int(r[1]), n_valid=int(r[2]),
+                                  error=float(np.asarray(r[3:4]).view(np.float32)[0])))
+
+        for k in range(min(2, len(chunks))):
+            self._stage_and_upload(k, frames, depths, *chunks[k])
+        for k, (s0, m) in enumerate(chunks):
+            base = (k % 2) * (self.chunk + 1)
+            ref = base + np.arange(m, dtype=np.int32)
+            tickets[k] = self.ctx.track_batch_host_async(base, m + 1, ref, ref + 1, self._poses[k % 2], self._stats[k % 2])
+            if k >= 1:
+                collect(k - 1)                                  # frees the other staging block and slot range ...
+                if k + 1 < len(chunks):
+                    self._stage_and_upload(k + 1, frames, depths, *chunks[k + 1])   # ... for the chunk after this one
+        if chunks:
+            collect(len(chunks) - 1)
+        return poses, stats
 
     def trajectory(self, poses, start_pose=None, reference_visualiser=False):
         """Visualizer::UpdateMessages accumulation (src/Visualizer.cpp:304-325); reference_visualiser reproduces the
