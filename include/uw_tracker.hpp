@@ -25,6 +25,10 @@
 
 #include "uwt.h"
 
+#ifdef __SSE__
+#include <xmmintrin.h>
+#endif
+
 #ifdef UW_WITH_OPENCV
 #include <opencv2/core.hpp>
 #endif
@@ -53,19 +57,39 @@ struct ImageView {
 #endif
 };
 
+struct Size {  // cv::Size() as System::AddFrame passes it to resize (src/System.cpp:247)
+  int width = 0, height = 0;
+};
+
+// cv::resize(src, dst, Size(), 0.5, 0.5) of System::AddFrame's pyramid loop (src/System.cpp:246-251).  The pixels of
+// levels 1.. are produced on the GPU when the tracker binds the frame (uwt_build_pyramids: the same 2x2 round-half-up
+// mean); here the destination view only takes its shape, with no host pixels (data == nullptr), so the loop compiles
+// and reads as it does in the reference.
+inline void resize(const ImageView& src, ImageView& dst, Size /*dsize*/, double fx, double fy) {
+  dst = ImageView(nullptr, (int)(src.rows * fy + 0.5), (int)(src.cols * fx + 0.5), 0);
+}
+
+class Tracker;
+
 // include/System.h:63-103 — the members the tracker reads or writes.
 class Frame {
  public:
+  Frame() = default;
+  ~Frame();                       // releases the device slot the frame holds, if any
+  Frame(const Frame&) = delete;   // a bound frame is known to its tracker by address
+  Frame& operator=(const Frame&) = delete;
+
   int idFrame_ = 0;
-  ImageView image0_;   // images_[0], CV_8UC1
-  ImageView depth0_;   // depths_[0], CV_16UC1 (optional)
+  std::vector<ImageView> images_ = std::vector<ImageView>(PYRAMID_LEVELS);  // [0]: CV_8UC1 host pixels; [1..]: shapes only
+  std::vector<ImageView> depths_ = std::vector<ImageView>(PYRAMID_LEVELS);  // [0]: CV_16UC1 host pixels (optional)
   bool depth_available_ = false;
   bool obtained_gradients_ = false;
   bool obtained_candidatePoints_ = false;
   SE3 rigid_transformation_;
   std::vector<float> keypoints_;                         // x0 y0 x1 y1 ... (cv::KeyPoint::pt of Frame::keypoints_)
   std::vector<float> candidatePoints_[PYRAMID_LEVELS];   // N x 4 [x y z w] per level when a sparse producer ran
-  int slot_ = -1;      // device frame slot once bound
+  int slot_ = -1;                 // device frame slot while bound; -1 again once the slot has gone to another frame
+  Tracker* tracker_ = nullptr;    // the tracker that holds the slot
 };
 
 class Tracker {
@@ -73,9 +97,18 @@ class Tracker {
   // include/Tracker.h:97.  `overrides` lets a caller change the constants the reference hard-codes as locals of
   // EstimatePose (src/Tracker.cpp:364-372); by default they are exactly those.
   explicit Tracker(bool _depth_available, int max_frames = 16, int device = 0)
-      : depth_available_(_depth_available), max_frames_(max_frames), device_(device) {}
+      : depth_available_(_depth_available), max_frames_(max_frames < 2 ? 2 : max_frames), device_(device),
+        owner_((size_t)(max_frames < 2 ? 2 : max_frames), nullptr), last_use_((size_t)(max_frames < 2 ? 2 : max_frames), 0) {}
   ~Tracker() {
+    for (Frame* f : owner_)
+      if (f) { f->slot_ = -1; f->tracker_ = nullptr; f->obtained_gradients_ = false; }
     if (ctx_) uwt_destroy(ctx_);
+  }
+  // a frame that goes away (System::FreeFrames, src/System.cpp:352-355) gives its slot back
+  void forget(Frame* f) {
+    if (f->slot_ >= 0 && f->slot_ < (int)owner_.size() && owner_[(size_t)f->slot_] == f) owner_[(size_t)f->slot_] = nullptr;
+    f->slot_ = -1;
+    f->tracker_ = nullptr;
   }
   Tracker(const Tracker&) = delete;
   Tracker& operator=(const Tracker&) = delete;
@@ -117,15 +150,39 @@ class Tracker {
   }
   // include/Tracker.h:122
   void EstimatePose(Frame* _previous_frame, Frame* _current_frame) {
-    if (!_previous_frame->obtained_gradients_) throw std::runtime_error("EstimatePose: ApplyGradient(previous) not called");
     const int32_t a = bind(_previous_frame), b = bind(_current_frame);
+    if (!_previous_frame->obtained_gradients_)
+      throw std::runtime_error("EstimatePose: ApplyGradient(previous) not called (or its slot was reused since)");
     check(uwt_estimate_pose_batch(ctx(), 1, &a, &b, _previous_frame->rigid_transformation_.data(), &last_stats_),
           "uwt_estimate_pose_batch");
+  }
+  // include/Tracker.h:124 — the vectorised prototype's schedule: levels PYRAMID_LEVELS-1 .. 0, <= 50 iterations, gain 50,
+  // epsilon 1e-3, no z / angle factor applied (src/Tracker.cpp:877-885, 1082).  The reference BODY is not reproduced: its
+  // residual ignores the warp (:933-944) and column 0 of Jw1 is zeroed by a typo (:986); this runs the same per-point
+  // terms as EstimatePose under that schedule.
+  void FastEstimatePose(Frame* _previous_frame, Frame* _current_frame) {
+    const int32_t a = bind(_previous_frame), b = bind(_current_frame);
+    if (!_previous_frame->obtained_gradients_)
+      throw std::runtime_error("FastEstimatePose: ApplyGradient(previous) not called (or its slot was reused since)");
+    uwt_params saved;
+    check(uwt_get_params(ctx(), &saved), "uwt_get_params");
+    uwt_params f = saved;
+    f.first_level = f.n_levels - 1; f.last_level = 0; f.max_iters = 50; f.gain = 50.0f; f.epsilon = 0.001f;
+    f.z_factor = 1.0f; f.angle_factor = 1.0f; f.early_exit = 1; f.handoff_scale_t = 0;
+    check(uwt_update_params(ctx(), &f), "uwt_update_params");
+    const int st = uwt_estimate_pose_batch(ctx(), 1, &a, &b, _previous_frame->rigid_transformation_.data(), &last_stats_);
+    uwt_update_params(ctx(), &saved);
+    check(st, "uwt_estimate_pose_batch");
+  }
+  // host copy of one level of a bound frame's planes (Frame::images_/depths_/gradientX_/gradientY_[lvl] in the reference)
+  void GetFrameLevel(Frame* _frame, int _lvl, int _plane, void* _host_out) {
+    check(uwt_get_plane(ctx(), bind(_frame), _lvl, _plane, _host_out), "uwt_get_plane");
   }
   // include/Tracker.h:145 — gradient_ > mean + GRADIENT_THRESHOLD (src/Options.cpp:27) on every level, x-major order
   void ObtainCandidatePoints(Frame* _frame, double gradient_threshold = 20.0) {
     const int slot = bind(_frame);
-    if (!_frame->obtained_gradients_) throw std::runtime_error("ObtainCandidatePoints: ApplyGradient not called");
+    if (!_frame->obtained_gradients_)
+      throw std::runtime_error("ObtainCandidatePoints: ApplyGradient not called (or the frame's slot was reused since)");
     for (int l = 0; l < params_.n_levels && l < PYRAMID_LEVELS; l++) {
       const uwt_level L = level(l);
       std::vector<float>& t = _frame->candidatePoints_[l];
@@ -152,7 +209,8 @@ class Tracker {
   // (src/Tracker.cpp:634-640, 834), over previous->candidatePoints_[0]
   void EstimatePoseFeatures(Frame* _previous_frame, Frame* _current_frame) {
     const int32_t a = bind(_previous_frame), b = bind(_current_frame);
-    if (!_previous_frame->obtained_gradients_) throw std::runtime_error("EstimatePoseFeatures: ApplyGradient(previous) not called");
+    if (!_previous_frame->obtained_gradients_)
+      throw std::runtime_error("EstimatePoseFeatures: ApplyGradient(previous) not called (or its slot was reused since)");
     uwt_params saved;
     check(uwt_get_params(ctx(), &saved), "uwt_get_params");
     uwt_params f = saved;
@@ -231,27 +289,60 @@ class Tracker {
     if (st != UWT_OK)
       throw std::runtime_error(std::string(what) + ": " + uwt_status_string(st) + (ctx_ ? std::string(" — ") + uwt_last_error(ctx_) : ""));
   }
-  // System::AddFrame's pyramid loop (src/System.cpp:246-251): upload level 0, build the other levels on the GPU
+  // System::AddFrame's pyramid loop (src/System.cpp:246-251): upload level 0, build the other levels on the GPU.
+  // Slots are handed out least-recently-used first; the frame that held a reused slot is told so (slot_ = -1, its
+  // gradient flag cleared): it uploads again when it is next used instead of silently reading another frame's planes.
   int bind(Frame* f) {
-    if (f->slot_ < 0) {
-      f->slot_ = next_slot_++ % max_frames_;
-      check(uwt_set_frame(ctx(), f->slot_, (const uint8_t*)f->image0_.data, f->image0_.step,
-                          depth_available_ ? (const uint16_t*)f->depth0_.data : nullptr, f->depth0_.step),
-            "uwt_set_frame");
-      check(uwt_build_pyramids(ctx(), f->slot_, 1), "uwt_build_pyramids");
+    if (f->slot_ >= 0 && f->tracker_ == this && owner_[(size_t)f->slot_] == f) {
+      last_use_[(size_t)f->slot_] = ++use_clock_;
+      return f->slot_;
     }
-    return f->slot_;
+    if (!f->images_[0].data) throw std::runtime_error("bind: Frame::images_[0] has no pixels");
+    int slot = 0;
+    for (int i = 0; i < max_frames_; i++) {
+      if (!owner_[(size_t)i]) { slot = i; break; }
+      if (last_use_[(size_t)i] < last_use_[(size_t)slot]) slot = i;
+    }
+    if (Frame* old = owner_[(size_t)slot]) {
+      old->slot_ = -1;
+      old->tracker_ = nullptr;
+      old->obtained_gradients_ = false;
+    }
+    owner_[(size_t)slot] = f;
+    last_use_[(size_t)slot] = ++use_clock_;
+    f->slot_ = slot;
+    f->tracker_ = this;
+    f->obtained_gradients_ = false;
+    check(uwt_set_frame(ctx(), slot, (const uint8_t*)f->images_[0].data, f->images_[0].step,
+                        depth_available_ ? (const uint16_t*)f->depths_[0].data : nullptr, f->depths_[0].step),
+          "uwt_set_frame");
+    check(uwt_build_pyramids(ctx(), slot, 1), "uwt_build_pyramids");
+    return slot;
   }
   bool depth_available_;
   int max_frames_, device_;
-  int next_slot_ = 0;
+  std::vector<Frame*> owner_;          // slot -> frame holding it
+  std::vector<uint64_t> last_use_;
+  uint64_t use_clock_ = 0;
   uwt_params params_{};
   uwt_ctx* ctx_ = nullptr;
   uwt_stats last_stats_{};
 };
 
-// include/LeastSquares.h:26-50.  update() buffers rows; finish*/() folds them on the GPU (uwt_ls_accumulate).
-// b keeps the reference's stored sign: b = -Σ w r J (src/LeastSquares.cpp:206).
+inline Frame::~Frame() {
+  if (tracker_) tracker_->forget(this);
+}
+
+// Four packed floats in place of __m128 where SSE is absent (LS::updateSSE's operands, include/LeastSquares.h:42).
+struct f4 {
+  float v[4];
+};
+
+// include/LeastSquares.h:26-50.  update() / updateSSE() buffer rows; finish*() folds them on the GPU (uwt_ls_accumulate for
+// the scalar rows, uwt_ls_accumulate_sse for the 4-wide ones — the two forms associate their products differently,
+// src/LeastSquares.cpp:151-153 vs :205) and adds the two, as finishNoDivide adds the lane sums onto A, b, error
+// (src/LeastSquares.cpp:39-139).  b keeps the reference's stored sign: b = -Σ w r J (:206, :117-133).
+// num_constraints counts 6 per updateSSE call like the reference (:201) unless count_quirk is switched off.
 class LS {
  public:
   explicit LS(uwt_ctx* ctx) : ctx_(ctx) { initialize(0); }
@@ -259,9 +350,11 @@ class LS {
   float b[6];
   float error;
   int num_constraints;
+  bool count_quirk = true;
 
   void initialize(const int /*max_num_constraints*/) {
     J_.clear(); r_.clear(); w_.clear();
+    J4_.clear(); r4_.clear(); w4_.clear();
     std::memset(A, 0, sizeof(A));
     std::memset(b, 0, sizeof(b));
     error = 0.f;
@@ -272,18 +365,52 @@ class LS {
     r_.push_back(res);
     w_.push_back(weight);
   }
-  void finishNoDivide() { fold(0); }
-  void finish() { fold(1); }
+  // four points at once: J1..J6 hold Jacobian component k of the four points (include/LeastSquares.h:42-43)
+  void updateSSE(const f4& J1, const f4& J2, const f4& J3, const f4& J4, const f4& J5, const f4& J6, const f4& res,
+                 const f4& weight) {
+    const f4* Jk[6] = {&J1, &J2, &J3, &J4, &J5, &J6};
+    for (int p = 0; p < 4; p++) {
+      for (int k = 0; k < 6; k++) J4_.push_back(Jk[k]->v[p]);
+      r4_.push_back(res.v[p]);
+      w4_.push_back(weight.v[p]);
+    }
+  }
+#ifdef __SSE__
+  void updateSSE(const __m128& J1, const __m128& J2, const __m128& J3, const __m128& J4, const __m128& J5, const __m128& J6,
+                 const __m128& res, const __m128& weight) {
+    f4 a[8];
+    const __m128* src[8] = {&J1, &J2, &J3, &J4, &J5, &J6, &res, &weight};
+    for (int i = 0; i < 8; i++) _mm_storeu_ps(a[i].v, *src[i]);
+    updateSSE(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
+  }
+#endif
+  void finishNoDivide() { fold(); }
+  void finish() {
+    fold();
+    const float n = (float)num_constraints;   // src/LeastSquares.cpp:141-146
+    for (float& x : A) x /= n;
+    for (float& x : b) x /= n;
+    error /= n;
+  }
 
  private:
-  void fold(int divide) {
-    int32_t n = 0;
-    const int st = uwt_ls_accumulate(ctx_, J_.data(), r_.data(), w_.data(), (int)r_.size(), divide, A, b, &error, &n);
-    if (st != UWT_OK) throw std::runtime_error(std::string("uwt_ls_accumulate: ") + uwt_status_string(st));
-    num_constraints = n;
+  void fold() {
+    float A1[36] = {}, b1[6] = {}, e1 = 0.f, A2[36] = {}, b2[6] = {}, e2 = 0.f;
+    int32_t n1 = 0, n2 = 0;
+    if (!r_.empty()) chk(uwt_ls_accumulate(ctx_, J_.data(), r_.data(), w_.data(), (int)r_.size(), 0, A1, b1, &e1, &n1), "uwt_ls_accumulate");
+    if (!r4_.empty())
+      chk(uwt_ls_accumulate_sse(ctx_, J4_.data(), r4_.data(), w4_.data(), (int)r4_.size(), 0, count_quirk ? 1 : 0, A2, b2, &e2, &n2),
+          "uwt_ls_accumulate_sse");
+    for (int i = 0; i < 36; i++) A[i] = A1[i] + A2[i];
+    for (int i = 0; i < 6; i++) b[i] = b1[i] + b2[i];
+    error = e1 + e2;
+    num_constraints = n1 + n2;
+  }
+  static void chk(int st, const char* what) {
+    if (st != UWT_OK) throw std::runtime_error(std::string(what) + ": " + uwt_status_string(st));
   }
   uwt_ctx* ctx_;
-  std::vector<float> J_, r_, w_;
+  std::vector<float> J_, r_, w_, J4_, r4_, w4_;
 };
 
 }  // namespace uw

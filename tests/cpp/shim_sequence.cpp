@@ -1,11 +1,33 @@
-// Drives the C++ shim (include/uw_tracker.hpp) through System::Tracking()'s call sequence (src/System.cpp:193-223)
-// on two frames read from a raw file:  <w> <h> then w*h bytes (previous) and w*h bytes (current).
-// Prints the resulting pose (qx qy qz qw tx ty tz) with %.9g and the iteration count.
+// Drives the C++ shim (include/uw_tracker.hpp) through System::AddFrame's pyramid loop and System::Tracking()'s call
+// sequence (src/System.cpp:225-251, 193-223) on two frames read from a raw file:  <w> <h> then w*h bytes (previous) and
+// w*h bytes (current).  Prints, one line each: the EstimatePose result, the feature variant, the LS mirror (scalar and
+// 4-wide rows), FastEstimatePose, and what happens to a frame whose device slot has been handed to another frame.
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <vector>
 
 #include "uw_tracker.hpp"
+
+using namespace uw;
+
+// System::AddFrame (src/System.cpp:225-251) with the file read replaced by a buffer
+static Frame* AddFrame(int _id, const std::vector<unsigned char>& pixels, int w, int h, bool depth_available_) {
+  Frame* newFrame = new Frame();
+  newFrame->idFrame_ = _id;
+  newFrame->images_[0] = ImageView(pixels.data(), h, w, (size_t)w);
+  for (int i = 1; i < PYRAMID_LEVELS; i++) {
+    resize(newFrame->images_[i - 1], newFrame->images_[i], Size(), 0.5, 0.5);
+    if (depth_available_) {
+      resize(newFrame->depths_[i - 1], newFrame->depths_[i], Size(), 0.5, 0.5);
+    }
+  }
+  return newFrame;
+}
+
+static void print_pose(const char* tag, const SE3& T, int iterations) {
+  std::printf("%s %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d\n", tag, T.q[0], T.q[1], T.q[2], T.q[3], T.t[0], T.t[1], T.t[2], iterations);
+}
 
 int main(int argc, char** argv) {
   if (argc < 4) return 2;
@@ -17,35 +39,70 @@ int main(int argc, char** argv) {
   try {
     const float fl = 525.0f * w / 640.0f;
     const float K[9] = {fl, 0, w / 2 - 0.5f, 0, fl, h / 2 - 0.5f, 0, 0, 1};
-    uw::Tracker* tracker_ = new uw::Tracker(false);
+    Tracker* tracker_ = new Tracker(false, /*max_frames=*/4);
     tracker_->InitializePyramid(w, h, K);
     tracker_->InitializeMasks();
-    uw::Frame previous_frame_, current_frame_;
-    previous_frame_.image0_ = uw::ImageView(a.data(), h, w, (size_t)w);
-    current_frame_.image0_ = uw::ImageView(b.data(), h, w, (size_t)w);
-    tracker_->ApplyGradient(&previous_frame_);
-    tracker_->ApplyGradient(&current_frame_);
-    tracker_->ObtainAllPoints(&previous_frame_);
-    tracker_->EstimatePose(&previous_frame_, &current_frame_);
-    const uw::SE3& T = previous_frame_.rigid_transformation_;
-    std::printf("%.9g %.9g %.9g %.9g %.9g %.9g %.9g %d\n", T.q[0], T.q[1], T.q[2], T.q[3], T.t[0], T.t[1], T.t[2],
-                tracker_->last_stats().iterations);
+    std::unique_ptr<Frame> previous_frame_(AddFrame(0, a, w, h, false)), current_frame_(AddFrame(1, b, w, h, false));
+    if (previous_frame_->images_[2].rows != h / 4 || previous_frame_->images_[2].cols != w / 4) return 4;
+    tracker_->ApplyGradient(previous_frame_.get());
+    tracker_->ApplyGradient(current_frame_.get());
+    tracker_->ObtainAllPoints(previous_frame_.get());
+    tracker_->EstimatePose(previous_frame_.get(), current_frame_.get());
+    const SE3 first = previous_frame_->rigid_transformation_;
+    print_pose("POSE", first, tracker_->last_stats().iterations);
     // the reference's live flow (src/System.cpp:193-223): key points -> ObtainPatchesPoints -> EstimatePoseFeatures
     for (int k = 0; k < 40; k++) {
-      previous_frame_.keypoints_.push_back(8.0f + (float)((k * 37) % (w - 16)));
-      previous_frame_.keypoints_.push_back(8.0f + (float)((k * 23) % (h - 16)));
+      previous_frame_->keypoints_.push_back(8.0f + (float)((k * 37) % (w - 16)));
+      previous_frame_->keypoints_.push_back(8.0f + (float)((k * 23) % (h - 16)));
     }
-    tracker_->ObtainPatchesPoints(&previous_frame_);
-    tracker_->EstimatePoseFeatures(&previous_frame_, &current_frame_);
-    const uw::SE3& F = previous_frame_.rigid_transformation_;
-    std::printf("FEATURES %.9g %.9g %.9g %.9g %.9g %.9g %.9g %d %d\n", F.q[0], F.q[1], F.q[2], F.q[3], F.t[0], F.t[1], F.t[2],
-                tracker_->last_stats().iterations, (int)(previous_frame_.candidatePoints_[0].size() / 4));
-    // LS mirror: one row, closed form A = (J J^T) w, b = -w r J
-    uw::LS ls(tracker_->ctx());
+    tracker_->ObtainPatchesPoints(previous_frame_.get());
+    tracker_->EstimatePoseFeatures(previous_frame_.get(), current_frame_.get());
+    std::printf("FEATURES ");
+    print_pose("", previous_frame_->rigid_transformation_, tracker_->last_stats().iterations);
+    std::printf("NPATCH %d\n", (int)(previous_frame_->candidatePoints_[0].size() / 4));
+    // LS mirror: one scalar row, closed form A = (J J^T) w, b = -w r J
+    LS ls(tracker_->ctx());
     const float J[6] = {1, 2, 3, 4, 5, 6};
     ls.update(J, 2.0f, 0.5f);
     ls.finishNoDivide();
     std::printf("LS %.9g %.9g %.9g %d\n", ls.A[0 * 6 + 1], ls.b[2], ls.error, ls.num_constraints);
+    // LS::updateSSE: two calls of four points each, component-major operands (include/LeastSquares.h:42)
+    ls.initialize(0);
+    for (int call = 0; call < 2; call++) {
+      f4 Jc[6], res, wgt;
+      for (int p = 0; p < 4; p++) {
+        const int q = call * 4 + p;
+        for (int k = 0; k < 6; k++) Jc[k].v[p] = 0.25f * (float)((q * 7 + k * 3) % 11) - 1.0f;
+        res.v[p] = (float)(q % 5) - 2.0f;
+        wgt.v[p] = 0.5f + 0.125f * (float)(q % 3);
+      }
+      ls.updateSSE(Jc[0], Jc[1], Jc[2], Jc[3], Jc[4], Jc[5], res, wgt);
+    }
+    ls.finish();
+    std::printf("LSSSE %.9g %.9g %.9g %.9g %.9g %d\n", ls.A[0], ls.A[1 * 6 + 4], ls.A[5 * 6 + 5], ls.b[3], ls.error, ls.num_constraints);
+    // FastEstimatePose: the 4 -> 0 / 50 iterations / gain 50 schedule (include/Tracker.h:124)
+    tracker_->FastEstimatePose(previous_frame_.get(), current_frame_.get());
+    print_pose("FAST", previous_frame_->rigid_transformation_, tracker_->last_stats().iterations);
+    // four more frames through a four-slot tracker: the first two lose their slots and are told so
+    std::vector<std::unique_ptr<Frame>> more;
+    for (int i = 0; i < 4; i++) {
+      more.emplace_back(AddFrame(2 + i, (i & 1) ? a : b, w, h, false));
+      tracker_->ApplyGradient(more.back().get());
+    }
+    const int slot_after = previous_frame_->slot_;
+    int thrown = 0;
+    try {
+      tracker_->EstimatePose(previous_frame_.get(), current_frame_.get());   // re-binds, but its gradients are gone
+    } catch (const std::exception&) {
+      thrown = 1;
+    }
+    tracker_->ApplyGradient(previous_frame_.get());
+    tracker_->EstimatePose(previous_frame_.get(), current_frame_.get());
+    const SE3& again = previous_frame_->rigid_transformation_;
+    std::printf("EVICT %d %d %d\n", slot_after, thrown, std::memcmp(&again, &first, sizeof(SE3)) == 0 ? 1 : 0);
+    more.clear();              // frames that go away give their slots back
+    previous_frame_.reset();
+    current_frame_.reset();
     delete tracker_;
   } catch (const std::exception& e) {
     std::fprintf(stderr, "error: %s\n", e.what());

@@ -37,23 +37,48 @@ def test_shim_sequence_matches_oracle(O, synth, tmp_path):
     raw.write_bytes(ref.tobytes() + tgt.tobytes())
     out = subprocess.run([exe, str(raw), str(w), str(h)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
-    lines = out.stdout.strip().splitlines()
-    vals = lines[0].split()
+    lines = {ln.split()[0]: ln.split()[1:] for ln in out.stdout.strip().splitlines()}
+    vals = lines["POSE"]
     pose = np.array([float(v) for v in vals[:7]], np.float32)
-    st, pose_cpu, tr = O.align_pair(O.default_params(w, h, f, f, w / 2 - 0.5, h / 2 - 0.5), ref, tgt, want_trace=True)
+    intr = (f, f, w / 2 - 0.5, h / 2 - 0.5)
+    st, pose_cpu, tr = O.align_pair(O.default_params(w, h, *intr), ref, tgt, want_trace=True)
     assert st == 0 and int(vals[7]) == len(tr)
     assert np.array_equal(pose, pose_cpu)
-    ft = lines[1].split()
-    assert ft[0] == "FEATURES"
+    ft = lines["FEATURES"]
     kp = np.array([[8.0 + (k * 37) % (w - 16), 8.0 + (k * 23) % (h - 16)] for k in range(40)], np.float32)
     pts, n = O.patch_points(kp, None, w, h)
     feat = dict(n_levels=5, first_level=0, last_level=0, max_iters=10, early_exit=1, gain=1.0, z_factor=0.002, handoff_scale_t=1)
-    so, pose_f, tr_f = O.align_pair_points(O.default_params(w, h, f, f, w / 2 - 0.5, h / 2 - 0.5, **feat), ref, tgt, {0: pts},
-                                           want_trace=True)
-    assert so == 0 and int(ft[9]) == n and int(ft[8]) == len(tr_f)
-    assert np.array_equal(np.array([float(v) for v in ft[1:8]], np.float32), pose_f)
-    ls = lines[2].split()
-    assert ls[0] == "LS" and float(ls[1]) == 1.0 and float(ls[2]) == -3.0 and float(ls[3]) == 2.0 and int(ls[4]) == 1
+    so, pose_f, tr_f = O.align_pair_points(O.default_params(w, h, *intr, **feat), ref, tgt, {0: pts}, want_trace=True)
+    assert so == 0 and int(lines["NPATCH"][0]) == n and int(ft[7]) == len(tr_f)
+    assert np.array_equal(np.array([float(v) for v in ft[:7]], np.float32), pose_f)
+    ls = lines["LS"]
+    assert float(ls[0]) == 1.0 and float(ls[1]) == -3.0 and float(ls[2]) == 2.0 and int(ls[3]) == 1
+    # LS::updateSSE twice + finish(): the oracle's 4-wide LS on the same operands (count quirk: 6 per call)
+    o = O.ls_new()
+    for call in range(2):
+        J = np.zeros((6, 4), np.float32); res = np.zeros(4, np.float32); wgt = np.zeros(4, np.float32)
+        for p in range(4):
+            q = call * 4 + p
+            for k in range(6):
+                J[k, p] = np.float32(0.25) * np.float32((q * 7 + k * 3) % 11) - np.float32(1.0)
+            res[p] = float(q % 5) - 2.0
+            wgt[p] = 0.5 + 0.125 * (q % 3)
+        O.ls_update4(o, J, res, wgt, quirk_plus6=True)
+    A, bvec, err, cnt = O.ls_finish(o, divide=True)
+    sse = lines["LSSSE"]
+    got = np.array([float(v) for v in sse[:5]], np.float32)
+    want = np.array([A[0, 0], A[1, 4], A[5, 5], bvec[3], err], np.float32)
+    assert int(sse[5]) == cnt == 12
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-6), (got, want)      # the bar of test_ls_accumulate_matches_oracle_ls
+    # FastEstimatePose = EstimatePose's terms under the 4 -> 0 / 50 / gain 50 schedule
+    fast = lines["FAST"]
+    fp = dict(n_levels=5, first_level=4, last_level=0, max_iters=50, early_exit=1, gain=50.0)
+    sf, pose_fast, tr_fast = O.align_pair(O.default_params(w, h, *intr, **fp), ref, tgt, want_trace=True)
+    assert sf == 0 and int(fast[7]) == len(tr_fast)
+    assert np.array_equal(np.array([float(v) for v in fast[:7]], np.float32), pose_fast)
+    # a frame whose slot went to another frame: told so (slot -1), EstimatePose refuses until ApplyGradient ran again,
+    # then reproduces the first pose bit for bit
+    assert lines["EVICT"] == ["-1", "1", "1"]
 
 
 BENCH = os.path.join(ROOT, "tools", "uwt_bench")

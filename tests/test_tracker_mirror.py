@@ -60,3 +60,49 @@ def test_system_tracking_sequences(O, synth):
     assert ls.num_constraints == n == 4 and np.allclose(ls.A, A, rtol=1e-5, atol=1e-5) and np.allclose(ls.b, b, rtol=1e-5, atol=1e-5)
     with pytest.raises(RuntimeError):
         tracker_.EstimatePose(T.Frame(ref), current_frame_)       # ApplyGradient not called on the new frame
+    # FastEstimatePose: EstimatePose's terms under the prototype's schedule (4 -> 0, <= 50 iterations, gain 50)
+    st = tracker_.FastEstimatePose(previous_frame_, current_frame_)
+    fp = dict(n_levels=5, first_level=4, last_level=0, max_iters=50, early_exit=1, gain=50.0)
+    so, pose_fast, tr = O.align_pair(O.default_params(w, h, *intr, **fp), ref, tgt, want_trace=True)
+    assert so == 0 and st["iterations"] == len(tr) and np.array_equal(previous_frame_.rigid_transformation_, pose_fast)
+    tracker_.EstimatePose(previous_frame_, current_frame_)          # constants restored
+    assert np.array_equal(previous_frame_.rigid_transformation_, pose_cpu)
+    # LS::updateSSE next to LS::update in one system: the oracle's LS fed the same way
+    ls.initialize(0)
+    o = O.ls_new()
+    J4 = rng.normal(0, 3, (6, 4)).astype(np.float32); r4 = rng.normal(0, 2, 4).astype(np.float32); w4 = rng.uniform(0.2, 1, 4).astype(np.float32)
+    ls.updateSSE(*J4, r4, w4)
+    O.ls_update4(o, J4, r4, w4, quirk_plus6=True)
+    ls.update(J[0], 1.5, 0.25)
+    O.ls_update(o, J[0], 1.5, 0.25)
+    ls.finishNoDivide()
+    A, b, e, n = O.ls_finish(o, False)
+    assert ls.num_constraints == n == 7
+    assert np.allclose(ls.A, A, rtol=1e-5, atol=1e-5) and np.allclose(ls.b, b, rtol=1e-5, atol=1e-5) and abs(ls.error - e) <= 1e-5 * abs(e)
+
+
+def test_slot_reuse_tells_the_evicted_frame(O, synth):
+    """More live frames than device slots: the least recently used frame loses its slot, knows it (slot None, gradient
+    flag cleared), and transparently uploads again — never another frame's planes under its name."""
+    T = importlib.import_module("uw-slam_amd.tracker")
+    w, h = 160, 96
+    f = 525.0 * w / 640.0
+    intr = (f, f, w / 2 - 0.5, h / 2 - 0.5)
+    K = np.array([[f, 0, intr[2]], [0, f, intr[3]], [0, 0, 1]], np.float32)
+    pairs = [synth.render_pair(w, h, *intr, seed=200 + s)[:2] for s in range(3)]
+    trk = T.Tracker(False, max_frames=4)
+    trk.InitializePyramid(w, h, K)
+    frames = [(T.Frame(a), T.Frame(b)) for a, b in pairs]
+    want = [O.align_pair(O.default_params(w, h, *intr), a, b)[1] for a, b in pairs]
+    for (fa, fb) in frames:                       # six frames through four slots
+        trk.ApplyGradient(fa)
+        trk.EstimatePose(fa, fb)
+    assert frames[0][0]._slot is None and frames[0][1]._slot is None and not frames[0][0].obtained_gradients_
+    assert frames[2][0]._slot is not None
+    with pytest.raises(RuntimeError):
+        trk.EstimatePose(frames[0][0], frames[0][1])            # re-bound, but its gradients were lost with the slot
+    for k in (0, 1, 2, 0):
+        fa, fb = frames[k]
+        trk.ApplyGradient(fa)
+        trk.EstimatePose(fa, fb)
+        assert np.array_equal(fa.rigid_transformation_, want[k]), k

@@ -45,7 +45,9 @@ class Tracker:
         self._device = device
         self._over = params
         self._ctx = None
-        self._next_slot = 0
+        self._owner = [None] * max_frames          # slot -> Frame holding it
+        self._last_use = [0] * max_frames
+        self._clock = 0
 
     def InitializePyramid(self, _width, _height, _K):
         K = np.asarray(_K, np.float32)
@@ -69,12 +71,25 @@ class Tracker:
 
     def _bind(self, frame):
         """System::AddFrame's pyramid loop (src/System.cpp:246-251): upload level 0, build levels 1.. on the GPU."""
-        if frame._slot is None:
-            frame._slot = self._next_slot % self._max_frames
-            self._next_slot += 1
-            self._ctx.set_frame(frame._slot, frame.images_[0], frame.depths_[0] if self.depth_available_ else None)
-            self._ctx.build_pyramids(frame._slot, 1)
-        return frame._slot
+        self._clock += 1
+        if frame._slot is not None and self._owner[frame._slot] is frame:
+            self._last_use[frame._slot] = self._clock
+            return frame._slot
+        # least-recently-used slot; the frame that held it is told (it uploads again when next used, and its gradients
+        # are gone) instead of silently reading another frame's planes
+        free = [i for i, o in enumerate(self._owner) if o is None]
+        slot = free[0] if free else min(range(self._max_frames), key=lambda i: self._last_use[i])
+        old = self._owner[slot]
+        if old is not None:
+            old._slot = None
+            old.obtained_gradients_ = False
+        self._owner[slot] = frame
+        self._last_use[slot] = self._clock
+        frame._slot = slot
+        frame.obtained_gradients_ = False
+        self._ctx.set_frame(slot, frame.images_[0], frame.depths_[0] if self.depth_available_ else None)
+        self._ctx.build_pyramids(slot, 1)
+        return slot
 
     def ApplyGradient(self, _frame):
         slot = self._bind(_frame)
@@ -91,10 +106,28 @@ class Tracker:
         return self._ctx.warp(int(_lvl), _points2warp, _rigid_transformation)
 
     def EstimatePose(self, _previous_frame, _current_frame):
-        if not _previous_frame.obtained_gradients_:
-            raise RuntimeError("ApplyGradient(previous_frame) must run before EstimatePose")  # reference: empty cv::Mat
         a, b = self._bind(_previous_frame), self._bind(_current_frame)
+        if not _previous_frame.obtained_gradients_:  # reference: empty cv::Mat
+            raise RuntimeError("ApplyGradient(previous_frame) must run before EstimatePose (or its slot was reused since)")
         poses, stats = self._ctx.estimate_pose_batch([a], [b], raise_on_pair_failure=True)
+        _previous_frame.rigid_transformation_ = poses[0]
+        return stats[0]
+
+    def FastEstimatePose(self, _previous_frame, _current_frame):
+        """include/Tracker.h:124 — the vectorised prototype's schedule (levels PYRAMID_LEVELS-1 .. 0, <= 50 iterations,
+        gain 50; src/Tracker.cpp:877-885, 1082) over EstimatePose's per-point terms.  The reference body is broken
+        (residual ignores the warp :933-944, Jw1 column 0 zeroed :986) and is not reproduced."""
+        a, b = self._bind(_previous_frame), self._bind(_current_frame)
+        if not _previous_frame.obtained_gradients_:
+            raise RuntimeError("ApplyGradient(previous_frame) must run before FastEstimatePose (or its slot was reused since)")
+        keys = ("first_level", "last_level", "max_iters", "gain", "epsilon", "z_factor", "angle_factor", "early_exit", "handoff_scale_t")
+        saved = {k: getattr(self._ctx.params, k) for k in keys}
+        self._ctx.update_params(first_level=self._ctx.params.n_levels - 1, last_level=0, max_iters=50, gain=50.0, epsilon=0.001,
+                                z_factor=1.0, angle_factor=1.0, early_exit=1, handoff_scale_t=0)
+        try:
+            poses, stats = self._ctx.estimate_pose_batch([a], [b], raise_on_pair_failure=True)
+        finally:
+            self._ctx.update_params(**saved)
         _previous_frame.rigid_transformation_ = poses[0]
         return stats[0]
 
@@ -114,6 +147,8 @@ class Tracker:
     def EstimatePoseFeatures(self, _previous_frame, _current_frame):
         """src/Tracker.cpp:632-872 — the reference's live variant (constants :634-640, :834, :856)."""
         a, b = self._bind(_previous_frame), self._bind(_current_frame)
+        if not _previous_frame.obtained_gradients_:
+            raise RuntimeError("ApplyGradient(previous_frame) must run before EstimatePoseFeatures (or its slot was reused since)")
         saved = {k: getattr(self._ctx.params, k) for k in ("first_level", "last_level", "max_iters", "gain", "z_factor",
                                                             "angle_factor", "handoff_scale_t", "early_exit")}
         self._ctx.update_params(first_level=0, last_level=0, max_iters=10, gain=1.0, z_factor=0.002, angle_factor=1.0,
@@ -150,14 +185,19 @@ class Tracker:
 
 
 class LS:
-    """include/LeastSquares.h:26-50 over the GPU reduction: rows are buffered by update() and folded by finish()."""
+    """include/LeastSquares.h:26-50 over the GPU reduction: rows are buffered by update() / updateSSE() and folded by
+    finish*() — scalar rows through uwt_ls_accumulate, 4-wide rows through uwt_ls_accumulate_sse (the two forms associate
+    their products differently, src/LeastSquares.cpp:151-153 vs :205), the two added as finishNoDivide adds the lane sums
+    onto A, b, error (:39-139)."""
 
-    def __init__(self, ctx):
+    def __init__(self, ctx, count_quirk=True):
         self._ctx = ctx
+        self.count_quirk = count_quirk          # "num_constraints += 6" per updateSSE call (src/LeastSquares.cpp:201)
         self.initialize(0)
 
     def initialize(self, max_num_constraints):
         self._J, self._r, self._w = [], [], []
+        self._J4, self._r4, self._w4 = [], [], []
         self.A = np.zeros((6, 6), np.float32)
         self.b = np.zeros(6, np.float32)
         self.error = 0.0
@@ -168,10 +208,26 @@ class LS:
         self._r.append(res)
         self._w.append(weight)
 
+    def updateSSE(self, J1, J2, J3, J4, J5, J6, res, weight):
+        """Four points at once; J1..J6 hold Jacobian component k of the four points (include/LeastSquares.h:42-43)."""
+        Jc = np.stack([np.asarray(x, np.float32).reshape(4) for x in (J1, J2, J3, J4, J5, J6)])   # 6 x 4
+        self._J4.append(Jc.T.copy())                                                              # 4 rows of 6
+        self._r4.append(np.asarray(res, np.float32).reshape(4))
+        self._w4.append(np.asarray(weight, np.float32).reshape(4))
+
     def _fold(self, divide):
-        J = np.stack(self._J) if self._J else np.zeros((0, 6), np.float32)
-        self.A, self.b, self.error, self.num_constraints = self._ctx.ls_accumulate(
-            J, np.array(self._r, np.float32), np.array(self._w, np.float32), divide)
+        A = np.zeros((6, 6), np.float32); b = np.zeros(6, np.float32); err = np.float32(0); n = 0
+        if self._r:
+            A1, b1, e1, n1 = self._ctx.ls_accumulate(np.stack(self._J), np.array(self._r, np.float32), np.array(self._w, np.float32), False)
+            A, b, err, n = A + A1, b + b1, np.float32(err + np.float32(e1)), n + n1
+        if self._r4:
+            A2, b2, e2, n2 = self._ctx.ls_accumulate_sse(np.concatenate(self._J4), np.concatenate(self._r4), np.concatenate(self._w4),
+                                                         False, self.count_quirk)
+            A, b, err, n = A + A2, b + b2, np.float32(err + np.float32(e2)), n + n2
+        if divide and n:
+            fn = np.float32(n)
+            A, b, err = A / fn, b / fn, np.float32(err / fn)
+        self.A, self.b, self.error, self.num_constraints = A.astype(np.float32), b.astype(np.float32), float(err), n
 
     def finishNoDivide(self):
         self._fold(False)
