@@ -133,6 +133,32 @@ def test_robust_weights_at_640x480_with_depth(capi, O, synth, mode):
     ctx.close()
 
 
+def test_per_stage_weighted_entry_on_a_level_larger_than_the_record_budget_assumed(capi, O, synth):
+    """1920x1088: the create-time slicing is coarser than the per-stage dump's 8192 pixels per record, so the dump has to
+    follow it (it used to need 255 records where 146 were allocated)."""
+    w, h = 1920, 1088
+    intr = (1500.0, 1500.0, 959.5, 543.5)
+    over = dict(n_levels=1, first_level=0, last_level=0, max_iters=2, early_exit=0, weights=2)
+    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, **over))
+    ref, tgt, _, _, _ = synth.render_pair(w, h, *intr, seed=77)
+    ctx.upload_frames(0, np.stack([ref, tgt]))
+    ctx.build_pyramids(0, 2)
+    ctx.apply_gradient(0, 2)
+    p = O.default_params(w, h, *intr, **over)
+    L = O.level_intrinsics(p, 0)
+    gx, gy = O.scharr3(ref)
+    pts = O.dense_points(None, w, h, 0)
+    pose = O.se3_exp(np.array([0.004, -0.003, 0.002, 0.001, -0.002, 0.003], np.float32))
+    wp = O.warp(pts, pose, L)
+    J, r, idx = O.residual_jacobian_ex(ref, tgt, gx, gy, pts, wp, L, sampler=0)
+    W = O.huber_weights(r)
+    A_ref, b_ref = O.normal_equations(J, r, W, 50.0)
+    out = ctx.residual_jacobian_weighted(0, 1, 0, pose)
+    assert out["n_valid"] == len(idx)
+    assert np.array_equal(out["A"].astype(np.float32), A_ref) and np.array_equal((-out["jtr"]).astype(np.float32), b_ref)
+    ctx.close()
+
+
 # ------------------------------------------------------------------ launch paths of bench.py
 
 def _run(cmd, extra_env=None, timeout=540):

@@ -340,8 +340,14 @@ int launch_general(uwt_ctx* c, const ResidualArgs& ra, int n_pairs) {
 int launch_general_dump(uwt_ctx* c, ResidualArgs ra, int n_pairs) {
   const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f);
   GeneralArgs ga = general_args(c);
-  ra.groups_per_block = kBlock * 32;
+  // pixels per record: 8192, or more where the level's create-time slicing (whose record count sized `partials`) is
+  // coarser than that — very large levels, where init raises the groups per thread to stay under kStageSlices
+  int lvl = 0;
+  while (lvl + 1 < c->p.n_levels && c->lv[lvl].n != ra.L.n) lvl++;
+  const int per_slice = (ra.L.n + c->slices[lvl] - 1) / c->slices[lvl];
+  ra.groups_per_block = std::max(kBlock * 32, (per_slice + kBlock - 1) / kBlock * kBlock);
   ra.slices = (ra.L.n + ra.groups_per_block - 1) / ra.groups_per_block;
+  if ((size_t)ra.slices * n_pairs > c->partial_records) return fail(c, UWT_ERR_CAPACITY, "per-stage dump needs more partial records than the context holds");
   const dim3 grid(ra.slices, n_pairs), blk(kBlock);
   if (ga.weights) {
     HIPCHK(c, hipMemsetAsync(c->hist + (size_t)ra.pair_base * kHistBins, 0, sizeof(unsigned int) * kHistBins * n_pairs, c->stream));
