@@ -59,6 +59,8 @@ struct uwt_ctx {
   long long busy_seq[kDeps] = {};
   bool busy_dropped = false, fresh_dropped = false;
   uint32_t* partials = nullptr;
+  uint32_t* partials2 = nullptr;        // the other parity of the chained (k_iterate) flow
+  PairState* state2 = nullptr;
   size_t partial_records = 0;
   float* d_poses = nullptr;
   StatsOut* d_stats = nullptr;
@@ -70,6 +72,8 @@ struct uwt_ctx {
   void* scratch = nullptr;              // per-stage entry points
   size_t scratch_bytes = 0;
   bool profiling = false;
+  int chained = -1;                     // -1: chained flow for n_pairs <= 2; UWT_CHAINED=1 / 0: always / never (A/B runs)
+  const uint32_t* prof_records = nullptr;
   bool compute_only = false;            // uwt_profile_enable(ctx, 2): residual launches run their no-memory diagnostic twin
   std::vector<hipEvent_t> ev_pool;      // start/stop pairs
   size_t ev_used = 0;
@@ -82,7 +86,7 @@ struct uwt_ctx {
 namespace {
 
 // x VEC pixels per thread at the finest slicing, the one a single pair runs with: short blocks, as many as the fold of
-// k_gn_update stages in LDS (kStageSlices).  One pair at 640x480: 150 level-0 blocks of 8 pixels per thread — 0.60 ms per
+// k_gn_update stages in LDS (kMaxSlices).  One pair at 640x480: 150 level-0 blocks of 8 pixels per thread — 0.60 ms per
 // 4 x 10 alignment against 0.75 ms with 8 groups per thread; batches coarsen the slicing in enqueue_estimate.  The f64
 // partial sums group differently with the slicing — 1e-16 relative, far below the f32 rounding of A and b.
 constexpr int kGroupsPerThread = 2;
@@ -337,17 +341,18 @@ int launch_general(uwt_ctx* c, const ResidualArgs& ra, int n_pairs) {
 }
 
 // The per-stage (dump-capable) form of the same evaluation: k_residual_general, one pixel per thread step.
-int launch_general_dump(uwt_ctx* c, ResidualArgs ra, int n_pairs) {
+int launch_general_dump(uwt_ctx* c, ResidualArgs ra, int n_pairs, int* slices_out = nullptr) {
   const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f);
   GeneralArgs ga = general_args(c);
   // pixels per record: 8192, or more where the level's create-time slicing (whose record count sized `partials`) is
-  // coarser than that — very large levels, where init raises the groups per thread to stay under kStageSlices
+  // coarser than that — very large levels, where init raises the groups per thread to stay under kMaxSlices
   int lvl = 0;
   while (lvl + 1 < c->p.n_levels && c->lv[lvl].n != ra.L.n) lvl++;
   const int per_slice = (ra.L.n + c->slices[lvl] - 1) / c->slices[lvl];
   ra.groups_per_block = std::max(kBlock * 32, (per_slice + kBlock - 1) / kBlock * kBlock);
   ra.slices = (ra.L.n + ra.groups_per_block - 1) / ra.groups_per_block;
   if ((size_t)ra.slices * n_pairs > c->partial_records) return fail(c, UWT_ERR_CAPACITY, "per-stage dump needs more partial records than the context holds");
+  if (slices_out) *slices_out = ra.slices;
   const dim3 grid(ra.slices, n_pairs), blk(kBlock);
   if (ga.weights) {
     HIPCHK(c, hipMemsetAsync(c->hist + (size_t)ra.pair_base * kHistBins, 0, sizeof(unsigned int) * kHistBins * n_pairs, c->stream));
@@ -378,9 +383,127 @@ UpdateArgs update_args(uwt_ctx* c, int lvl) {
   return ua;
 }
 
+// k_iterate launch for the dense nearest-neighbour / identity-weights path (VEC = 4)
+template <bool DEPTH, bool UNIT>
+void launch_iterate_t(hipStream_t s, const ResidualArgs& a, const IterArgs& ia, int n_pairs, bool acc64, bool compute_only) {
+  const dim3 grid(a.slices, n_pairs), blk(kBlock);
+  const bool square = a.L.fx == a.L.fy;
+  if (acc64 && square && UNIT && compute_only) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, true, true>), grid, blk, 0, s, a, ia);
+  else if (acc64 && square && UNIT) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, true>), grid, blk, 0, s, a, ia);
+  else if (acc64) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, false>), grid, blk, 0, s, a, ia);
+  else hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, float, false>), grid, blk, 0, s, a, ia);
+}
+
+int launch_iterate(uwt_ctx* c, const ResidualArgs& a, const IterArgs& ia, int n_pairs) {
+  const bool depth = c->p.has_depth != 0, unit = (a.zf == 1.0f && a.af == 1.0f), acc64 = c->p.accumulate_f64 != 0;
+  if (depth && unit) launch_iterate_t<true, true>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
+  else if (depth) launch_iterate_t<true, false>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
+  else if (unit) launch_iterate_t<false, true>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
+  else launch_iterate_t<false, false>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
+// The chained form of Tracker::EstimatePose for a batch (dense points, nearest-neighbour sampler, identity weights, level
+// widths divisible by 4): one k_iterate launch per iteration — each block first applies the update of the previous
+// evaluation (and the level hand-off when a level begins), then evaluates — and one k_finish at the end; levels x
+// iterations + 1 launches instead of 2 x levels x iterations + levels + 2.
+int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats, const hipEvent_t* level_ready) {
+  const uwt_params& p = c->p;
+  uint32_t* recs[2] = {c->partials, c->partials2};
+  PairState* states[2] = {c->state, c->state2};
+  int rp = 0, sp = 0;            // parity of the records / states the NEXT launch writes
+  IterArgs ia;
+  std::memset(&ia, 0, sizeof(ia));
+  ia.u.max_iters = p.max_iters;
+  ia.u.early_exit = p.early_exit;
+  ia.u.epsilon = p.epsilon;
+  ia.u.gain = p.gain;
+  ia.scale_t = p.handoff_scale_t;
+  ia.initial_error = p.initial_error;
+  bool first = true;
+  int prev_slices = 0, prev_k = 0, prev_lvl = p.first_level;
+  for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
+    if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(c->stream, level_ready[lvl], 0));  // its gradients
+    ResidualArgs ra = residual_args(c, lvl);
+    ra.state = nullptr;
+    {  // slicing follows the batch, as in enqueue_estimate
+      const int n_groups = c->lv[lvl].n / c->vec;
+      int want = (c->target_blocks + n_pairs - 1) / n_pairs;
+      want = std::max(1, std::min(want, c->slices[lvl]));
+      const int gpt = (n_groups + want * kBlock - 1) / (want * kBlock);
+      ra.groups_per_block = gpt * kBlock;
+      ra.slices = (n_groups + ra.groups_per_block - 1) / ra.groups_per_block;
+    }
+    int next_poll = 2;
+    int k = 0;
+    for (; k < p.max_iters; k++) {
+      ia.mode = first ? 0 : (k == 0 ? 2 : 1);
+      ia.u.partials = recs[rp ^ 1];
+      ia.u.slices = prev_slices;
+      ia.u.k = prev_k;
+      ia.prev_lvl = prev_lvl;
+      ia.state_in = states[sp ^ 1];
+      ia.state_out = states[sp];
+      ra.partials = recs[rp];
+      // the update inside launch k belongs to evaluation k - 1: a poll at launch k sees what the separate-kernel flow saw
+      // after its update k - 1
+      const bool poll = p.early_exit && k == next_poll && k < p.max_iters;
+      ia.u.active = poll ? c->d_active : nullptr;
+      if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
+      size_t ev = 0;
+      if (c->profiling) {
+        int st = prof_begin(c, &ev);
+        if (st) return st;
+        ra.probe = 1;
+        c->prof_slices = ra.slices;
+        c->prof_pairs = n_pairs;
+        c->prof_records = recs[rp];
+      }
+      int st = launch_iterate(c, ra, ia, n_pairs);
+      if (st) return st;
+      if (c->profiling) {
+        HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
+        c->prof_launches += 1;
+        c->prof_pixels += (long long)n_pairs * c->lv[lvl].n;
+      }
+      first = false;
+      prev_slices = ra.slices;
+      prev_k = k;
+      prev_lvl = lvl;
+      rp ^= 1;
+      sp ^= 1;
+      if (poll) {  // reference-mode early exit: stop launching once every pair has left this level
+        HIPCHK(c, hipMemcpyAsync(c->h_active, c->d_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*c->h_active == 0) { k++; break; }
+        next_poll *= 2;
+      }
+    }
+  }
+  // the last evaluation's update, the last level's hand-off, results
+  ia.mode = 2;
+  ia.u.partials = recs[rp ^ 1];
+  ia.u.slices = prev_slices;
+  ia.u.k = prev_k;
+  ia.u.active = nullptr;
+  ia.prev_lvl = prev_lvl;
+  ia.state_in = states[sp ^ 1];
+  ia.state_out = c->state;      // the final state always lands in the primary buffer
+  if (ia.state_in == ia.state_out) ia.state_out = c->state2;
+  hipLaunchKernelGGL(k_finish, dim3(n_pairs), dim3(kUpdateBlock), 0, c->stream, ia, d_poses, d_stats);
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
 // Tracker::EstimatePose for a batch, enqueued on the context's stream (src/Tracker.cpp:362-597)
 int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats, const hipEvent_t* level_ready = nullptr) {
   const uwt_params& p = c->p;
+  // The chained flow pays where an alignment is bound by kernel boundaries and dependent round trips, not by arithmetic: a
+  // pair or two on their own (the drop-in call).  In a batch every block would repeat its pair's update (UWT_CHAINED=1 / 0
+  // force it on / off for A/B runs).
+  if (c->vec == 4 && p.sampler == 0 && p.weights == 0 && (c->chained > 0 || (c->chained < 0 && n_pairs <= 2)))
+    return enqueue_estimate_chained(c, n_pairs, d_poses, d_stats, level_ready);
   const int tb = 128;
   hipLaunchKernelGGL(k_init_state, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs,
                      p.initial_error);
@@ -412,6 +535,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
           ra.probe = 1;
           c->prof_slices = ra.slices;
           c->prof_pairs = n_pairs;
+          c->prof_records = c->partials;
         }
         int st = general ? launch_general(c, ra, n_pairs) : launch_residual(c, ra, n_pairs, false);
         if (st) return st;
@@ -592,7 +716,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   size_t max_slices = 1;
   for (int l = 0; l < p->n_levels; l++) {
     const int n_groups = c->lv[l].n / c->vec;
-    int gpt = std::max(kGroupsPerThread, (n_groups + kStageSlices * kBlock - 1) / (kStageSlices * kBlock));
+    int gpt = std::max(kGroupsPerThread, (n_groups + kMaxSlices * kBlock - 1) / (kMaxSlices * kBlock));
     if (const char* e = std::getenv("UWT_GROUPS_PER_THREAD")) gpt = std::max(1, std::atoi(e));  // tuning experiments only
     c->groups_per_block[l] = kBlock * gpt;
     c->slices[l] = (n_groups + c->groups_per_block[l] - 1) / c->groups_per_block[l];
@@ -622,6 +746,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
   for (int l = 0; l < UWT_MAX_LEVELS; l++) CREATE_CHK(hipEventCreateWithFlags(&c->ev_level[l], hipEventDisableTiming));
   if (const char* e = std::getenv("UWT_OVERLAP_GRAD")) c->overlap_gradients = std::atoi(e) != 0;
+  if (const char* e = std::getenv("UWT_CHAINED")) c->chained = std::atoi(e) != 0 ? 1 : 0;
   for (int l = 0; l < p->n_levels; l++) {
     const size_t n = (size_t)c->lv[l].n * p->max_frames;
     CREATE_CHK(hipMalloc((void**)&c->img[l], n + 4096));
@@ -633,6 +758,8 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_ref, sizeof(int) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_tgt, sizeof(int) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->partials, c->partial_records * kRecWords * sizeof(uint32_t)));
+  CREATE_CHK(hipMalloc((void**)&c->partials2, c->partial_records * kRecWords * sizeof(uint32_t)));
+  CREATE_CHK(hipMalloc((void**)&c->state2, sizeof(PairState) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_poses, sizeof(float) * 7 * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_stats, sizeof(StatsOut) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_active, sizeof(int)));
@@ -666,6 +793,8 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->d_ref) (void)hipFree(c->d_ref);
   if (c->d_tgt) (void)hipFree(c->d_tgt);
   if (c->partials) (void)hipFree(c->partials);
+  if (c->partials2) (void)hipFree(c->partials2);
+  if (c->state2) (void)hipFree(c->state2);
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stats) (void)hipFree(c->d_stats);
   if (c->d_active) (void)hipFree(c->d_active);
@@ -1026,7 +1155,7 @@ int uwt_profile_clock(uwt_ctx* c, double* shader_ghz) {
   double cyc = 0.0, sec = 0.0;
   for (int p = 0; p < n; p++) {  // slice 0 of the first pairs of the last profiled launch
     uint32_t w[2];
-    HIPCHK(c, hipMemcpy(w, c->partials + ((size_t)p * c->prof_slices) * kRecWords + 60, sizeof(w), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(w, (c->prof_records ? c->prof_records : c->partials) + ((size_t)p * c->prof_slices) * kRecWords + 60, sizeof(w), hipMemcpyDeviceToHost));
     cyc += (double)w[0];
     sec += (double)w[1] * 1e-8;  // s_memrealtime: 100 MHz
   }
@@ -1172,9 +1301,9 @@ int uwt_residual_jacobian_weighted(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slo
   a.dumpR = a.dumpJ + 6 * n;
   a.dumpW = a.dumpR + n;
   a.dumpV = (uint8_t*)(a.dumpW + n);
-  st = launch_general_dump(c, a, 1);
+  int slices = 0;
+  st = launch_general_dump(c, a, 1, &slices);
   if (st) return st;
-  const int slices = (int)((n + kBlock * 32 - 1) / (kBlock * 32));
   std::vector<uint32_t> recs((size_t)slices * kRecWords);
   HIPCHK(c, hipMemcpyAsync(recs.data(), c->partials, recs.size() * 4, hipMemcpyDeviceToHost, c->stream));
   PairScale sc;

@@ -23,6 +23,7 @@ namespace uwt {
 constexpr int kBlock = 256;
 constexpr int kAccFloats = 27;   // 21 upper-triangle JᵀJ + 6 Jᵀr
 constexpr int kRecWords = 64;    // one partial record (256 B): 27 f64 | n_valid u32 @ word 54 | Σr² u64 @ words 56-57
+constexpr int kMaxSlices = 160;  // slices per pair and level at most (a 1280x960 level 0 has 150 at 2 groups per thread)
 
 struct LevelK {
   int w, h, n;
@@ -459,14 +460,19 @@ __device__ __forceinline__ void accumulate_weighted(AccT acc[kAccFloats], AccT& 
 // the exact sums the reference's double-accumulating gemm produces (src/Tracker.cpp:560-561).
 // Stage 1 transposes 29 rows x 256 threads into LDS; stage 2: 232 threads each fold 32 columns; stage 3: 29
 // threads fold the 8 segment sums and write the 256-B record.
+// The LDS image of the reduction, carved out of a raw buffer so that a kernel can reuse the same bytes for another phase:
+// red[14][256] AccT | redi[2][256] u32 | seg_f[28][8] f64 | seg_u[2][8] u64  (sized for AccT = double)
+constexpr int kReduceLdsBytes = 14 * kBlock * 8 + 2 * kBlock * 4 + (kAccFloats + 1) * 8 * 8 + 2 * 8 * 8;   // 32640
+
 template <typename AccT, bool HAS_EXTRA = false>
-__device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], uint32_t sum_r2, uint32_t n_valid,
-                                                   uint32_t* __restrict__ rec, AccT extra = (AccT)0) {
+__device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict__ lds, const AccT acc[kAccFloats],
+                                                      uint32_t sum_r2, uint32_t n_valid, uint32_t* __restrict__ rec,
+                                                      AccT extra = (AccT)0) {
   constexpr int kPass = 14;  // accumulators per LDS pass (2 passes; keeps the f64 image under 29 KB per block)
-  __shared__ AccT red[kPass][kBlock];
-  __shared__ uint32_t redi[2][kBlock];
-  __shared__ double seg_f[kAccFloats + 1][8];
-  __shared__ unsigned long long seg_u[2][8];
+  AccT(*red)[kBlock] = reinterpret_cast<AccT(*)[kBlock]>(lds);
+  uint32_t(*redi)[kBlock] = reinterpret_cast<uint32_t(*)[kBlock]>(lds + kPass * kBlock * 8);
+  double(*seg_f)[8] = reinterpret_cast<double(*)[8]>(lds + kPass * kBlock * 8 + 2 * kBlock * 4);
+  unsigned long long(*seg_u)[8] = reinterpret_cast<unsigned long long(*)[8]>(lds + kPass * kBlock * 8 + 2 * kBlock * 4 + (kAccFloats + 1) * 8 * 8);
   const int tid = threadIdx.x;
   const int v = tid >> 3, seg = tid & 7;
   redi[0][tid] = n_valid;
@@ -512,6 +518,13 @@ __device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], u
     for (int k = 1; k < 8; k++) s += seg_f[kAccFloats][k];
     reinterpret_cast<double*>(rec)[29] = s;  // Σ r·(r·w): the error numerator when residuals are not integers / weighted
   }
+}
+
+template <typename AccT, bool HAS_EXTRA = false>
+__device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], uint32_t sum_r2, uint32_t n_valid,
+                                                   uint32_t* __restrict__ rec, AccT extra = (AccT)0) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kReduceLdsBytes];
+  block_reduce_store_at<AccT, HAS_EXTRA>(lds, acc, sum_r2, n_valid, rec, extra);
 }
 
 // robust weights / bilinear sampler shared by the dense kernels and the general (dump-capable) kernel
@@ -666,6 +679,22 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
 
 // COMPUTE_ONLY (diagnostic, uwt_profile_enable(ctx, 2)): the same instruction stream with every load of the loop replaced
 // by register arithmetic — results are meaningless, its duration is the kernel's own instruction-issue floor.
+// residual_core evaluates one slice of one pair at `pose`; `lds` (optional) is the caller's buffer for the block reduction.
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
+          bool COMPUTE_ONLY = false, bool EXT_LDS = false>
+__device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
+                                              unsigned char* lds, const RefGroup<VEC>* first = nullptr);
+
+// the reference planes of the first group of (pair, slice) for this thread: what residual_core loads before anything else
+template <int VEC, bool DEPTH, bool COMPUTE_ONLY>
+__device__ __forceinline__ void load_first_group(RefGroup<VEC>& rg, const ResidualArgs& a, int pair, int slice) {
+  const size_t ref_off = (size_t)a.ref_slots[pair] * a.L.n;
+  const int n_groups = a.L.n / VEC;
+  const int g = slice * a.groups_per_block + (int)threadIdx.x;
+  load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, a.img + ref_off, a.gx + ref_off, a.gy + ref_off, DEPTH ? a.depth + ref_off : nullptr,
+                                       (uint32_t)min(g, n_groups - 1) * VEC);
+}
+
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
           bool COMPUTE_ONLY = false>
 __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int pair, const int slice) {
@@ -679,6 +708,13 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   } else {
     pose = a.pose;
   }
+  residual_core<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, slice, pose, nullptr);
+}
+
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
+          bool EXT_LDS>
+__device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
+                                              unsigned char* lds, const RefGroup<VEC>* first) {
   WarpK K;
   pose_to_T12(pose, K.T);
 #pragma unroll
@@ -718,7 +754,8 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   // are needed last, for the residuals).
   RefGroup<VEC> rg;
   int g = g_begin + (int)threadIdx.x;
-  load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
+  if (first) rg = *first;   // requested by the caller ahead of the pose (k_iterate: before the update)
+  else load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
   // Pixel coordinates of the thread's group, as floats (small integers: exact).  One division up front, then each step
   // of kBlock groups moves (x, y) by the level's fixed (step mod w, step / w) with at most one wrap.  Lanes past the end
   // of the level run on with coordinates outside the image; they are inactive and every term of theirs is discarded.
@@ -828,7 +865,9 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
     yf += wrap ? 1.f : 0.f;
   }
   const uint32_t n_valid = (threadIdx.x & 63) == 0 ? n_valid_wave : 0u;
-  block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + slice) * kRecWords, err);
+  uint32_t* out_rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
+  if constexpr (EXT_LDS) block_reduce_store_at<AccT, GENERAL>(lds, acc, sum_r2, n_valid, out_rec, err);
+  else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err);
   if (a.probe && threadIdx.x == 0) {
     uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
     rec[60] = (uint32_t)(__builtin_amdgcn_s_memtime() - clk0);
@@ -1119,9 +1158,11 @@ __global__ __launch_bounds__(kBlock) void k_residual_general(const ResidualArgs 
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// k_gn_update: one wave per pair.  Lanes 0..26 fold the block partials of one accumulator in slice order in
-// f64; lane 0 then runs the scalar tail of the iteration: error (src/Tracker.cpp:499-502), exit test (:508),
-// A/b (:554-561), A.inv()*b (:564), pose <- pose * exp(delta) (:574).
+// The scalar tail of one Gauss-Newton iteration for one pair: fold the block partials of the evaluation in slice order
+// (f64), error (src/Tracker.cpp:499-502), exit test (:508), A/b (:554-561), A.inv()*b (:564), pose <- pose * exp(delta)
+// (:574).  update_compute is executed by a whole 256-thread block and hands every thread the pair's new state; it is
+// the body of k_gn_update (one block per pair) and the first phase of k_iterate (every block of the pair's next
+// evaluation recomputes it — a few microseconds of mostly serial work — instead of waiting for a launch of its own).
 // ------------------------------------------------------------------------------------------------------------
 struct UpdateArgs {
   const uint32_t* partials;
@@ -1137,122 +1178,194 @@ struct UpdateArgs {
   int* active;       // optional: counts the pairs still iterating after this update (early-exit polling)
 };
 
-// Slice order is kept (the f64 sums are order-dependent in the last bit); the loads of kFoldBatch records are issued
-// together so that a level-0 fold (38 slices) costs a few memory round trips instead of one per slice.
-constexpr int kFoldBatch = 8;
-constexpr int kUpdateBlock = 256;   // threads of k_gn_update: four waves stage the records, wave 0 folds, lane 0 solves
-constexpr int kStageSlices = 160;   // 40 KB of LDS: a 1280x960 level 0 has 150 slices
+constexpr int kUpdateBlock = 256;   // threads of an updating block: all stage the records, wave 0 folds and solves
+constexpr int kStageRecords = 128;  // records staged in LDS per round (32 KB); more slices take more rounds
+constexpr int kUpdateLdsBytes = kStageRecords * kRecWords * 4 + 512;   // + sums, integer sums, the state to broadcast
 
-template <typename T>
-__device__ __forceinline__ void fold_column(const T* __restrict__ col, int slices, T& sum) {
-  constexpr int kStride = kRecWords * 4 / (int)sizeof(T);  // record stride in units of T
-  int s = 0;
-  for (; s + kFoldBatch <= slices; s += kFoldBatch) {
-    T v[kFoldBatch];
-#pragma unroll
-    for (int u = 0; u < kFoldBatch; u++) v[u] = col[(size_t)(s + u) * kStride];
-#pragma unroll
-    for (int u = 0; u < kFoldBatch; u++) sum += v[u];
-  }
-  for (; s < slices; s++) sum += col[(size_t)s * kStride];
-}
-
-__device__ inline void fold_partials(const uint32_t* __restrict__ recs, int slices, int lane, double& colsum,
-                                     long long& isum) {
-  colsum = 0.0;
-  isum = 0;
-  if (lane < kAccFloats || lane == 29) {
-    fold_column(reinterpret_cast<const double*>(recs) + lane, slices, colsum);
-  } else if (lane == 27) {
-    uint32_t n = 0;
-    fold_column(recs + 54, slices, n);   // n_valid <= level pixels < 2^32
-    isum = n;
-  } else if (lane == 28) {
-    fold_column(reinterpret_cast<const long long*>(recs) + 28, slices, isum);
-  }
-}
-
-// The scalar tail of one GN iteration for one pair, executed by one wave.
-__device__ __forceinline__ void update_block(const UpdateArgs& a, const int pair) {
-  const int lane = threadIdx.x;
-  __shared__ double sums[kAccFloats + 1];
-  __shared__ long long isums[2];
-  PairState st = a.state[pair];
+__device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const uint32_t* __restrict__ recs, PairState st,
+                                                    unsigned char* __restrict__ lds, bool count_active) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  uint4* stage = reinterpret_cast<uint4*>(lds);
+  double* sums = reinterpret_cast<double*>(lds + kStageRecords * kRecWords * 4);          // [kAccFloats + 1]
+  long long* isums = reinterpret_cast<long long*>(sums + kAccFloats + 1);               // [2]
+  PairState* s_state = reinterpret_cast<PairState*>(isums + 2);
   const bool live = !(st.level_done || st.status);  // block-uniform
-  const uint32_t* recs = a.partials + (size_t)pair * a.slices * kRecWords;
-  // All waves of the block pull the pair's records into LDS with one batch of independent 16-byte loads (one memory
-  // round trip for a 640x480 level 0); the fold below then runs in the same slice order out of LDS.
-  __shared__ uint4 stage[kStageSlices * (kRecWords / 4)];
-  const bool staged = a.slices <= kStageSlices;  // block-uniform
-  if (live && staged) {
-    const int n16 = a.slices * (kRecWords / 4);
-    const uint4* g4 = reinterpret_cast<const uint4*>(recs);
-    for (int base = 0; base < n16; base += 4 * kUpdateBlock) {
-      uint4 v[4];
+  if (live) {
+    // The records travel through LDS in rounds of kStageRecords: every thread pulls a batch of independent 16-byte loads
+    // (one memory round trip per round), then the lanes of wave 0 add their column in slice order — the order of the
+    // sums is the slice order whatever the round size.
+    double cs = 0.0;
+    long long is = 0;
+    for (int base = 0; base < a.slices; base += kStageRecords) {
+      const int cnt = min(kStageRecords, a.slices - base);
+      const int n16 = cnt * (kRecWords / 4);
+      const uint4* g4 = reinterpret_cast<const uint4*>(recs + (size_t)base * kRecWords);
+      if (base) __syncthreads();   // the previous round has been folded
+      for (int i0 = 0; i0 < n16; i0 += 4 * kUpdateBlock) {
+        uint4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = base + u * kUpdateBlock + lane;
-        if (i < n16) v[u] = g4[i];
-      }
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * kUpdateBlock + tid;
+          if (i < n16) v[u] = g4[i];
+        }
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int i = base + u * kUpdateBlock + lane;
-        if (i < n16) stage[i] = v[u];
+        for (int u = 0; u < 4; u++) {
+          const int i = i0 + u * kUpdateBlock + tid;
+          if (i < n16) stage[i] = v[u];
+        }
       }
+      __syncthreads();
+      if (tid < 64) {
+        const uint32_t* r = reinterpret_cast<const uint32_t*>(stage);
+        if (lane < kAccFloats || lane == 29) {
+          const double* col = reinterpret_cast<const double*>(r) + lane;
+          for (int q = 0; q < cnt; q++) cs += col[(size_t)q * (kRecWords / 2)];
+        } else if (lane == 27) {
+          for (int q = 0; q < cnt; q++) is += (long long)r[(size_t)q * kRecWords + 54];   // n_valid <= level pixels < 2^32
+        } else if (lane == 28) {
+          const long long* col = reinterpret_cast<const long long*>(r) + 28;
+          for (int q = 0; q < cnt; q++) is += col[(size_t)q * (kRecWords / 2)];
+        }
+      }
+    }
+    if (tid < 64) {
+      if (lane < kAccFloats) sums[lane] = cs;
+      else if (lane == 27) isums[0] = (long long)(uint32_t)is;
+      else if (lane == 28) isums[1] = is;
+      else if (lane == 29) sums[kAccFloats] = a.general ? cs : 0.0;
     }
   }
   __syncthreads();
-  if (live && lane < 64) {
-    double cs;
-    long long is;
-    if (staged) fold_partials(reinterpret_cast<const uint32_t*>(stage), a.slices, lane, cs, is);
-    else fold_partials(recs, a.slices, lane, cs, is);
-    if (lane < kAccFloats) sums[lane] = cs;
-    else if (lane < 29) isums[lane - 27] = is;
-    else if (lane == 29) sums[kAccFloats] = a.general ? cs : 0.0;
-  }
-  __syncthreads();
-  if (lane >= 64) return;   // wave 0 runs the tail together on the same (uniform) values; lane 0 stores the result
-  if (live) {
-    const int n = (int)isums[0];
-    const long long sr2 = isums[1];
-    st.iters += 1;
-    st.n_valid = n;
-    bool update = true;
-    if (n == 0) {
-      st.status = 2;  // UWT_ERR_NO_VALID_POINTS
-      st.level_done = 1;
-      update = false;
-    } else {
-      const float inv_n = (float)(1.0 / (double)n);                 // src/Tracker.cpp:499
-      const float error = a.general ? (float)((double)inv_n * sums[kAccFloats])   // Σ r·(r·w): float / weighted residuals
-                                    : (float)((double)inv_n * (double)sr2);       // :501, scaled-gemm form (exact integer Σr²)
-      st.error = error;
-      if (a.early_exit &&
-          (error >= st.last_error || a.k == a.max_iters - 1 || fabsf(error - st.last_error) < a.epsilon)) {  // :508
+  if (tid < 64) {   // wave 0 runs the tail together on the same (uniform) values
+    if (live) {
+      const int n = (int)isums[0];
+      const long long sr2 = isums[1];
+      st.iters += 1;
+      st.n_valid = n;
+      bool update = true;
+      if (n == 0) {
+        st.status = 2;  // UWT_ERR_NO_VALID_POINTS
         st.level_done = 1;
         update = false;
       } else {
-        st.last_error = error;  // :529
+        const float inv_n = (float)(1.0 / (double)n);                 // src/Tracker.cpp:499
+        const float error = a.general ? (float)((double)inv_n * sums[kAccFloats])   // Σ r·(r·w): float / weighted residuals
+                                      : (float)((double)inv_n * (double)sr2);       // :501, scaled-gemm form (exact integer Σr²)
+        st.error = error;
+        if (a.early_exit &&
+            (error >= st.last_error || a.k == a.max_iters - 1 || fabsf(error - st.last_error) < a.epsilon)) {  // :508
+          st.level_done = 1;
+          update = false;
+        } else {
+          st.last_error = error;  // :529
+        }
+      }
+      if (update) {
+        float b[6], delta[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+          b[i] = a.general ? (float)(-sums[21 + i]) : (float)(-((double)a.gain * sums[21 + i]));  // :559-561
+        solve_delta_wave(sums, b, delta);                                                // :554-564, A = (float)sums[0..20]
+        Pose d, np;
+        se3_exp_wave(delta, d);                                                         // :574
+        se3_mul(st.pose, d, np);
+        st.pose = np;
+        if (count_active && a.active && lane == 0) atomicAdd(a.active, 1);
       }
     }
-    if (update) {
-      float b[6], delta[6];
-#pragma unroll
-      for (int i = 0; i < 6; i++)
-        b[i] = a.general ? (float)(-sums[21 + i]) : (float)(-((double)a.gain * sums[21 + i]));  // :559-561
-      solve_delta_wave(sums, b, delta);                                                // :554-564, A = (float)sums[0..20]
-      Pose d, np;
-      se3_exp(delta, d);                                                              // :574
-      se3_mul(st.pose, d, np);
-      st.pose = np;
-      if (a.active && lane == 0) atomicAdd(a.active, 1);
-    }
+    if (lane == 0) *s_state = st;
   }
-  if (lane == 0) a.state[pair] = st;
+  __syncthreads();
+  return *s_state;
 }
 
-__global__ __launch_bounds__(kUpdateBlock) void k_gn_update(const UpdateArgs a) { update_block(a, (int)blockIdx.x + a.pair_base); }
+__global__ __launch_bounds__(kUpdateBlock) void k_gn_update(const UpdateArgs a) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kUpdateLdsBytes];
+  const int pair = (int)blockIdx.x + a.pair_base;
+  const PairState st = update_compute(a, a.partials + (size_t)pair * a.slices * kRecWords, a.state[pair], lds, true);
+  if (threadIdx.x == 0) a.state[pair] = st;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_iterate: one launch = one Gauss-Newton iteration of one pyramid level for a whole batch, on the dense
+// nearest-neighbour / identity-weights path.  Every block first brings its pair's state up to date — the update that
+// belongs to the PREVIOUS evaluation (records of the other parity), and the level hand-off when this launch opens a new
+// level — then evaluates its slice at the new pose.  Compared with k_residual + k_gn_update per iteration this halves
+// the launches of an alignment (a pair on its own spends most of its time in kernel boundaries and dependent memory
+// round trips, not in arithmetic) and takes the update's launch out of the batch's critical path.  States and records
+// are double-buffered: blocks of one launch read the previous launch's and write this launch's.
+// ------------------------------------------------------------------------------------------------------------
+struct IterArgs {
+  UpdateArgs u;               // the pending update: u.partials / u.slices / u.k describe the previous evaluation
+  const PairState* state_in;
+  PairState* state_out;
+  int mode;                   // 0: first evaluation of the alignment (fresh state); 1: update, evaluate; 2: update, hand-off, evaluate
+  int prev_lvl;               // level the pending update / hand-off belongs to (mode 2)
+  int scale_t;
+  float initial_error;
+};
+
+__device__ __forceinline__ PairState iterate_state(const IterArgs& ia, int pair, unsigned char* lds, bool count_active) {
+  PairState st;
+  if (ia.mode == 0) {
+    pose_identity(st.pose);  // src/Tracker.cpp:385
+    st.last_error = ia.initial_error;
+    st.error = 0.f;
+    st.level_done = 0;
+    st.status = 0;
+    st.iters = 0;
+    st.n_valid = 0;
+    return st;
+  }
+  st = update_compute(ia.u, ia.u.partials + (size_t)pair * ia.u.slices * kRecWords, ia.state_in[pair], lds, count_active);
+  if (ia.mode == 2) {   // end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
+    if (st.status == 0 && ia.prev_lvl != 0) {
+      if (!se3_handoff(st.pose, ia.scale_t != 0)) st.status = 1;  // SOPHUS_ENSURE would abort
+    }
+    st.level_done = 0;
+    st.last_error = ia.initial_error;
+  }
+  return st;
+}
+
+constexpr int kIterateLdsBytes = kUpdateLdsBytes > kReduceLdsBytes ? kUpdateLdsBytes : kReduceLdsBytes;
+
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, bool COMPUTE_ONLY = false>
+__global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterArgs ia) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kIterateLdsBytes];   // the update's staging, then the reduction's image
+  const int pair = (int)blockIdx.y + a.pair_base, slice = (int)blockIdx.x;
+  // the first group's reference planes do not depend on the pose: their (cold) loads travel while the update runs
+  RefGroup<VEC> first;
+  load_first_group<VEC, DEPTH, COMPUTE_ONLY>(first, a, pair, slice);
+  PairState st = iterate_state(ia, pair, lds, slice == 0);
+  if (slice == 0 && threadIdx.x == 0) ia.state_out[pair] = st;
+  if constexpr (COMPUTE_ONLY) {
+    st.level_done = 0;
+    st.status = 0;
+    pose_identity(st.pose);   // the twin does the full work of every launch, whatever its meaningless sums produced
+  }
+  if (st.level_done || st.status) return;
+  __syncthreads();   // the staging bytes become the reduction's
+  residual_core<VEC, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, COMPUTE_ONLY, true>(a, pair, slice, st.pose, lds, &first);
+}
+
+struct StatsOut { int status, iterations, n_valid; float error; };
+
+// After the last evaluation: its update, the last level's hand-off, and the results (one block per pair).
+__global__ __launch_bounds__(kUpdateBlock) void k_finish(const IterArgs ia, float* __restrict__ poses, StatsOut* __restrict__ stats) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kUpdateLdsBytes];
+  const int pair = (int)blockIdx.x + ia.u.pair_base;
+  const PairState st = iterate_state(ia, pair, lds, true);
+  if (threadIdx.x) return;
+  ia.state_out[pair] = st;
+  for (int k = 0; k < 4; k++) poses[7 * pair + k] = st.pose.q[k];
+  for (int k = 0; k < 3; k++) poses[7 * pair + 4 + k] = st.pose.t[k];
+  if (stats) {
+    StatsOut o;
+    o.status = st.status; o.iterations = st.iters; o.n_valid = st.n_valid; o.error = st.error;
+    stats[pair] = o;
+  }
+}
 
 __global__ void k_set_pose(PairState* state, Pose pose, float initial_error) {
   if (threadIdx.x || blockIdx.x) return;
@@ -1293,8 +1406,6 @@ __global__ void k_level_end(PairState* state, int n, int lvl, int scale_t, float
   st.last_error = initial_error;
   state[i] = st;
 }
-
-struct StatsOut { int status, iterations, n_valid; float error; };
 
 __global__ void k_write_out(const PairState* state, int n, float* poses, StatsOut* stats) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

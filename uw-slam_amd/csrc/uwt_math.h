@@ -70,20 +70,19 @@ __device__ inline void quat_rotate(const float q[4], const float v[3], float o[3
 
 constexpr float kSophusEps = 1e-5f;  // Constants<float>::epsilon, common.hpp:154-158
 
-// SE3f::exp (se3.hpp:723-744) with SO3f::expAndTheta (so3.hpp:534-566); xi = [upsilon, omega]
-__device__ inline void se3_exp(const float xi[6], Pose& out) {
+// SE3f::exp (se3.hpp:723-744) with SO3f::expAndTheta (so3.hpp:534-566); xi = [upsilon, omega].
+// sh, ch = sin, cos of theta / 2 and st, ct = sin, cos of theta, each evaluated in f64 and rounded once (S5).
+__device__ inline void se3_exp_with(const float xi[6], float theta_sq, float theta, float sh, float ch, float st, float ct,
+                                    Pose& out) {
   const float o0 = xi[3], o1 = xi[4], o2 = xi[5];
-  const float theta_sq = o0 * o0 + o1 * o1 + o2 * o2;
-  const float theta = sqrtf(theta_sq);
-  const float half_theta = 0.5f * theta;
   float imag, real;
   if (theta < kSophusEps) {
     const float theta_po4 = theta_sq * theta_sq;
     imag = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * theta_po4;
     real = 1.f - (float)(1.0 / 8.0) * theta_sq + (float)(1.0 / 384.0) * theta_po4;
   } else {
-    imag = sin_r(half_theta) / theta;
-    real = cos_r(half_theta);
+    imag = sh / theta;
+    real = ch;
   }
   out.q[0] = imag * o0; out.q[1] = imag * o1; out.q[2] = imag * o2; out.q[3] = real;
 
@@ -99,8 +98,8 @@ __device__ inline void se3_exp(const float xi[6], Pose& out) {
       for (int j = 0; j < 3; j++)
         Om2[3 * i + j] = (Om[3 * i] * Om[j] + Om[3 * i + 1] * Om[3 + j]) + Om[3 * i + 2] * Om[6 + j];
     const float tsq = theta * theta;
-    const float c1 = (1.f - cos_r(theta)) / tsq;
-    const float c2 = (theta - sin_r(theta)) / (tsq * theta);
+    const float c1 = (1.f - ct) / tsq;
+    const float c2 = (theta - st) / (tsq * theta);
 #pragma unroll
     for (int i = 0; i < 9; i++) {
       const float id = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
@@ -109,6 +108,32 @@ __device__ inline void se3_exp(const float xi[6], Pose& out) {
   }
 #pragma unroll
   for (int i = 0; i < 3; i++) out.t[i] = (V[3 * i] * xi[0] + V[3 * i + 1] * xi[1]) + V[3 * i + 2] * xi[2];
+}
+
+__device__ inline void se3_exp(const float xi[6], Pose& out) {
+  const float theta_sq = xi[3] * xi[3] + xi[4] * xi[4] + xi[5] * xi[5];
+  const float theta = sqrtf(theta_sq);
+  const float half_theta = 0.5f * theta;
+  float sh = 0.f, ch = 1.f, st = 0.f, ct = 1.f;
+  if (!(theta < kSophusEps)) { sh = sin_r(half_theta); ch = cos_r(half_theta); st = sin_r(theta); ct = cos_r(theta); }
+  se3_exp_with(xi, theta_sq, theta, sh, ch, st, ct, out);
+}
+
+// The same on a full wave holding uniform values (the update's tail): the four transcendentals — the longest dependent
+// stretch of the tail — are taken in one pass, lane 0 on theta / 2 and lane 1 on theta, each by the sin and the cos of its
+// own argument, instead of four evaluations one after the other.  Same functions, same results.
+__device__ inline void se3_exp_wave(const float xi[6], Pose& out) {
+  const float theta_sq = xi[3] * xi[3] + xi[4] * xi[4] + xi[5] * xi[5];
+  const float theta = sqrtf(theta_sq);
+  const float half_theta = 0.5f * theta;
+  const int lane = (int)(threadIdx.x & 63u);
+  const float arg = (lane & 1) ? theta : half_theta;
+  const float s = sin_r(arg), c = cos_r(arg);
+  const float sh = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s), 0));
+  const float ch = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(c), 0));
+  const float st = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s), 1));
+  const float ct = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(c), 1));
+  se3_exp_with(xi, theta_sq, theta, sh, ch, st, ct, out);
 }
 
 // SE3f::operator*= (se3.hpp:317-321) and SO3f::operator*= with the 2/(1+|q|²) renormalisation (so3.hpp:338-354)
