@@ -151,7 +151,11 @@ int uwt_estimate_pose_batch(uwt_ctx* ctx, int32_t n_pairs, const int32_t* ref_sl
  * grad_refs_only != 0: the planes the tracker reads of the reference frame only — gradients (src/Tracker.cpp:407-408)
  * and the depth pyramid levels 1.. (:1266-1272) — are built for the pairs' ref_slots alone (wherever they lie);
  * the image pyramids still cover the whole slot range.  0 prepares every frame of the range fully, as
- * System::AddFrame / System::Tracking do for each new frame. */
+ * System::AddFrame / System::Tracking do for each new frame.
+ * Asynchronous with early_exit = 0 (fixed iteration counts: nothing in the call waits for the device).  With
+ * early_exit = 1 — the reference's schedule, uwt_default_params' setting — the call itself waits for the device a few
+ * times per level (after iterations 2, 4, 8, ... it reads back how many pairs are still iterating and stops launching for
+ * a level every pair has left), so it returns only once the last level's first iterations are queued. */
 int uwt_track_batch_async(uwt_ctx* ctx, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only,
                           int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
                           float* d_poses_out, uwt_stats* d_stats_out_or_null);
