@@ -246,6 +246,11 @@ int uwt_gradient_magnitude(uwt_ctx* ctx, int32_t slot, int32_t lvl, uint8_t* mag
  * Writes min(count, cap) points; *count_out is the full count. */
 int uwt_obtain_candidate_points(uwt_ctx* ctx, int32_t slot, int32_t lvl, double threshold, float* pts_out, int32_t cap,
                                 int32_t* count_out);
+/* The same for frames first_slot .. first_slot + n_frames - 1 in one call (many blocks per frame: per-column counts by
+ * row band, an exclusive scan in the reference's x-major order, ordered write).  pts_out: n_frames x cap x 4 floats (frame
+ * f's points start at f * cap * 4), counts_out: n_frames full counts. */
+int uwt_obtain_candidate_points_batch(uwt_ctx* ctx, int32_t first_slot, int32_t n_frames, int32_t lvl, double threshold,
+                                      float* pts_out, int32_t cap, int32_t* counts_out);
 /* Tracker::ObtainPatchesPoints (src/Tracker.cpp:1178-1257): 11x11 level-0 patches around <= 200 key points (x, y). */
 int uwt_obtain_patch_points(uwt_ctx* ctx, int32_t slot, const float* keypoints_xy, int32_t n_keypoints, float* pts_out,
                             int32_t cap, int32_t* count_out);
@@ -279,6 +284,12 @@ int uwt_ingest_frame(uwt_ingest* ing, uwt_ctx* ctx, int32_t slot, const uint8_t*
  * poses: n x 7 host floats (per-pair poses from uwt_estimate_pose_batch); traj_out: n x 7 host floats. */
 int uwt_accumulate_trajectory(uwt_ctx* ctx, const float* poses, int32_t n, const float start_pose[7], float t_scale,
                               int32_t reference_axes, float* traj_out);
+/* The same accumulation as a parallel prefix product (one block: per-thread runs, a scan over the run products, replay).
+ * SE(3) composition is associative; in floats the grouping shows in the last bits, so results agree with the sequential
+ * form to rounding, not bit for bit — the clean default for long trajectories; the reference-visualiser mode
+ * (t_scale 40, reference_axes 1) that has to reproduce src/Visualizer.cpp:304-325 exactly stays sequential. */
+int uwt_accumulate_trajectory_scan(uwt_ctx* ctx, const float* poses, int32_t n, const float start_pose[7], float t_scale,
+                                   int32_t reference_axes, float* traj_out);
 
 #ifdef __cplusplus
 }

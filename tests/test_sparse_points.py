@@ -148,3 +148,31 @@ def test_gpu_estimate_pose_features_flow(capi, O, synth, depth):
     so, pose_cpu, tr = O.align_pair_points(p, ref, tgt, {0: pts_cpu}, ref_depth=dep if depth else None, want_trace=True)
     assert so == 0 and st["status"] == 0 and st["iterations"] == len(tr) and 1 <= len(tr) <= 10
     assert np.array_equal(pose, pose_cpu)
+
+
+@pytest.mark.gpu
+def test_gpu_candidate_points_batch_of_frames_matches_oracle_per_frame(capi, O, synth):
+    """uwt_obtain_candidate_points_batch: many frames, many blocks per frame, the reference's x-major order kept."""
+    w, h, n = 320, 240, 9
+    intr = (262.5, 262.5, 159.5, 119.5)
+    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=n, max_pairs=1, has_depth=1))
+    frames, depths = [], []
+    for s_ in range(n):
+        ref, _, dep, _, _ = synth.render_pair(w, h, *intr, seed=700 + s_, with_depth=True)
+        frames.append(ref); depths.append(dep)
+    ctx.upload_frames(0, np.stack(frames), np.stack(depths))
+    ctx.build_pyramids(0, n)
+    ctx.apply_gradient(0, n)
+    for lvl, thr in ((0, 20.0), (2, 5.0), (4, 0.0)):
+        got, cnt = ctx.obtain_candidate_points_batch(0, n, lvl, thr)
+        for f in range(n):
+            img, dp = frames[f], depths[f]
+            for _ in range(lvl):
+                img, dp = O.halve_u8(img), O.halve_u16(dp)
+            mag = O.gradient_mag(*O.scharr3(img))
+            want, nw = O.candidate_points(mag, dp, thr)
+            assert cnt[f] == nw and np.array_equal(got[f], want), (lvl, f)
+    capped, cnt = ctx.obtain_candidate_points_batch(2, 3, 0, 20.0, cap=50)      # a sub-range of slots, capped output
+    full, cnt2 = ctx.obtain_candidate_points_batch(2, 3, 0, 20.0)
+    assert np.array_equal(cnt, cnt2) and all(np.array_equal(capped[f], full[f][:50]) for f in range(3))
+    ctx.close()

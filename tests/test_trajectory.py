@@ -68,3 +68,29 @@ def test_gpu_trajectory_bit_exact(O):
         b = O.accumulate_trajectory(poses, **kw)
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
     assert ctx.accumulate_trajectory(np.zeros((0, 7), np.float32)).shape == (0, 7)
+
+
+@pytest.mark.gpu
+def test_gpu_trajectory_scan_agrees_with_the_sequential_product():
+    """uwt_accumulate_trajectory_scan: a prefix product regrouped — equal to the sequential accumulation to float rounding;
+    one and two poses (no regrouping possible) bit for bit."""
+    import importlib
+    capi = importlib.import_module("uw-slam_amd.capi")
+    ctx = capi.Context(capi.default_params(64, 48, 64.0, 64.0, 31.5, 23.5, n_levels=3, first_level=2, last_level=0))
+    rng = np.random.default_rng(5)
+    for n in (1, 2, 7, 1024, 1025, 5000):
+        q = rng.normal(0, 0.02, (n, 4)).astype(np.float32); q[:, 3] = 1.0
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        poses = np.concatenate([q, rng.normal(0, 0.01, (n, 3)).astype(np.float32)], axis=1)
+        start = np.array([0.1, -0.2, 0.05, 0.97, 1.0, 2.0, 3.0], np.float32)
+        start[:4] /= np.linalg.norm(start[:4])
+        seq = ctx.accumulate_trajectory(poses, start)
+        par = ctx.accumulate_trajectory(poses, start, scan=True)
+        if n <= 2:
+            assert np.array_equal(seq, par)
+        dq = np.minimum(np.abs(seq[:, :4] - par[:, :4]).max(), np.abs(seq[:, :4] + par[:, :4]).max())
+        assert dq < 2e-5 and np.abs(seq[:, 4:] - par[:, 4:]).max() < 1e-4 * max(1.0, np.abs(seq[:, 4:]).max()), (n, dq)
+        ref = ctx.accumulate_trajectory(poses, start, 40.0, True, scan=True)       # scale and axis permutation in scan form too
+        ref_seq = ctx.accumulate_trajectory(poses, start, 40.0, True)
+        assert np.abs(ref - ref_seq).max() < 1e-3 * max(1.0, np.abs(ref_seq).max())
+    ctx.close()

@@ -48,9 +48,9 @@ SYMBOLS = [
     "uwt_build_pyramids", "uwt_apply_gradient", "uwt_estimate_pose_batch", "uwt_track_batch_async", "uwt_track_batch_host_async", "uwt_wait_ticket", "uwt_sync",
     "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_profile_clock", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
     "uwt_warp", "uwt_residual_jacobian", "uwt_ls_accumulate", "uwt_se3_exp", "uwt_se3_mul", "uwt_se3_matrix",
-    "uwt_se3_handoff", "uwt_solve_delta", "uwt_accumulate_trajectory",
+    "uwt_se3_handoff", "uwt_solve_delta", "uwt_accumulate_trajectory", "uwt_accumulate_trajectory_scan",
     "uwt_residual_jacobian_weighted", "uwt_estimate_pose_points", "uwt_gradient_magnitude",
-    "uwt_obtain_candidate_points", "uwt_obtain_patch_points",
+    "uwt_obtain_candidate_points", "uwt_obtain_candidate_points_batch", "uwt_obtain_patch_points",
     "uwt_ingest_create", "uwt_ingest_destroy", "uwt_ingest_maps", "uwt_ingest_undistort", "uwt_ingest_calculate_roi",
     "uwt_ingest_frame", "uwt_update_params", "uwt_get_params", "uwt_ls_accumulate_sse", "uwt_robust_weights",
 ]
@@ -405,12 +405,14 @@ class Context:
                                         C.byref(ok)))
         return d, Ai.reshape(6, 6), bool(ok.value)
 
-    def accumulate_trajectory(self, poses, start=None, t_scale=1.0, reference_axes=False):
+    def accumulate_trajectory(self, poses, start=None, t_scale=1.0, reference_axes=False, scan=False):
+        """scan=True: the parallel prefix product (equal to the sequential form to float rounding, not bit for bit)."""
         poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 7)
         start = np.array([0, 0, 0, 1, 0, 0, 0], np.float32) if start is None else np.ascontiguousarray(start, np.float32)
         out = np.empty_like(poses)
-        self._chk(lib().uwt_accumulate_trajectory(self._h, _p(poses, C.c_float), poses.shape[0], _p(start, C.c_float),
-                                                  C.c_float(t_scale), int(bool(reference_axes)), _p(out, C.c_float)))
+        fn = lib().uwt_accumulate_trajectory_scan if scan else lib().uwt_accumulate_trajectory
+        self._chk(fn(self._h, _p(poses, C.c_float), poses.shape[0], _p(start, C.c_float), C.c_float(t_scale),
+                     int(bool(reference_axes)), _p(out, C.c_float)))
         return out
 
     def estimate_pose_points(self, ref_slot, tgt_slot, tables):
@@ -454,6 +456,16 @@ class Context:
         self._chk(lib().uwt_obtain_candidate_points(self._h, slot, lvl, C.c_double(threshold), _p(pts, C.c_float), cap,
                                                     C.byref(cnt)))
         return pts[:min(cnt.value, cap)].copy(), cnt.value
+
+    def obtain_candidate_points_batch(self, first_slot, n_frames, lvl, threshold=20.0, cap=None):
+        """Returns (list of [count_f, 4] arrays, counts)."""
+        L = self.level_info(lvl)
+        cap = L.w * L.h if cap is None else cap
+        pts = np.empty((n_frames, max(cap, 1), 4), np.float32)
+        cnt = np.zeros(n_frames, np.int32)
+        self._chk(lib().uwt_obtain_candidate_points_batch(self._h, first_slot, n_frames, lvl, C.c_double(threshold), _p(pts, C.c_float),
+                                                          cap, _p(cnt, C.c_int32)))
+        return [pts[f, :min(int(cnt[f]), cap)].copy() for f in range(n_frames)], cnt
 
     def obtain_patch_points(self, slot, keypoints, cap=200 * 144):
         kp = np.ascontiguousarray(keypoints, np.float32).reshape(-1, 2)

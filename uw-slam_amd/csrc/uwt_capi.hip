@@ -1552,37 +1552,61 @@ int uwt_gradient_magnitude(uwt_ctx* c, int32_t slot, int32_t lvl, uint8_t* mag_o
   return UWT_OK;
 }
 
+int uwt_obtain_candidate_points_batch(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int32_t lvl, double threshold,
+                                      float* pts_out, int32_t cap, int32_t* counts_out) {
+  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
+  if (!c || !counts_out || cap < 0 || (cap > 0 && !pts_out) || n_frames < 1 || !slot_range_ok(c, first_slot, n_frames) || lvl < 0 ||
+      lvl >= c->p.n_levels)
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_obtain_candidate_points_batch");
+  const int w = c->lv[lvl].w, h = c->lv[lvl].h;
+  const size_t n = c->lv[lvl].n;
+  const int kcap = (int)std::min<size_t>((size_t)cap, n);
+  // row bands: enough blocks for a lone frame to spread over the chip, a few rows per thread at least
+  const int col_blocks = (w + kBlock - 1) / kBlock;
+  int bands = std::max(1, std::min(h / 8, 512 / std::max(1, col_blocks * n_frames)));
+  const size_t m = (size_t)w * bands;
+  auto up = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  const size_t o_sums = 0, o_mag = up(8 * (size_t)n_frames), o_cnt = o_mag + up(n * n_frames), o_off = o_cnt + up(4 * m * n_frames),
+               o_tot = o_off + up(4 * m * n_frames), o_out = o_tot + up(4 * (size_t)n_frames),
+               total = o_out + (size_t)n_frames * kcap * 16 + 256;
+  int st = ensure_scratch(c, total);
+  if (st) return st;
+  st = compute_begin(c, first_slot, n_frames);
+  if (st) return st;
+  uint8_t* base = (uint8_t*)c->scratch;
+  unsigned long long* d_sums = (unsigned long long*)(base + o_sums);
+  uint8_t* d_mag = base + o_mag;
+  int* d_cnt = (int*)(base + o_cnt);
+  int* d_off = (int*)(base + o_off);
+  int* d_tot = (int*)(base + o_tot);
+  float4* d_out = (float4*)(base + o_out);
+  const uint16_t* d_depth = c->p.has_depth ? c->depth[lvl] : nullptr;
+  HIPCHK(c, hipMemsetAsync(d_sums, 0, 8 * (size_t)n_frames, c->stream));
+  const int mag_blocks = (int)std::min<size_t>(256, (n + kBlock - 1) / kBlock);
+  hipLaunchKernelGGL(k_grad_mag_batch, dim3(mag_blocks, n_frames), dim3(kBlock), 0, c->stream, c->gx[lvl], c->gy[lvl], (int)n, first_slot,
+                     d_mag, d_sums);
+  const dim3 grid(col_blocks, bands, n_frames);
+  hipLaunchKernelGGL(k_candidates_batch<false>, grid, dim3(kBlock), 0, c->stream, d_mag, d_depth, first_slot, w, h, bands, d_sums, threshold,
+                     d_cnt, (const int*)nullptr, (float4*)nullptr, 0);
+  hipLaunchKernelGGL(k_scan_counts, dim3(n_frames), dim3(1024), 0, c->stream, d_cnt, (int)m, d_off, d_tot);
+  hipLaunchKernelGGL(k_candidates_batch<true>, grid, dim3(kBlock), 0, c->stream, d_mag, d_depth, first_slot, w, h, bands, d_sums, threshold,
+                     (int*)nullptr, d_off, d_out, kcap);
+  HIPCHK(c, hipGetLastError());
+  HIPCHK(c, hipMemcpyAsync(counts_out, d_tot, 4 * (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  for (int f = 0; f < n_frames; f++) {   // each frame's points are packed at f * cap in the caller's buffer
+    const int k = std::min(counts_out[f], kcap);
+    if (k > 0)
+      HIPCHK(c, hipMemcpyAsync(pts_out + (size_t)f * cap * 4, d_out + (size_t)f * kcap, (size_t)k * 16, hipMemcpyDeviceToHost, c->stream));
+  }
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return UWT_OK;
+}
+
 int uwt_obtain_candidate_points(uwt_ctx* c, int32_t slot, int32_t lvl, double threshold, float* pts_out, int32_t cap,
                                 int32_t* count_out) {
-  if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
-  if (!c || !count_out || cap < 0 || (cap > 0 && !pts_out) || !slot_range_ok(c, slot, 1) || lvl < 0 || lvl >= c->p.n_levels)
-    return fail(c, UWT_ERR_INVALID_ARG, "uwt_obtain_candidate_points");
-  uint8_t* d_mag;
-  unsigned long long* d_sum;
-  int st = mag_to_scratch(c, slot, lvl, &d_mag, &d_sum);
-  if (st) return st;
-  unsigned long long sum = 0;
-  HIPCHK(c, hipMemcpyAsync(&sum, d_sum, 8, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  const size_t n = c->lv[lvl].n;
-  const double thres = (double)sum / (double)n + threshold;  // cuda::meanStdDev mean + GRADIENT_THRESHOLD (src/Tracker.cpp:1325-1327)
-  const size_t off = (n + 64 + 63) & ~(size_t)63;
-  float4* d_out = (float4*)((uint8_t*)c->scratch + off);
-  int* d_cnt = (int*)c->scratch + 2;
-  const int kcap = (int)std::min<size_t>((size_t)cap, n);
-  hipLaunchKernelGGL(k_candidate_points, dim3(1), dim3(1024), 0, c->stream, d_mag,
-                     c->p.has_depth ? c->depth[lvl] + slot * n : nullptr, c->lv[lvl].w, c->lv[lvl].h, thres, d_out, kcap, d_cnt);
-  HIPCHK(c, hipGetLastError());
-  int cnt = 0;
-  HIPCHK(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  *count_out = cnt;
-  const int m = std::min(cnt, kcap);
-  if (m > 0) {
-    HIPCHK(c, hipMemcpyAsync(pts_out, d_out, (size_t)m * 16, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-  }
-  return UWT_OK;
+  if (!count_out) return fail(c, UWT_ERR_INVALID_ARG, "uwt_obtain_candidate_points");
+  return uwt_obtain_candidate_points_batch(c, slot, 1, lvl, threshold, pts_out, cap, count_out);
 }
 
 int uwt_obtain_patch_points(uwt_ctx* c, int32_t slot, const float* kp, int32_t n_kp, float* pts_out, int32_t cap,
@@ -1814,7 +1838,7 @@ int uwt_ingest_frame(uwt_ingest* g, uwt_ctx* c, int32_t slot, const uint8_t* raw
   return UWT_OK;
 }
 
-int uwt_accumulate_trajectory(uwt_ctx* c, const float* poses, int32_t n, const float start_pose[7], float t_scale,
+static int accumulate_trajectory_impl(uwt_ctx* c, bool scan, const float* poses, int32_t n, const float start_pose[7], float t_scale,
                               int32_t reference_axes, float* traj_out) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !poses || !start_pose || !traj_out || n < 0) return fail(c, UWT_ERR_INVALID_ARG, "uwt_accumulate_trajectory");
@@ -1828,12 +1852,23 @@ int uwt_accumulate_trajectory(uwt_ctx* c, const float* poses, int32_t n, const f
   Pose P;
   for (int k = 0; k < 4; k++) P.q[k] = start_pose[k];
   for (int k = 0; k < 3; k++) P.t[k] = start_pose[4 + k];
-  hipLaunchKernelGGL(k_trajectory, dim3(1), dim3(64), 0, c->stream, din, n, P, t_scale, reference_axes, dout);
+  if (scan) hipLaunchKernelGGL(k_trajectory_scan, dim3(1), dim3(1024), 0, c->stream, din, n, P, t_scale, reference_axes, dout);
+  else hipLaunchKernelGGL(k_trajectory, dim3(1), dim3(64), 0, c->stream, din, n, P, t_scale, reference_axes, dout);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(traj_out, dout, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
 }
 
+
+int uwt_accumulate_trajectory(uwt_ctx* c, const float* poses, int32_t n, const float start_pose[7], float t_scale,
+                              int32_t reference_axes, float* traj_out) {
+  return accumulate_trajectory_impl(c, false, poses, n, start_pose, t_scale, reference_axes, traj_out);
+}
+
+int uwt_accumulate_trajectory_scan(uwt_ctx* c, const float* poses, int32_t n, const float start_pose[7], float t_scale,
+                                   int32_t reference_axes, float* traj_out) {
+  return accumulate_trajectory_impl(c, true, poses, n, start_pose, t_scale, reference_axes, traj_out);
+}
 
 }  // extern "C"

@@ -1602,44 +1602,88 @@ __global__ __launch_bounds__(kBlock) void k_grad_mag(const int16_t* __restrict__
   if (threadIdx.x == 0) atomicAdd(sum, (unsigned long long)red[0]);  // integer: order-independent
 }
 
-// Ordered compaction, one block: cell c (0 <= c < n_cells) is kept iff keep(c); kept cells are written in cell order.
-// ObtainCandidatePoints order: x outer, y inner (src/Tracker.cpp:1334-1335) => c = x*h + y.
-__global__ __launch_bounds__(1024) void k_candidate_points(const uint8_t* __restrict__ mag, const uint16_t* __restrict__ depth,
-                                                           int w, int h, double thres, float4* __restrict__ out, int cap,
-                                                           int* __restrict__ count) {
-  __shared__ int cnt[1024];
-  const int n_cells = w * h, tid = threadIdx.x;
-  const int per = (n_cells + 1023) / 1024;
-  const int c0 = min(tid * per, n_cells), c1 = min(c0 + per, n_cells);
-  auto keep = [&](int c, float& z) -> bool {
-    const int x = c / h, y = c - x * h;
-    if (!((double)mag[(size_t)y * w + x] > thres)) return false;
-    z = 1.0f;
-    if (depth) {  // the reference indexes the 16-bit plane through at<uchar> (:1339, :1344): byte x of row y
-      const uint8_t b = reinterpret_cast<const uint8_t*>(depth + (size_t)y * w)[x];
-      if (b == 0) return false;
+// Tracker::ObtainCandidatePoints (src/Tracker.cpp:1314-1362) for a batch of frames, many blocks per frame, three passes:
+// gradient_ and its per-frame sum: grid (blocks, frames)
+__global__ __launch_bounds__(kBlock) void k_grad_mag_batch(const int16_t* __restrict__ gx, const int16_t* __restrict__ gy, int n,
+                                                           int first_slot, uint8_t* __restrict__ mag,
+                                                           unsigned long long* __restrict__ sums) {
+  const int f = blockIdx.y;
+  const size_t src = (size_t)(first_slot + f) * n, dst = (size_t)f * n;
+  unsigned int local = 0;
+  for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
+    const int ax = min(abs((int)gx[src + i]), 255), ay = min(abs((int)gy[src + i]), 255);
+    const int s = ax + ay;
+    int m = s >> 1;
+    if (s & 1) m += (m & 1);
+    mag[dst + i] = (uint8_t)m;
+    local += (unsigned int)m;
+  }
+  __shared__ unsigned int red[kBlock];
+  red[threadIdx.x] = local;
+  __syncthreads();
+  for (int st = kBlock / 2; st > 0; st >>= 1) {
+    if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) atomicAdd(&sums[f], (unsigned long long)red[0]);  // integer: order-independent
+}
+
+// One thread owns one column x of one row band of one frame and walks its rows top to bottom (a row of the block's
+// columns is one coalesced read); cells are kept as in k_candidate_points.  WRITE = false: counts[f][x * bands + band];
+// WRITE = true: the points, at the offsets an exclusive scan of the counts in that (x, band) order gives — which is the
+// reference's order, x outer, y inner (src/Tracker.cpp:1334-1335).
+template <bool WRITE>
+__global__ __launch_bounds__(kBlock) void k_candidates_batch(const uint8_t* __restrict__ mag, const uint16_t* __restrict__ depth,
+                                                             int first_slot, int w, int h, int bands,
+                                                             const unsigned long long* __restrict__ sums, double threshold,
+                                                             int* __restrict__ counts, const int* __restrict__ offsets,
+                                                             float4* __restrict__ out, int cap) {
+  const int f = blockIdx.z, band = blockIdx.y, x = blockIdx.x * kBlock + threadIdx.x;
+  if (x >= w) return;
+  const size_t n = (size_t)w * h;
+  const double thres = (double)sums[f] / (double)n + threshold;  // cuda::meanStdDev mean + GRADIENT_THRESHOLD (:1325-1327)
+  const uint8_t* m = mag + (size_t)f * n;
+  const uint16_t* dp = depth ? depth + (size_t)(first_slot + f) * n : nullptr;
+  const int rows = (h + bands - 1) / bands, y0 = band * rows, y1 = min(y0 + rows, h);
+  int k = WRITE ? offsets[(size_t)f * w * bands + (size_t)x * bands + band] : 0;
+  float4* o = WRITE ? out + (size_t)f * cap : nullptr;
+  for (int y = y0; y < y1; y++) {
+    if (!((double)m[(size_t)y * w + x] > thres)) continue;
+    float z = 1.0f;
+    if (dp) {  // the reference indexes the 16-bit plane through at<uchar> (:1339, :1344): byte x of row y
+      const uint8_t b = reinterpret_cast<const uint8_t*>(dp + (size_t)y * w)[x];
+      if (b == 0) continue;
       z = (float)b * 0.0002f;
     }
-    return true;
-  };
-  int k = 0;
-  float z;
-  for (int c = c0; c < c1; c++) k += keep(c, z) ? 1 : 0;
-  cnt[tid] = k;
-  __syncthreads();
-  if (tid == 0) {
-    int run = 0;
-    for (int i = 0; i < 1024; i++) { const int v = cnt[i]; cnt[i] = run; run += v; }
-    *count = run;
-  }
-  __syncthreads();
-  int o = cnt[tid];
-  for (int c = c0; c < c1; c++)
-    if (keep(c, z)) {
-      const int x = c / h, y = c - x * h;
-      if (o < cap) out[o] = make_float4((float)x, (float)y, z, 1.0f);
-      o++;
+    if (WRITE) {
+      if (k < cap) o[k] = make_float4((float)x, (float)y, z, 1.0f);
     }
+    k++;
+  }
+  if (!WRITE) counts[(size_t)f * w * bands + (size_t)x * bands + band] = k;
+}
+
+// exclusive scan of the m = w * bands counts of one frame (one block per frame), total to totals[f]
+__global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ counts, int m, int* __restrict__ offsets,
+                                                      int* __restrict__ totals) {
+  __shared__ int part[1024];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  const int* c = counts + (size_t)f * m;
+  int* o = offsets + (size_t)f * m;
+  const int per = (m + 1023) / 1024, i0 = min(tid * per, m), i1 = min(i0 + per, m);
+  int s = 0;
+  for (int i = i0; i < i1; i++) s += c[i];
+  part[tid] = s;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partial sums
+    const int v = tid >= d ? part[tid - d] : 0;
+    __syncthreads();
+    part[tid] += v;
+    __syncthreads();
+  }
+  int run = tid ? part[tid - 1] : 0;
+  for (int i = i0; i < i1; i++) { o[i] = run; run += c[i]; }
+  if (tid == 1023) totals[f] = part[1023];
 }
 
 // Tracker::ObtainPatchesPoints (src/Tracker.cpp:1178-1257): level 0, <= 200 key points, 11x11 patches
@@ -1721,6 +1765,52 @@ __global__ void k_trajectory(const float* __restrict__ poses, int n, Pose prev, 
     const float len = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);  // SE3(q, t) normalises q
     cur.q[0] = p[0] / len; cur.q[1] = p[1] / len; cur.q[2] = p[2] / len; cur.q[3] = p[3] / len;
     cur.t[0] = t_scale * p[4]; cur.t[1] = t_scale * p[5]; cur.t[2] = t_scale * p[6];
+    se3_mul(prev, cur, fin);
+    prev = fin;
+    float* o = out + 7 * (size_t)i;
+    o[0] = fin.q[0]; o[1] = fin.q[1]; o[2] = fin.q[2]; o[3] = fin.q[3];
+    if (reference_axes) { o[4] = -fin.t[2]; o[5] = -fin.t[0]; o[6] = -fin.t[1]; }
+    else { o[4] = fin.t[0]; o[5] = fin.t[1]; o[6] = fin.t[2]; }
+  }
+}
+
+// The same accumulation as a prefix product (SE(3) composition is associative; in floats the grouping shows in the last
+// bits, so this is the default "clean" mode, not the reference-visualiser one): one block, every thread multiplies its run
+// of poses, a Hillis-Steele scan over the 1024 run products, then every thread replays its run behind its prefix.
+__global__ __launch_bounds__(1024) void k_trajectory_scan(const float* __restrict__ poses, int n, Pose start, float t_scale,
+                                                          int reference_axes, float* __restrict__ out) {
+  __shared__ Pose part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n + 1023) / 1024, i0 = min(tid * per, n), i1 = min(i0 + per, n);
+  auto load = [&](int i, Pose& cur) {
+    const float* p = poses + 7 * (size_t)i;
+    const float len = sqrtf(p[0] * p[0] + p[1] * p[1] + p[2] * p[2] + p[3] * p[3]);  // SE3(q, t) normalises q
+    cur.q[0] = p[0] / len; cur.q[1] = p[1] / len; cur.q[2] = p[2] / len; cur.q[3] = p[3] / len;
+    cur.t[0] = t_scale * p[4]; cur.t[1] = t_scale * p[5]; cur.t[2] = t_scale * p[6];
+  };
+  Pose acc;
+  pose_identity(acc);
+  for (int i = i0; i < i1; i++) {
+    Pose cur, nxt;
+    load(i, cur);
+    se3_mul(acc, cur, nxt);
+    acc = nxt;
+  }
+  part[tid] = acc;
+  __syncthreads();
+  for (int d = 1; d < 1024; d <<= 1) {
+    Pose left, mine = part[tid], prod;
+    const bool has = tid >= d;
+    if (has) left = part[tid - d];
+    __syncthreads();
+    if (has) { se3_mul(left, mine, prod); part[tid] = prod; }
+    __syncthreads();
+  }
+  Pose prev;
+  if (tid) { Pose pre = part[tid - 1]; se3_mul(start, pre, prev); } else prev = start;
+  for (int i = i0; i < i1; i++) {
+    Pose cur, fin;
+    load(i, cur);
     se3_mul(prev, cur, fin);
     prev = fin;
     float* o = out + 7 * (size_t)i;

@@ -105,12 +105,13 @@ class SequenceTracker:
             collect(len(chunks) - 1)
         return poses, stats
 
-    def trajectory(self, poses, start_pose=None, reference_visualiser=False):
+    def trajectory(self, poses, start_pose=None, reference_visualiser=False, scan=False):
         """Visualizer::UpdateMessages accumulation (src/Visualizer.cpp:304-325); reference_visualiser reproduces the
-        x40 translation scale and the (-z, -x, -y) axis permutation."""
+        x40 translation scale and the (-z, -x, -y) axis permutation (sequential, bit-exact).  scan=True takes the plain
+        SE(3) prefix product as a parallel scan (long trajectories; equal to the sequential form to float rounding)."""
         if reference_visualiser:
             return self.ctx.accumulate_trajectory(poses, start_pose, 40.0, True)
-        return self.ctx.accumulate_trajectory(poses, start_pose, 1.0, False)
+        return self.ctx.accumulate_trajectory(poses, start_pose, 1.0, False, scan=scan)
 
     def close(self):
         self.ctx.close()
