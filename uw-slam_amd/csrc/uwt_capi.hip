@@ -72,6 +72,7 @@ struct uwt_ctx {
   void* scratch = nullptr;              // per-stage entry points
   size_t scratch_bytes = 0;
   bool profiling = false;
+  int first_poll = 3;                   // evaluations of a level before the first early-exit read-back
   int chained = -1;                     // -1: chained flow for n_pairs <= 2; UWT_CHAINED=1 / 0: always / never (A/B runs)
   const uint32_t* prof_records = nullptr;
   bool compute_only = false;            // uwt_profile_enable(ctx, 2): residual launches run their no-memory diagnostic twin
@@ -435,7 +436,7 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
       ra.groups_per_block = gpt * kBlock;
       ra.slices = (n_groups + ra.groups_per_block - 1) / ra.groups_per_block;
     }
-    int next_poll = 2;
+    int next_poll = c->first_poll;   // see enqueue_estimate
     int k = 0;
     for (; k < p.max_iters; k++) {
       ia.mode = first ? 0 : (k == 0 ? 2 : 1);
@@ -526,7 +527,10 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         ra.slices = (n_groups + ra.groups_per_block - 1) / ra.groups_per_block;
         ua.slices = ra.slices;
       }
-      int next_poll = 2;
+      // Early exit: the host reads back how many pairs are still iterating after the update of evaluation first_poll - 1,
+      // then after twice as many, ...  With the reference's constants a level ends at its third evaluation as a rule
+      // (error rises or stalls, src/Tracker.cpp:508), so the first look comes after three (UWT_FIRST_POLL).
+      int next_poll = c->first_poll;
       for (int k = 0; k < p.max_iters; k++) {
         size_t ev = 0;
         if (c->profiling) {
@@ -746,6 +750,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
   for (int l = 0; l < UWT_MAX_LEVELS; l++) CREATE_CHK(hipEventCreateWithFlags(&c->ev_level[l], hipEventDisableTiming));
   if (const char* e = std::getenv("UWT_OVERLAP_GRAD")) c->overlap_gradients = std::atoi(e) != 0;
+  if (const char* e = std::getenv("UWT_FIRST_POLL")) c->first_poll = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("UWT_CHAINED")) c->chained = std::atoi(e) != 0 ? 1 : 0;
   for (int l = 0; l < p->n_levels; l++) {
     const size_t n = (size_t)c->lv[l].n * p->max_frames;
