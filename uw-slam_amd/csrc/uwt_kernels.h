@@ -6,8 +6,11 @@
 //                  (src/Tracker.cpp:1417-1471, 432-490; src/LeastSquares.cpp:148-209)
 //   k_gn_update    error / exit test / normal equations / solve / pose update (src/Tracker.cpp:495-574)
 //   k_level_end    level hand-off                           (src/Tracker.cpp:580-590)
+//   k_iterate, k_finish   the same loop chained: update + hand-off at the head of the next evaluation (one or two pairs)
+//   k_residual_points, k_residual_general, k_resid_hist*, k_scale_stage   explicit point tables; robust weights / bilinear
+//   k_grad_mag*, k_candidates_batch, k_scan_counts, k_patch_points, k_remap_crop, k_trajectory*   the rows next to the path
 //
-// Memory-bound integer/float stencil + gather + reduction work: no MFMA.  Wave = 64 lanes, blocks of 256.
+// Stencil + gather + reduction work with a 6-wide contraction: no MFMA.  Wave = 64 lanes, blocks of 256.
 // Build with -ffp-contract=off: the per-pixel float sequence is part of the contract (every FMA is explicit).
 #pragma once
 
@@ -1629,7 +1632,8 @@ __global__ __launch_bounds__(kBlock) void k_grad_mag_batch(const int16_t* __rest
 }
 
 // One thread owns one column x of one row band of one frame and walks its rows top to bottom (a row of the block's
-// columns is one coalesced read); cells are kept as in k_candidate_points.  WRITE = false: counts[f][x * bands + band];
+// columns is one coalesced read); a cell is kept iff gradient_ > mean + threshold and, with a depth plane, the byte the
+// reference reads there is not zero (src/Tracker.cpp:1336-1347).  WRITE = false: counts[f][x * bands + band];
 // WRITE = true: the points, at the offsets an exclusive scan of the counts in that (x, band) order gives — which is the
 // reference's order, x outer, y inner (src/Tracker.cpp:1334-1335).
 template <bool WRITE>
