@@ -107,3 +107,11 @@ def test_native_bench_runs_without_python_in_the_loop():
     out = subprocess.run([exe, "--pairs", "4", "--unique", "4", "--width", "160", "--height", "96", "--reference-schedule", "--no-depth",
                           "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
+    # the multi-GPU mode's path with the one device of the box: RCCL communicator, all-gather on the context's stream
+    out = subprocess.run([exe, "--pairs", "12", "--unique", "3", "--width", "160", "--height", "96", "--levels", "3", "--steps", "2",
+                          "--warmup", "1", "--gpus", "1", "--rccl"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["gathered_blocks_match"] is True and d["tiled_pairs_identical"] and d["n_gpus"] == 1
+    out = subprocess.run([exe, "--gpus", "64", "--pairs", "2"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 2 and "device(s) visible" in out.stderr
