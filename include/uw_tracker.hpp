@@ -12,7 +12,8 @@
 //     tracker_->EstimatePose(previous_frame_, current_frame_);   // -> previous_frame_->rigid_transformation_
 //
 // OpenCV / Eigen / Sophus are not required: images are passed as uw::ImageView (data, rows, cols, step — the four
-// cv::Mat fields the path reads); define UW_WITH_OPENCV before including to get the cv::Mat overloads.
+// cv::Mat fields the path reads); define UW_WITH_OPENCV before including to get the cv::Mat overloads, UW_WITH_EIGEN for
+// Eigen::Map views of LS::A / LS::b.
 // Every numeric step runs in libuwt_hip.so on the GPU; a non-zero status becomes a std::runtime_error (the reference
 // surfaces misuse as cv::Exception / SOPHUS_ENSURE aborts).
 #pragma once
@@ -31,6 +32,9 @@
 
 #ifdef UW_WITH_OPENCV
 #include <opencv2/core.hpp>
+#endif
+#ifdef UW_WITH_EIGEN
+#include <Eigen/Core>
 #endif
 
 namespace uw {
@@ -383,6 +387,12 @@ class LS {
     for (int i = 0; i < 8; i++) _mm_storeu_ps(a[i].v, *src[i]);
     updateSSE(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
   }
+#endif
+#ifdef UW_WITH_EIGEN
+  // the reference's Mat66f / Mat61f views of A and b (include/LeastSquares.h:34-35): A is symmetric, so the row-major
+  // storage reads the same either way
+  Eigen::Map<Eigen::Matrix<float, 6, 6, Eigen::RowMajor>> A_eigen() { return Eigen::Map<Eigen::Matrix<float, 6, 6, Eigen::RowMajor>>(A); }
+  Eigen::Map<Eigen::Matrix<float, 6, 1>> b_eigen() { return Eigen::Map<Eigen::Matrix<float, 6, 1>>(b); }
 #endif
   void finishNoDivide() { fold(); }
   void finish() {
