@@ -322,7 +322,7 @@ int launch_general(uwt_ctx* c, const ResidualArgs& ra, int n_pairs) {
       default: hipLaunchKernelGGL((k_resid_hist_v<4, true, 1>), grid, blk, 0, c->stream, ra, c->hist); break;
     }
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_scale_stage, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, ga, ra.state, n_pairs, ra.pair_base);
+    hipLaunchKernelGGL(k_scale_stage, dim3((n_pairs + 3) / 4), dim3(256), 0, c->stream, ga, ra.state, n_pairs, ra.pair_base);
     HIPCHK(c, hipGetLastError());
   }
   const int key = (c->vec == 4 ? 4 : 0) | (depth ? 2 : 0) | (unit ? 1 : 0);
@@ -360,7 +360,7 @@ int launch_general_dump(uwt_ctx* c, ResidualArgs ra, int n_pairs, int* slices_ou
     if (depth) hipLaunchKernelGGL(k_resid_hist<true>, grid, blk, 0, c->stream, ra, ga);
     else hipLaunchKernelGGL(k_resid_hist<false>, grid, blk, 0, c->stream, ra, ga);
     HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_scale_stage, dim3((n_pairs + 63) / 64), dim3(64), 0, c->stream, ga, ra.state, n_pairs, ra.pair_base);
+    hipLaunchKernelGGL(k_scale_stage, dim3((n_pairs + 3) / 4), dim3(256), 0, c->stream, ga, ra.state, n_pairs, ra.pair_base);
     HIPCHK(c, hipGetLastError());
   }
   if (depth && unit) hipLaunchKernelGGL((k_residual_general<true, true>), grid, blk, 0, c->stream, ra, ga);

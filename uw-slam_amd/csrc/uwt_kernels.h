@@ -970,6 +970,8 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
   __syncthreads();
   WarpK K;
   pose_to_T12(st.pose, K.T);
+#pragma unroll
+  for (int i = 0; i < 12; i++) K.T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(K.T[i])));
   const LevelK L = a.L;
   const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
   const uint8_t* __restrict__ I1 = a.img + ref_off;
@@ -990,22 +992,36 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
       i1[0] = I1[idx];
       if constexpr (DEPTH) dp[0] = DP[idx];
     }
-    float x2[VEC], y2[VEC], iz;
+    // pairs of adjacent pixels through the packed float sequence (see v2f), as in the accumulation kernel
+    constexpr int N = (VEC % 2 == 0) ? 2 : 1;
+    using F = typename std::conditional<N == 2, v2f, float>::type;
+    float x2[VEC], y2[VEC];
     bool ok[VEC];
     uint32_t gidx[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; j++) {
-      float z = 1.0f;
-      bool okin = true;
-      if constexpr (DEPTH) {
-        const int d = (int)(int16_t)dp[j];
-        okin = d > 0;
-        z = (float)d * L.zscale;
+    for (int u = 0; u < VEC / N; u++) {
+      F z = bc<F>(1.0f), xf, x2u, y2u, izu;
+      unsigned long long okin_m[N], okm[N];
+#pragma unroll
+      for (int c = 0; c < N; c++) {
+        const int j = u * N + c;
+        bool okin = true;
+        if constexpr (DEPTH) {
+          const int d = (int)(int16_t)dp[j];
+          okin = d > 0;
+          put(z, c, (float)d);
+        }
+        okin_m[c] = __builtin_amdgcn_ballot_w64(okin);
+        put(xf, c, (float)x + (float)j);
       }
-      unsigned long long okm;
-      const unsigned long long okin_m = __builtin_amdgcn_ballot_w64(okin);
-      pixel_warp<float>(L, K, (float)x + (float)j, (float)y, z, &okin_m, x2[j], y2[j], iz, &okm, &gidx[j]);
-      ok[j] = lane_bit(okm);
+      if constexpr (DEPTH) z = z * bc<F>(L.zscale);
+      pixel_warp<F>(L, K, xf, bc<F>((float)y), z, okin_m, x2u, y2u, izu, okm, &gidx[u * N]);
+#pragma unroll
+      for (int c = 0; c < N; c++) {
+        x2[u * N + c] = get(x2u, c);
+        y2[u * N + c] = get(y2u, c);
+        ok[u * N + c] = lane_bit(okm[c]);
+      }
     }
     float rf[VEC];
 #pragma unroll
@@ -1032,66 +1048,108 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
 //   (float)(n / 2)); the reference Tukey saturates negatives to 0 first (:1572-1573), Huber keeps the sign;
 //   the deviation histogram |q - med| follows from the same bins (clamped at 255 like the u8 conversion of
 //   MedianAbsoluteDeviation's input, :1613, or at 510 for Huber); MAD = 1.4826 * its median (:1607-1619), 0 => 1 (:1634-1637).
-__global__ void k_scale_stage(const GeneralArgs ga, const PairState* state, int n_pairs, int pair_base) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// One wave per pair (four pairs per block).  Both medians are "the first bin whose cumulative count exceeds (float)(n / 2)"
+// of a histogram that is a function of the pair's 511 signed bins, so each is one pass: every lane owns 8 consecutive bins,
+// the lane totals are scanned across the wave, and the lane that holds the crossing reports the smallest index.
+__device__ __forceinline__ int first_crossing(const unsigned int v[8], float m, int lane) {
+  unsigned int tot = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) tot += v[k];
+  unsigned int inc = tot;   // inclusive scan of the lane totals over the 64 lanes
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const unsigned int up = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += up;
+  }
+  unsigned int cum = inc - tot;
+  int idx = 0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    cum += v[k];
+    if (idx == 0x7fffffff && (float)cum > m) idx = lane * 8 + k;
+  }
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) idx = min(idx, __shfl_xor(idx, d, 64));
+  return idx;   // 0x7fffffff: no bin crosses
+}
+
+__global__ __launch_bounds__(256) void k_scale_stage(const GeneralArgs ga, const PairState* state, int n_pairs, int pair_base) {
+  __shared__ unsigned int sh[4][kHistBins];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
   if (i >= n_pairs) return;
   const int pair = i + pair_base;
   const PairState st = state[pair];
   if (st.level_done || st.status) return;
   const unsigned int* gh = ga.hist + (size_t)pair * kHistBins;
+  unsigned int* h = sh[wave];
   const bool tukey = ga.weights == kWeightsTukeyRef;
-  unsigned int n = 0;
-  for (int b = 0; b < 511; b++) n += gh[b];
+  unsigned int mine[8], n = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int b = lane * 8 + k;
+    mine[k] = b < 511 ? gh[b] : 0u;
+    h[b] = mine[k];
+    n += mine[k];
+  }
+  __builtin_amdgcn_wave_barrier();   // h is written and read by this wave alone (LDS operations of a wave stay in order)
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) n += __shfl_xor(n, d, 64);
   const float m = (float)(n / 2);
-  // median of the residuals
-  int med = 0;
+  // median of the residuals: bins q + 255; the reference Tukey saturates negatives first — every q <= 0 lands in bin 0
+  // of its histogram (MedianMat, src/Tracker.cpp:1572-1591) — Huber keeps the sign
+  int med;
   {
-    unsigned int cum = 0;
-    bool found = false;
+    unsigned int v[8];
     if (tukey) {
-      for (int b = 0; b <= 255; b++) cum += gh[b];          // every q <= 0 lands in bin 0 of the saturated histogram
-      if ((float)cum > m) { med = 0; found = true; }
-      for (int v = 1; v <= 255 && !found; v++) {
-        cum += gh[v + 255];
-        if ((float)cum > m) { med = v; found = true; }
+      unsigned int neg = 0;   // sum of bins 0..255
+#pragma unroll
+      for (int k = 0; k < 8; k++) neg += (lane * 8 + k <= 255) ? mine[k] : 0u;
+#pragma unroll
+      for (int d = 32; d > 0; d >>= 1) neg += __shfl_xor(neg, d, 64);
+#pragma unroll
+      for (int k = 0; k < 8; k++) {   // saturated histogram: value 0 = neg, value t (1..255) = bin t + 255
+        const int t = lane * 8 + k;
+        v[k] = t == 0 ? neg : (t <= 255 ? h[t + 255] : 0u);
       }
-      if (!found) med = 255;
+      const int idx = first_crossing(v, m, lane);
+      med = idx == 0x7fffffff ? 255 : idx;
     } else {
-      for (int b = 0; b < 511 && !found; b++) {
-        cum += gh[b];
-        if ((float)cum > m) { med = b - 255; found = true; }
-      }
-      if (!found) med = 255;
+      const int idx = first_crossing(mine, m, lane);
+      med = idx == 0x7fffffff ? 255 : idx - 255;
     }
   }
-  // median of |q - med| from the same histogram
+  // median of |q - med| from the same bins: deviation d collects bins med - d and med + d; deviations >= dmax (the u8
+  // saturation of MedianAbsoluteDeviation's input, :1613, or 510 for Huber) share the last value, which the cumulative count
+  // always reaches
   const int dmax = tukey ? 255 : 510;
-  int dmed = dmax;
+  int dmed;
   {
-    unsigned int cum = 0;
-    bool found = false;
-    for (int d = 0; d <= dmax && !found; d++) {
+    unsigned int v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int d = lane * 8 + k;
       unsigned int c = 0;
       if (d < dmax) {
         const int lo = med - d, hi = med + d;
-        if (lo >= -255) c += gh[lo + 255];
-        if (d > 0 && hi <= 255) c += gh[hi + 255];
-      } else {  // clamp bin: every deviation >= dmax
-        for (int q = -255; q <= 255; q++)
-          if (abs(q - med) >= dmax) c += gh[q + 255];
+        if (lo >= -255 && lo <= 255) c += h[lo + 255];
+        if (d > 0 && hi <= 255 && hi >= -255) c += h[hi + 255];
       }
-      cum += c;
-      if ((float)cum > m) { dmed = d; found = true; }
+      v[k] = c;
     }
+    const int idx = first_crossing(v, m, lane);
+    dmed = idx == 0x7fffffff ? dmax : idx;
   }
-  PairScale sc;
-  sc.med0 = (float)med;
-  sc.n_valid = (int)n;
-  sc.pad = 0;
-  float mad = 1.4826f * (float)dmed;
-  if (!n || mad == 0.f) mad = 1.f;
-  sc.inv_mad = (float)(1.0 / (double)mad);
-  ga.scale[pair] = sc;
+  if (lane == 0) {
+    PairScale sc;
+    sc.med0 = (float)med;
+    sc.n_valid = (int)n;
+    sc.pad = 0;
+    float mad = 1.4826f * (float)dmed;
+    if (!n || mad == 0.f) mad = 1.f;
+    sc.inv_mad = (float)(1.0 / (double)mad);
+    ga.scale[pair] = sc;
+  }
 }
 
 // weighted / bilinear accumulation: J <- w·J, r <- gain·r, A = Σ(wJ)(wJ)ᵀ, jtr = Σ(wJ)·((gain r)·w) (src/Tracker.cpp:554-561),
