@@ -159,6 +159,28 @@ def test_per_stage_weighted_entry_on_a_level_larger_than_the_record_budget_assum
     ctx.close()
 
 
+def test_speculative_launching_redoes_a_cut_short_alignment(capi, O, synth, monkeypatch):
+    """One pair under the reference's early-exit schedule is launched without read-backs, a level's usual evaluations plus
+    one; with the budget forced down to two evaluations per level nearly every level is cut short, the flag is raised and
+    the careful second run must deliver the oracle's pose and iteration count — as the unforced call does."""
+    w, h = 320, 240
+    intr = (262.5, 262.5, 159.5, 119.5)
+    ref, tgt, dep, _, _ = synth.render_pair(w, h, *intr, seed=808, max_t=0.02, max_deg=1.0, with_depth=True)
+    st, pose_cpu, tr = O.align_pair(O.default_params(w, h, *intr, has_depth=1), ref, tgt, dep, want_trace=True)
+    assert st == 0 and len(tr) > 8          # more than two evaluations on some level
+    out = []
+    for forced in (False, True):
+        if forced:
+            monkeypatch.setenv("UWT_FIRST_POLL", "1")
+        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, has_depth=1))
+        _upload_pair(ctx, ref, tgt, dep)
+        poses, stats = ctx.estimate_pose_batch([0], [1], raise_on_pair_failure=True)
+        out.append((poses[0].copy(), stats[0]["iterations"]))
+        ctx.close()
+    for pose, iters in out:
+        assert np.array_equal(pose.view(np.uint32), pose_cpu.view(np.uint32)) and iters == len(tr)
+
+
 # ------------------------------------------------------------------ launch paths of bench.py
 
 def _run(cmd, extra_env=None, timeout=540):

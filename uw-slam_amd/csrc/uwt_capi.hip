@@ -72,6 +72,9 @@ struct uwt_ctx {
   void* scratch = nullptr;              // per-stage entry points
   size_t scratch_bytes = 0;
   bool profiling = false;
+  bool speculate = false;               // set by the synchronous entry for one or two pairs: launch a level's usual number of
+                                        // iterations without reading back, check once at the end, redo conservatively if cut short
+  int* d_cut = nullptr;
   int first_poll = 3;                   // evaluations of a level before the first early-exit read-back
   int chained = -1;                     // -1: chained flow for n_pairs <= 2; UWT_CHAINED=1 / 0: always / never (A/B runs)
   const uint32_t* prof_records = nullptr;
@@ -424,6 +427,14 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
   ia.initial_error = p.initial_error;
   bool first = true;
   int prev_slices = 0, prev_k = 0, prev_lvl = p.first_level;
+  // Speculative launching (early-exit schedules, the synchronous one- or two-pair call): every read-back of "who is still
+  // iterating" costs a host round trip of about two evaluations; instead each level gets the evaluations levels usually
+  // take plus one, nothing is read back, and the level switch notes on the device whether a pair was cut short — the
+  // caller looks once, behind the results, and redoes the alignment the careful way in that (rare) case.
+  const bool speculate = c->speculate && p.early_exit;
+  const int spec_iters = std::min(p.max_iters, c->first_poll + 1);
+  ia.cut_short = speculate ? c->d_cut : nullptr;
+  if (speculate) HIPCHK(c, hipMemsetAsync(c->d_cut, 0, sizeof(int), c->stream));
   for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
     if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(c->stream, level_ready[lvl], 0));  // its gradients
     ResidualArgs ra = residual_args(c, lvl);
@@ -438,7 +449,7 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
     }
     int next_poll = c->first_poll;   // see enqueue_estimate
     int k = 0;
-    for (; k < p.max_iters; k++) {
+    for (; k < (speculate ? spec_iters : p.max_iters); k++) {
       ia.mode = first ? 0 : (k == 0 ? 2 : 1);
       ia.u.partials = recs[rp ^ 1];
       ia.u.slices = prev_slices;
@@ -449,7 +460,7 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
       ra.partials = recs[rp];
       // the update inside launch k belongs to evaluation k - 1: a poll at launch k sees what the separate-kernel flow saw
       // after its update k - 1
-      const bool poll = p.early_exit && k == next_poll && k < p.max_iters;
+      const bool poll = p.early_exit && !speculate && k == next_poll && k < p.max_iters;
       ia.u.active = poll ? c->d_active : nullptr;
       if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
       size_t ev = 0;
@@ -768,6 +779,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_poses, sizeof(float) * 7 * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_stats, sizeof(StatsOut) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_active, sizeof(int)));
+  CREATE_CHK(hipMalloc((void**)&c->d_cut, sizeof(int)));
   if (const char* e = std::getenv("UWT_TARGET_BLOCKS")) c->target_blocks = std::max(1, std::atoi(e));  // tuning experiments only
   if (p->sampler || p->weights) {
     CREATE_CHK(hipMalloc((void**)&c->hist, sizeof(unsigned int) * kHistBins * p->max_pairs));
@@ -803,6 +815,7 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stats) (void)hipFree(c->d_stats);
   if (c->d_active) (void)hipFree(c->d_active);
+  if (c->d_cut) (void)hipFree(c->d_cut);
   if (c->hist) (void)hipFree(c->hist);
   if (c->scale) (void)hipFree(c->scale);
   if (c->h_active) (void)hipHostFree(c->h_active);
@@ -1005,12 +1018,22 @@ int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slot
   if (st) return st;
   st = compute_begin(c, 0, c->p.max_frames);
   if (st) return st;
-  st = enqueue_estimate(c, n_pairs, c->d_poses, c->d_stats);
-  if (st) return st;
-  HIPCHK(c, hipMemcpyAsync(poses_out, c->d_poses, sizeof(float) * 7 * n_pairs, hipMemcpyDeviceToHost, c->stream));
   std::vector<uwt_stats> tmp(n_pairs);
-  HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_stats, sizeof(uwt_stats) * n_pairs, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // One or two pairs under an early-exit schedule are launched speculatively (see enqueue_estimate_chained): no read-back
+  // inside the alignment, one look at the "cut short" flag behind the results, a careful second run if it is set.
+  c->speculate = n_pairs <= 2 && c->p.early_exit && !c->profiling && c->chained != 0 && !std::getenv("UWT_NO_SPECULATION");
+  for (int attempt = 0; attempt < 2; attempt++) {
+    st = enqueue_estimate(c, n_pairs, c->d_poses, c->d_stats);
+    if (st) { c->speculate = false; return st; }
+    int cut = 0;
+    HIPCHK(c, hipMemcpyAsync(poses_out, c->d_poses, sizeof(float) * 7 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_stats, sizeof(uwt_stats) * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    if (c->speculate) HIPCHK(c, hipMemcpyAsync(&cut, c->d_cut, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    const bool redo = c->speculate && cut != 0;
+    c->speculate = false;
+    if (!redo) break;
+  }
   if (c->profiling) {
     st = prof_collect(c);
     if (st) return st;

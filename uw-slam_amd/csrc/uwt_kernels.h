@@ -1364,6 +1364,8 @@ struct IterArgs {
   int prev_lvl;               // level the pending update / hand-off belongs to (mode 2)
   int scale_t;
   float initial_error;
+  int* cut_short;             // optional (speculative launching, early-exit schedules): set when a level's launches ran out
+                              // before the pair's exit test fired, i.e. the host stopped launching too early
 };
 
 __device__ __forceinline__ PairState iterate_state(const IterArgs& ia, int pair, unsigned char* lds, bool count_active) {
@@ -1380,6 +1382,8 @@ __device__ __forceinline__ PairState iterate_state(const IterArgs& ia, int pair,
   }
   st = update_compute(ia.u, ia.u.partials + (size_t)pair * ia.u.slices * kRecWords, ia.state_in[pair], lds, count_active);
   if (ia.mode == 2) {   // end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
+    // with early exit a level ends only through its exit test (which fires at the last iteration at the latest)
+    if (ia.cut_short && ia.u.early_exit && !st.level_done && st.status == 0 && count_active && threadIdx.x == 0) atomicOr(ia.cut_short, 1);
     if (st.status == 0 && ia.prev_lvl != 0) {
       if (!se3_handoff(st.pose, ia.scale_t != 0)) st.status = 1;  // SOPHUS_ENSURE would abort
     }
