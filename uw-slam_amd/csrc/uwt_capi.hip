@@ -1173,6 +1173,14 @@ int uwt_profile_read(uwt_ctx* c, double* ms_total, int64_t* launches, int64_t* p
   return UWT_OK;
 }
 
+#ifdef UWT_EXP_STAMPS
+int uwt_exp_read_records(uwt_ctx* c, int parity, uint32_t* out, int n_words) {
+  hipStreamSynchronize(c->stream);
+  if (parity == 2) return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_exp_stamps), 64) == hipSuccess ? 0 : 1;
+  return hipMemcpy(out, parity ? c->partials2 : c->partials, (size_t)n_words * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
+
 int uwt_profile_clock(uwt_ctx* c, double* shader_ghz) {
   if (c) (void)hipSetDevice(c->p.device);
   if (!c || !shader_ghz) return UWT_ERR_INVALID_ARG;

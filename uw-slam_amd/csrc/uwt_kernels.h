@@ -458,68 +458,88 @@ __device__ __forceinline__ void accumulate_weighted(AccT acc[kAccFloats], AccT& 
   for (int i = 0; i < 6; i++) acc[21 + i] = (AccT)__builtin_fma(Jd[i], (double)rw, (double)acc[21 + i]);
 }
 
+#ifdef UWT_EXP_STAMPS
+__device__ uint32_t g_exp_stamps[16];
+#define EXP_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_exp_stamps[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define EXP_STAMP(i) do { } while (0)
+#endif
 // Deterministic block reduction of the per-thread accumulators through LDS (fixed order, no atomics).
 // Threads accumulate a handful of pixels in f32; from here on every sum is f64 so that the totals are, to ~1e-9,
 // the exact sums the reference's double-accumulating gemm produces (src/Tracker.cpp:560-561).
 // Stage 1 transposes 29 rows x 256 threads into LDS; stage 2: 232 threads each fold 32 columns; stage 3: 29
 // threads fold the 8 segment sums and write the 256-B record.
-// The LDS image of the reduction, carved out of a raw buffer so that a kernel can reuse the same bytes for another phase:
-// red[14][256] AccT | redi[2][256] u32 | seg_f[28][8] f64 | seg_u[2][8] u64  (sized for AccT = double)
-constexpr int kReduceLdsBytes = 14 * kBlock * 8 + 2 * kBlock * 4 + (kAccFloats + 1) * 8 * 8 + 2 * 8 * 8;   // 32640
+// The LDS image of the reduction is carved out of a raw buffer so that a kernel can reuse the same bytes for another phase
+// (sized for AccT = double).  PASS = rows per
+// LDS pass: 14 (two passes, 34 KB: four blocks per CU) for the batch kernels; 27 (one pass, 60 KB) where a block has its
+// CU to itself and the reduction's latency is on the critical path (k_iterate).
+constexpr int reduce_lds_bytes(int pass) { return pass * kBlock * 8 + 2 * kBlock * 8 + (kAccFloats + 3) * 8 * 8; }
+constexpr int kReduceLdsBytes = reduce_lds_bytes(14);   // 34688
+constexpr int kIteratePass = kAccFloats;                // k_iterate: one pass, 61312 B
 
-template <typename AccT, bool HAS_EXTRA = false>
+template <typename AccT, bool HAS_EXTRA = false, int PASS = 14>
 __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict__ lds, const AccT acc[kAccFloats],
                                                       uint32_t sum_r2, uint32_t n_valid, uint32_t* __restrict__ rec,
                                                       AccT extra = (AccT)0) {
-  constexpr int kPass = 14;  // accumulators per LDS pass (2 passes; keeps the f64 image under 29 KB per block)
+  constexpr int kPass = PASS;  // accumulators per LDS pass
+  constexpr int kRows = kAccFloats + (HAS_EXTRA ? 1 : 0);   // the extra sum rides in the last pass
+  constexpr int kPasses = (kRows + kPass - 1) / kPass;
+  static_assert(kPass + 2 <= 32, "the count rows are folded by threads v = kPass, kPass + 1 of pass 0");
+  // red[kPass][256] AccT | cnt[2][256] f64 | seg[30][8] f64.  The two counts (valid pixels, Σ r² — integers below 2^53)
+  // travel as doubles, which add exactly: with AccT = double they are simply rows kPass and kPass + 1 of the image and every
+  // wave of the fold runs one code path.  seg rows are record slots: 0..26 sums, 27 valid count, 28 Σ r², 29 the extra sum.
   AccT(*red)[kBlock] = reinterpret_cast<AccT(*)[kBlock]>(lds);
-  uint32_t(*redi)[kBlock] = reinterpret_cast<uint32_t(*)[kBlock]>(lds + kPass * kBlock * 8);
-  double(*seg_f)[8] = reinterpret_cast<double(*)[8]>(lds + kPass * kBlock * 8 + 2 * kBlock * 4);
-  unsigned long long(*seg_u)[8] = reinterpret_cast<unsigned long long(*)[8]>(lds + kPass * kBlock * 8 + 2 * kBlock * 4 + (kAccFloats + 1) * 8 * 8);
+  double(*cnt2)[kBlock] = reinterpret_cast<double(*)[kBlock]>(lds + kPass * kBlock * 8);
+  double(*seg_f)[8] = reinterpret_cast<double(*)[8]>(lds + kPass * kBlock * 8 + 2 * kBlock * 8);
   const int tid = threadIdx.x;
   const int v = tid >> 3, seg = tid & 7;
-  redi[0][tid] = n_valid;
-  redi[1][tid] = sum_r2;
+  EXP_STAMP(11);
+  cnt2[0][tid] = (double)n_valid;
+  cnt2[1][tid] = (double)sum_r2;
 #pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
+  for (int pass = 0; pass < kPasses; pass++) {
     const int base = pass * kPass;
-    const int cnt = pass == 0 ? kPass : kAccFloats - kPass + (HAS_EXTRA ? 1 : 0);  // the extra sum rides in pass 1
+    const int cnt = kRows - base < kPass ? kRows - base : kPass;
     if (pass) __syncthreads();
 #pragma unroll
     for (int i = 0; i < kPass; i++)
       if (i < cnt) red[i][tid] = (base + i < kAccFloats) ? acc[base + i < kAccFloats ? base + i : 0] : extra;
     __syncthreads();
-    if (v < cnt) {
-      double s = 0.0;
+    const bool count_row = pass == 0 && v >= kPass && v < kPass + 2;
+    if constexpr (std::is_same<AccT, double>::value) {
+      if (v < cnt || count_row) {
+        const double* row = v < cnt ? red[v] : cnt2[v - kPass];
+        double s = 0.0;
 #pragma unroll 8
-      for (int j = 0; j < 32; j++) s += (double)red[v][seg * 32 + ((j + tid) & 31)];
-      seg_f[base + v][seg] = s;
-    } else if (pass == 0 && v >= kPass && v < kPass + 2) {
-      unsigned long long s = 0;
+        for (int j = 0; j < 32; j++) s += row[seg * 32 + ((j + tid) & 31)];
+        const int slot = v < cnt ? (base + v < kAccFloats ? base + v : 29) : 27 + v - kPass;
+        seg_f[slot][seg] = s;
+      }
+    } else {
+      if (v < cnt) {
+        double s = 0.0;
 #pragma unroll 8
-      for (int j = 0; j < 32; j++) s += redi[v - kPass][seg * 32 + ((j + tid) & 31)];
-      seg_u[v - kPass][seg] = s;
+        for (int j = 0; j < 32; j++) s += (double)red[v][seg * 32 + ((j + tid) & 31)];
+        seg_f[base + v < kAccFloats ? base + v : 29][seg] = s;
+      } else if (count_row) {
+        double s = 0.0;
+#pragma unroll 8
+        for (int j = 0; j < 32; j++) s += cnt2[v - kPass][seg * 32 + ((j + tid) & 31)];
+        seg_f[27 + v - kPass][seg] = s;
+      }
     }
+    EXP_STAMP(12 + pass);
   }
   __syncthreads();
-  if (tid < kAccFloats) {
+  EXP_STAMP(14);
+  if (tid < (HAS_EXTRA ? 30 : 29)) {
     double s = seg_f[tid][0];
 #pragma unroll
     for (int k = 1; k < 8; k++) s += seg_f[tid][k];
-    reinterpret_cast<double*>(rec)[tid] = s;
-  } else if (tid == 27) {
-    unsigned long long s = 0;
-    for (int k = 0; k < 8; k++) s += seg_u[0][k];
-    rec[54] = (uint32_t)s;
-  } else if (tid == 28) {
-    unsigned long long s = 0;
-    for (int k = 0; k < 8; k++) s += seg_u[1][k];
-    reinterpret_cast<unsigned long long*>(rec)[28] = s;
-  } else if (HAS_EXTRA && tid == 29) {
-    double s = seg_f[kAccFloats][0];
-#pragma unroll
-    for (int k = 1; k < 8; k++) s += seg_f[kAccFloats][k];
-    reinterpret_cast<double*>(rec)[29] = s;  // Σ r·(r·w): the error numerator when residuals are not integers / weighted
+    if (tid == 27) rec[54] = (uint32_t)(unsigned long long)s;                                     // valid pixels
+    else if (tid == 28) reinterpret_cast<unsigned long long*>(rec)[28] = (unsigned long long)s;   // Σ r² (integer residuals)
+    else reinterpret_cast<double*>(rec)[tid] = s;   // 29: Σ r·(r·w), the error numerator when residuals are not integers / weighted
+    EXP_STAMP(15);
   }
 }
 
@@ -869,7 +889,10 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   }
   const uint32_t n_valid = (threadIdx.x & 63) == 0 ? n_valid_wave : 0u;
   uint32_t* out_rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
-  if constexpr (EXT_LDS) block_reduce_store_at<AccT, GENERAL>(lds, acc, sum_r2, n_valid, out_rec, err);
+#ifdef UWT_EXP_STAMPS
+  if (threadIdx.x == 0) out_rec[62] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
+  if constexpr (EXT_LDS) block_reduce_store_at<AccT, GENERAL, kIteratePass>(lds, acc, sum_r2, n_valid, out_rec, err);   // the caller's bytes: k_iterate
   else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err);
   if (a.probe && threadIdx.x == 0) {
     uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
@@ -1239,64 +1262,62 @@ struct UpdateArgs {
   int* active;       // optional: counts the pairs still iterating after this update (early-exit polling)
 };
 
-constexpr int kUpdateBlock = 256;   // threads of an updating block: all stage the records, wave 0 folds and solves
-constexpr int kStageRecords = 128;  // records staged in LDS per round (32 KB); more slices take more rounds
-constexpr int kUpdateLdsBytes = kStageRecords * kRecWords * 4 + 512;   // + sums, integer sums, the state to broadcast
+constexpr int kUpdateBlock = 256;   // threads of an updating block: all fold the records, wave 0 solves
+constexpr int kFoldBatch = 16;      // record loads a thread keeps in flight (8 x 16 = 128 records per round trip)
+constexpr int kUpdateLdsBytes = 2 * 8 * 32 * 8 + 512;   // part sums (two readings) + sums, integer sums, the state to broadcast
 
 __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const uint32_t* __restrict__ recs, PairState st,
                                                     unsigned char* __restrict__ lds, bool count_active) {
   const int tid = threadIdx.x, lane = tid & 63;
-  uint4* stage = reinterpret_cast<uint4*>(lds);
-  double* sums = reinterpret_cast<double*>(lds + kStageRecords * kRecWords * 4);          // [kAccFloats + 1]
-  long long* isums = reinterpret_cast<long long*>(sums + kAccFloats + 1);               // [2]
+  double(*part_f)[32] = reinterpret_cast<double(*)[32]>(lds);                              // [8][32] part sums, f64 reading
+  long long(*part_i)[32] = reinterpret_cast<long long(*)[32]>(lds + 8 * 32 * 8);            // [8][32] part sums, integer reading
+  double* sums = reinterpret_cast<double*>(lds + 2 * 8 * 32 * 8);                           // [kAccFloats + 1]
+  long long* isums = reinterpret_cast<long long*>(sums + kAccFloats + 1);                 // [2]
   PairState* s_state = reinterpret_cast<PairState*>(isums + 2);
   const bool live = !(st.level_done || st.status);  // block-uniform
+  EXP_STAMP(0);
   if (live) {
-    // The records travel through LDS in rounds of kStageRecords: every thread pulls a batch of independent 16-byte loads
-    // (one memory round trip per round), then the lanes of wave 0 add their column in slice order — the order of the
-    // sums is the slice order whatever the round size.
+    // Fold of the evaluation's records, all threads at once: a record is 32 eight-byte slots; thread (slot = tid & 31,
+    // part = tid >> 5) pulls slot `slot` of records part, part + 8, part + 16, ... straight from memory — independent
+    // loads, one round trip per kFoldBatch of them — and adds them in that order; the eight part sums of a slot are then
+    // added in part order by one lane.  The order of the additions is fixed by (slices) alone.
+    const int slot = tid & 31, part = tid >> 5;
+    const unsigned long long* g8 = reinterpret_cast<const unsigned long long*>(recs) + slot;
     double cs = 0.0;
     long long is = 0;
-    for (int base = 0; base < a.slices; base += kStageRecords) {
-      const int cnt = min(kStageRecords, a.slices - base);
-      const int n16 = cnt * (kRecWords / 4);
-      const uint4* g4 = reinterpret_cast<const uint4*>(recs + (size_t)base * kRecWords);
-      if (base) __syncthreads();   // the previous round has been folded
-      for (int i0 = 0; i0 < n16; i0 += 4 * kUpdateBlock) {
-        uint4 v[4];
+    for (int q0 = part; q0 < a.slices; q0 += 8 * kFoldBatch) {
+      unsigned long long v[kFoldBatch];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + u * kUpdateBlock + tid;
-          if (i < n16) v[u] = g4[i];
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int i = i0 + u * kUpdateBlock + tid;
-          if (i < n16) stage[i] = v[u];
-        }
+      for (int u = 0; u < kFoldBatch; u++) {
+        const int q = q0 + 8 * u;
+        v[u] = q < a.slices ? g8[(size_t)q * (kRecWords / 2)] : 0ull;   // +0.0 / 0: neutral in both readings
       }
-      __syncthreads();
-      if (tid < 64) {
-        const uint32_t* r = reinterpret_cast<const uint32_t*>(stage);
-        if (lane < kAccFloats || lane == 29) {
-          const double* col = reinterpret_cast<const double*>(r) + lane;
-          for (int q = 0; q < cnt; q++) cs += col[(size_t)q * (kRecWords / 2)];
-        } else if (lane == 27) {
-          for (int q = 0; q < cnt; q++) is += (long long)r[(size_t)q * kRecWords + 54];   // n_valid <= level pixels < 2^32
-        } else if (lane == 28) {
-          const long long* col = reinterpret_cast<const long long*>(r) + 28;
-          for (int q = 0; q < cnt; q++) is += col[(size_t)q * (kRecWords / 2)];
-        }
+#pragma unroll
+      for (int u = 0; u < kFoldBatch; u++) {
+        cs += __longlong_as_double((long long)v[u]);
+        is += (long long)(slot == 27 ? (v[u] & 0xffffffffull) : v[u]);   // slot 27: n_valid in the low word
       }
     }
-    if (tid < 64) {
-      if (lane < kAccFloats) sums[lane] = cs;
-      else if (lane == 27) isums[0] = (long long)(uint32_t)is;
-      else if (lane == 28) isums[1] = is;
-      else if (lane == 29) sums[kAccFloats] = a.general ? cs : 0.0;
+    part_f[part][slot] = cs;
+    part_i[part][slot] = is;
+    __syncthreads();
+    EXP_STAMP(1);
+    if (tid < 32) {
+      double fs = part_f[0][tid];
+      long long ls = part_i[0][tid];
+#pragma unroll
+      for (int q = 1; q < 8; q++) {
+        fs += part_f[q][tid];
+        ls += part_i[q][tid];
+      }
+      if (tid < kAccFloats) sums[tid] = fs;
+      else if (tid == 27) isums[0] = (long long)(uint32_t)ls;
+      else if (tid == 28) isums[1] = ls;
+      else if (tid == 29) sums[kAccFloats] = a.general ? fs : 0.0;
     }
   }
   __syncthreads();
+  EXP_STAMP(5);
   if (tid < 64) {   // wave 0 runs the tail together on the same (uniform) values
     if (live) {
       const int n = (int)isums[0];
@@ -1326,17 +1347,22 @@ __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const u
 #pragma unroll
         for (int i = 0; i < 6; i++)
           b[i] = a.general ? (float)(-sums[21 + i]) : (float)(-((double)a.gain * sums[21 + i]));  // :559-561
+        EXP_STAMP(6);
         solve_delta_wave(sums, b, delta);                                                // :554-564, A = (float)sums[0..20]
+        EXP_STAMP(7);
         Pose d, np;
         se3_exp_wave(delta, d);                                                         // :574
+        EXP_STAMP(8);
         se3_mul(st.pose, d, np);
         st.pose = np;
+        EXP_STAMP(9);
         if (count_active && a.active && lane == 0) atomicAdd(a.active, 1);
       }
     }
     if (lane == 0) *s_state = st;
   }
   __syncthreads();
+  EXP_STAMP(10);
   return *s_state;
 }
 
@@ -1393,7 +1419,7 @@ __device__ __forceinline__ PairState iterate_state(const IterArgs& ia, int pair,
   return st;
 }
 
-constexpr int kIterateLdsBytes = kUpdateLdsBytes > kReduceLdsBytes ? kUpdateLdsBytes : kReduceLdsBytes;
+constexpr int kIterateLdsBytes = kUpdateLdsBytes > reduce_lds_bytes(kIteratePass) ? kUpdateLdsBytes : reduce_lds_bytes(kIteratePass);
 
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, bool COMPUTE_ONLY = false>
 __global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterArgs ia) {
@@ -1401,8 +1427,14 @@ __global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterAr
   const int pair = (int)blockIdx.y + a.pair_base, slice = (int)blockIdx.x;
   // the first group's reference planes do not depend on the pose: their (cold) loads travel while the update runs
   RefGroup<VEC> first;
+#ifdef UWT_EXP_STAMPS
+  const uint32_t stamp0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
   load_first_group<VEC, DEPTH, COMPUTE_ONLY>(first, a, pair, slice);
   PairState st = iterate_state(ia, pair, lds, slice == 0);
+#ifdef UWT_EXP_STAMPS
+  const uint32_t stamp1 = (uint32_t)__builtin_amdgcn_s_memrealtime();
+#endif
   if (slice == 0 && threadIdx.x == 0) ia.state_out[pair] = st;
   if constexpr (COMPUTE_ONLY) {
     st.level_done = 0;
@@ -1412,6 +1444,14 @@ __global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterAr
   if (st.level_done || st.status) return;
   __syncthreads();   // the staging bytes become the reduction's
   residual_core<VEC, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, COMPUTE_ONLY, true>(a, pair, slice, st.pose, lds, &first);
+#ifdef UWT_EXP_STAMPS
+  if (threadIdx.x == 0) {   // experiment: 100 MHz wall stamps of this block's phases in the record's spare words
+    uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
+    rec[60] = stamp0;
+    rec[61] = stamp1;
+    rec[63] = (uint32_t)__builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 struct StatsOut { int status, iterations, n_valid; float error; };
