@@ -354,8 +354,9 @@ def test_identical_frames_identity_and_status_codes(capi, synth):
         ctx.estimate_pose_batch([0], [1], raise_on_pair_failure=True)
     with pytest.raises(capi.UwtError):
         ctx.estimate_pose_batch([0], [7])          # slot out of range
-    with pytest.raises(capi.UwtError):
+    with pytest.raises(capi.UwtError) as e:
         ctx.estimate_pose_batch([0, 0], [1, 1])    # exceeds max_pairs
+    assert e.value.status == capi.ERR_CAPACITY
     with pytest.raises(capi.UwtError):
         capi.Context(capi.default_params(100, 96, *MID))  # width not divisible by 2^(levels-1)
 

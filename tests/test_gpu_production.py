@@ -181,6 +181,32 @@ def test_speculative_launching_redoes_a_cut_short_alignment(capi, O, synth, monk
         assert np.array_equal(pose.view(np.uint32), pose_cpu.view(np.uint32)) and iters == len(tr)
 
 
+@pytest.mark.parametrize("mode", ["reference", "fixed"])
+def test_two_pairs_with_slots_in_the_kernel_arguments(capi, O, synth, mode):
+    """The synchronous call with one or two pairs hands the frame slots to k_iterate in its arguments and has the results
+    written into page-locked host memory: two different pairs in scrambled slots (ref 3 / tgt 1, ref 0 / tgt 2), then the
+    same context with the pairs swapped and with one pair only — every pose and count the oracle's."""
+    w, h = 320, 240
+    intr = (262.5, 262.5, 159.5, 119.5)
+    over = dict(has_depth=1) if mode == "reference" else dict(has_depth=1, n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0)
+    pairs = [synth.render_pair(w, h, *intr, seed=4100 + i, max_t=0.015, max_deg=0.8, with_depth=True)[:3] for i in range(2)]
+    want = [O.align_pair(O.default_params(w, h, *intr, **over), r, t, d, want_trace=True) for r, t, d in pairs]
+    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=4, max_pairs=2, **over))
+    slots = [(3, 1), (0, 2)]
+    for (r, t, d), (rs, ts) in zip(pairs, slots):
+        ctx.upload_frames(rs, r[None], d[None])
+        ctx.upload_frames(ts, t[None], d[None])
+    ctx.build_pyramids(0, 4)
+    ctx.apply_gradient(0, 4)
+    for order in ([0, 1], [1, 0], [1], [0]):
+        poses, stats = ctx.estimate_pose_batch([slots[i][0] for i in order], [slots[i][1] for i in order], raise_on_pair_failure=True)
+        for k, i in enumerate(order):
+            st, pose_cpu, tr = want[i]
+            assert st == 0
+            assert np.array_equal(poses[k].view(np.uint32), pose_cpu.view(np.uint32)) and stats[k]["iterations"] == len(tr)
+    ctx.close()
+
+
 # ------------------------------------------------------------------ launch paths of bench.py
 
 def _run(cmd, extra_env=None, timeout=540):

@@ -74,7 +74,14 @@ struct uwt_ctx {
   bool profiling = false;
   bool speculate = false;               // set by the synchronous entry for one or two pairs: launch a level's usual number of
                                         // iterations without reading back, check once at the end, redo conservatively if cut short
-  int* d_cut = nullptr;
+  // the synchronous small-batch call: results and the cut-short flag are written by the last kernel straight into this
+  // page-locked block (no device-to-host copies), and one or two pairs travel in the kernel arguments (no pair list upload)
+  static constexpr int kSmallBatch = 8;
+  struct SmallResults { float poses[kSmallBatch * 7]; StatsOut stats[kSmallBatch]; int cut; };
+  SmallResults* h_small = nullptr;      // pinned, device-visible
+  SmallResults* d_small = nullptr;      // its device address
+  bool inline_pairs = false;
+  int pair_slots[4] = {0, 0, 0, 0};
   int first_poll = 3;                   // evaluations of a level before the first early-exit read-back
   int chained = -1;                     // -1: chained flow for n_pairs <= 2; UWT_CHAINED=1 / 0: always / never (A/B runs)
   const uint32_t* prof_records = nullptr;
@@ -433,8 +440,10 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
   // caller looks once, behind the results, and redoes the alignment the careful way in that (rare) case.
   const bool speculate = c->speculate && p.early_exit;
   const int spec_iters = std::min(p.max_iters, c->first_poll + 1);
-  ia.cut_short = speculate ? c->d_cut : nullptr;
-  if (speculate) HIPCHK(c, hipMemsetAsync(c->d_cut, 0, sizeof(int), c->stream));
+  ia.cut_short = speculate ? &c->d_small->cut : nullptr;
+  if (speculate) c->h_small->cut = 0;   // host store into page-locked memory, ahead of the launches that may set it
+  ia.inline_pairs = c->inline_pairs ? 1 : 0;
+  for (int i = 0; i < 4; i++) ia.pair_slots[i] = c->pair_slots[i];
   for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
     if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(c->stream, level_ready[lvl], 0));  // its gradients
     ResidualArgs ra = residual_args(c, lvl);
@@ -509,13 +518,16 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
 }
 
 // Tracker::EstimatePose for a batch, enqueued on the context's stream (src/Tracker.cpp:362-597)
+// The chained flow pays where an alignment is bound by kernel boundaries and dependent round trips, not by arithmetic: a
+// pair or two on their own (the drop-in call).  In a batch every block would repeat its pair's update (UWT_CHAINED=1 / 0
+// force it on / off for A/B runs).
+static bool takes_chained_flow(const uwt_ctx* c, int n_pairs) {
+  return c->vec == 4 && c->p.sampler == 0 && c->p.weights == 0 && (c->chained > 0 || (c->chained < 0 && n_pairs <= 2));
+}
+
 int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats, const hipEvent_t* level_ready = nullptr) {
   const uwt_params& p = c->p;
-  // The chained flow pays where an alignment is bound by kernel boundaries and dependent round trips, not by arithmetic: a
-  // pair or two on their own (the drop-in call).  In a batch every block would repeat its pair's update (UWT_CHAINED=1 / 0
-  // force it on / off for A/B runs).
-  if (c->vec == 4 && p.sampler == 0 && p.weights == 0 && (c->chained > 0 || (c->chained < 0 && n_pairs <= 2)))
-    return enqueue_estimate_chained(c, n_pairs, d_poses, d_stats, level_ready);
+  if (takes_chained_flow(c, n_pairs)) return enqueue_estimate_chained(c, n_pairs, d_poses, d_stats, level_ready);
   const int tb = 128;
   hipLaunchKernelGGL(k_init_state, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs,
                      p.initial_error);
@@ -779,7 +791,8 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_poses, sizeof(float) * 7 * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_stats, sizeof(StatsOut) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_active, sizeof(int)));
-  CREATE_CHK(hipMalloc((void**)&c->d_cut, sizeof(int)));
+  CREATE_CHK(hipHostMalloc((void**)&c->h_small, sizeof(uwt_ctx::SmallResults)));
+  CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_small, c->h_small, 0));
   if (const char* e = std::getenv("UWT_TARGET_BLOCKS")) c->target_blocks = std::max(1, std::atoi(e));  // tuning experiments only
   if (p->sampler || p->weights) {
     CREATE_CHK(hipMalloc((void**)&c->hist, sizeof(unsigned int) * kHistBins * p->max_pairs));
@@ -815,7 +828,7 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stats) (void)hipFree(c->d_stats);
   if (c->d_active) (void)hipFree(c->d_active);
-  if (c->d_cut) (void)hipFree(c->d_cut);
+  if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->hist) (void)hipFree(c->hist);
   if (c->scale) (void)hipFree(c->scale);
   if (c->h_active) (void)hipHostFree(c->h_active);
@@ -1014,26 +1027,49 @@ int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slot
                             float* poses_out, uwt_stats* stats_out) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !poses_out) return fail(c, UWT_ERR_INVALID_ARG, "uwt_estimate_pose_batch: null argument");
-  int st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
-  if (st) return st;
+  if (!ref_slots || !tgt_slots || n_pairs < 1) return fail(c, UWT_ERR_INVALID_ARG, "null pair lists or n_pairs < 1");
+  if (n_pairs > c->p.max_pairs) return fail(c, UWT_ERR_CAPACITY, "n_pairs exceeds max_pairs");
+  int st;
+  c->inline_pairs = n_pairs <= 2 && takes_chained_flow(c, n_pairs);
+  if (c->inline_pairs) {   // the slots travel in the kernel arguments
+    for (int i = 0; i < n_pairs; i++) {
+      if (ref_slots[i] < 0 || ref_slots[i] >= c->p.max_frames || tgt_slots[i] < 0 || tgt_slots[i] >= c->p.max_frames) {
+        c->inline_pairs = false;
+        return fail(c, UWT_ERR_INVALID_ARG, "pair slot out of range");
+      }
+      c->pair_slots[2 * i] = ref_slots[i];
+      c->pair_slots[2 * i + 1] = tgt_slots[i];
+    }
+  } else {
+    st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
+    if (st) return st;
+  }
   st = compute_begin(c, 0, c->p.max_frames);
-  if (st) return st;
+  if (st) { c->inline_pairs = false; return st; }
   std::vector<uwt_stats> tmp(n_pairs);
+  // A small batch has its results written by the last kernel straight into page-locked host memory: nothing to copy back.
+  const bool small = n_pairs <= uwt_ctx::kSmallBatch;
+  static_assert(sizeof(StatsOut) == sizeof(uwt_stats), "stats are copied as they are");
   // One or two pairs under an early-exit schedule are launched speculatively (see enqueue_estimate_chained): no read-back
   // inside the alignment, one look at the "cut short" flag behind the results, a careful second run if it is set.
-  c->speculate = n_pairs <= 2 && c->p.early_exit && !c->profiling && c->chained != 0 && !std::getenv("UWT_NO_SPECULATION");
+  c->speculate = n_pairs <= 2 && c->p.early_exit && !c->profiling && takes_chained_flow(c, n_pairs) && !std::getenv("UWT_NO_SPECULATION");
   for (int attempt = 0; attempt < 2; attempt++) {
-    st = enqueue_estimate(c, n_pairs, c->d_poses, c->d_stats);
-    if (st) { c->speculate = false; return st; }
-    int cut = 0;
-    HIPCHK(c, hipMemcpyAsync(poses_out, c->d_poses, sizeof(float) * 7 * n_pairs, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_stats, sizeof(uwt_stats) * n_pairs, hipMemcpyDeviceToHost, c->stream));
-    if (c->speculate) HIPCHK(c, hipMemcpyAsync(&cut, c->d_cut, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    st = enqueue_estimate(c, n_pairs, small ? c->d_small->poses : c->d_poses, small ? c->d_small->stats : c->d_stats);
+    if (st) { c->speculate = false; c->inline_pairs = false; return st; }
+    if (!small) {
+      HIPCHK(c, hipMemcpyAsync(poses_out, c->d_poses, sizeof(float) * 7 * n_pairs, hipMemcpyDeviceToHost, c->stream));
+      HIPCHK(c, hipMemcpyAsync(tmp.data(), c->d_stats, sizeof(uwt_stats) * n_pairs, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    const bool redo = c->speculate && cut != 0;
+    if (small) {
+      std::memcpy(poses_out, c->h_small->poses, sizeof(float) * 7 * n_pairs);
+      std::memcpy(tmp.data(), c->h_small->stats, sizeof(uwt_stats) * n_pairs);
+    }
+    const bool redo = c->speculate && c->h_small->cut != 0;
     c->speculate = false;
     if (!redo) break;
   }
+  c->inline_pairs = false;
   if (c->profiling) {
     st = prof_collect(c);
     if (st) return st;

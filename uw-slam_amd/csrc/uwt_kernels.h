@@ -706,12 +706,13 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
           bool COMPUTE_ONLY = false, bool EXT_LDS = false>
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
-                                              unsigned char* lds, const RefGroup<VEC>* first = nullptr);
+                                              unsigned char* lds, const RefGroup<VEC>* first = nullptr, int ref_slot = -1,
+                                              int tgt_slot = -1);
 
 // the reference planes of the first group of (pair, slice) for this thread: what residual_core loads before anything else
 template <int VEC, bool DEPTH, bool COMPUTE_ONLY>
-__device__ __forceinline__ void load_first_group(RefGroup<VEC>& rg, const ResidualArgs& a, int pair, int slice) {
-  const size_t ref_off = (size_t)a.ref_slots[pair] * a.L.n;
+__device__ __forceinline__ void load_first_group(RefGroup<VEC>& rg, const ResidualArgs& a, int ref_slot, int slice) {
+  const size_t ref_off = (size_t)ref_slot * a.L.n;
   const int n_groups = a.L.n / VEC;
   const int g = slice * a.groups_per_block + (int)threadIdx.x;
   load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, a.img + ref_off, a.gx + ref_off, a.gy + ref_off, DEPTH ? a.depth + ref_off : nullptr,
@@ -737,14 +738,18 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
           bool EXT_LDS>
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
-                                              unsigned char* lds, const RefGroup<VEC>* first) {
+                                              unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot) {
   WarpK K;
   pose_to_T12(pose, K.T);
 #pragma unroll
   for (int i = 0; i < 12; i++)  // the rigid matrix is block-uniform: keep it in scalar registers
     K.T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(K.T[i])));
   const LevelK L = a.L;
-  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
+  if (ref_slot < 0) {   // the pair list in memory (batches); k_iterate hands the slots over
+    ref_slot = a.ref_slots[pair];
+    tgt_slot = a.tgt_slots[pair];
+  }
+  const size_t ref_off = (size_t)ref_slot * L.n, tgt_off = (size_t)tgt_slot * L.n;
   const uint8_t* __restrict__ I1 = a.img + ref_off;
   const uint8_t* __restrict__ I2 = a.img + tgt_off;
   const int16_t* __restrict__ GX = a.gx + ref_off;
@@ -1391,7 +1396,9 @@ struct IterArgs {
   int scale_t;
   float initial_error;
   int* cut_short;             // optional (speculative launching, early-exit schedules): set when a level's launches ran out
-                              // before the pair's exit test fired, i.e. the host stopped launching too early
+                              // before the pair's exit test fired, i.e. the host stopped launching too early (may be host memory)
+  int inline_pairs;           // 1: the (at most two) pairs' slots travel in the kernel arguments, no pair list in memory
+  int pair_slots[4];          // ref 0, tgt 0, ref 1, tgt 1
 };
 
 __device__ __forceinline__ PairState iterate_state(const IterArgs& ia, int pair, unsigned char* lds, bool count_active) {
@@ -1409,7 +1416,8 @@ __device__ __forceinline__ PairState iterate_state(const IterArgs& ia, int pair,
   st = update_compute(ia.u, ia.u.partials + (size_t)pair * ia.u.slices * kRecWords, ia.state_in[pair], lds, count_active);
   if (ia.mode == 2) {   // end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
     // with early exit a level ends only through its exit test (which fires at the last iteration at the latest)
-    if (ia.cut_short && ia.u.early_exit && !st.level_done && st.status == 0 && count_active && threadIdx.x == 0) atomicOr(ia.cut_short, 1);
+    if (ia.cut_short && ia.u.early_exit && !st.level_done && st.status == 0 && count_active && threadIdx.x == 0)
+      __hip_atomic_store(ia.cut_short, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     if (st.status == 0 && ia.prev_lvl != 0) {
       if (!se3_handoff(st.pose, ia.scale_t != 0)) st.status = 1;  // SOPHUS_ENSURE would abort
     }
@@ -1430,7 +1438,11 @@ __global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterAr
 #ifdef UWT_EXP_STAMPS
   const uint32_t stamp0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
-  load_first_group<VEC, DEPTH, COMPUTE_ONLY>(first, a, pair, slice);
+  const int lp = (int)blockIdx.y;
+  // (selects, not an indexed read: indexing the by-value argument would send it through scratch memory)
+  const int ref_slot = ia.inline_pairs ? (lp == 0 ? ia.pair_slots[0] : ia.pair_slots[2]) : a.ref_slots[pair];
+  const int tgt_slot = ia.inline_pairs ? (lp == 0 ? ia.pair_slots[1] : ia.pair_slots[3]) : a.tgt_slots[pair];
+  load_first_group<VEC, DEPTH, COMPUTE_ONLY>(first, a, ref_slot, slice);
   PairState st = iterate_state(ia, pair, lds, slice == 0);
 #ifdef UWT_EXP_STAMPS
   const uint32_t stamp1 = (uint32_t)__builtin_amdgcn_s_memrealtime();
@@ -1443,7 +1455,7 @@ __global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterAr
   }
   if (st.level_done || st.status) return;
   __syncthreads();   // the staging bytes become the reduction's
-  residual_core<VEC, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, COMPUTE_ONLY, true>(a, pair, slice, st.pose, lds, &first);
+  residual_core<VEC, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, COMPUTE_ONLY, true>(a, pair, slice, st.pose, lds, &first, ref_slot, tgt_slot);
 #ifdef UWT_EXP_STAMPS
   if (threadIdx.x == 0) {   // experiment: 100 MHz wall stamps of this block's phases in the record's spare words
     uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
