@@ -1271,7 +1271,7 @@ constexpr int kUpdateBlock = 256;   // threads of an updating block: all fold th
 constexpr int kFoldBatch = 16;      // record loads a thread keeps in flight (8 x 16 = 128 records per round trip)
 constexpr int kUpdateLdsBytes = 2 * 8 * 32 * 8 + 512;   // part sums (two readings) + sums, integer sums, the state to broadcast
 
-__device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const uint32_t* __restrict__ recs, PairState st,
+__device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const uint32_t* __restrict__ recs, const PairState* __restrict__ st_in,
                                                     unsigned char* __restrict__ lds, bool count_active) {
   const int tid = threadIdx.x, lane = tid & 63;
   double(*part_f)[32] = reinterpret_cast<double(*)[32]>(lds);                              // [8][32] part sums, f64 reading
@@ -1279,28 +1279,37 @@ __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const u
   double* sums = reinterpret_cast<double*>(lds + 2 * 8 * 32 * 8);                           // [kAccFloats + 1]
   long long* isums = reinterpret_cast<long long*>(sums + kAccFloats + 1);                 // [2]
   PairState* s_state = reinterpret_cast<PairState*>(isums + 2);
+  // Fold of the evaluation's records, all threads at once: a record is 32 eight-byte slots; thread (slot = tid & 31,
+  // part = tid >> 5) pulls slot `slot` of records part, part + 8, part + 16, ... straight from memory — independent
+  // loads, one round trip per kFoldBatch of them — and adds them in that order; the eight part sums of a slot are then
+  // added in part order by one lane.  The order of the additions is fixed by (slices) alone.  The first batch is requested
+  // before the pair's state is looked at, so that both arrive in one round trip.
+  const int slot = tid & 31, part = tid >> 5;
+  const unsigned long long* g8 = reinterpret_cast<const unsigned long long*>(recs) + slot;
+  unsigned long long v[kFoldBatch];
+#pragma unroll
+  for (int u = 0; u < kFoldBatch; u++) {
+    const int q = part + 8 * u;
+    v[u] = q < a.slices ? g8[(size_t)q * (kRecWords / 2)] : 0ull;   // +0.0 / 0: neutral in both readings
+  }
+  PairState st = *st_in;
   const bool live = !(st.level_done || st.status);  // block-uniform
   EXP_STAMP(0);
   if (live) {
-    // Fold of the evaluation's records, all threads at once: a record is 32 eight-byte slots; thread (slot = tid & 31,
-    // part = tid >> 5) pulls slot `slot` of records part, part + 8, part + 16, ... straight from memory — independent
-    // loads, one round trip per kFoldBatch of them — and adds them in that order; the eight part sums of a slot are then
-    // added in part order by one lane.  The order of the additions is fixed by (slices) alone.
-    const int slot = tid & 31, part = tid >> 5;
-    const unsigned long long* g8 = reinterpret_cast<const unsigned long long*>(recs) + slot;
     double cs = 0.0;
     long long is = 0;
-    for (int q0 = part; q0 < a.slices; q0 += 8 * kFoldBatch) {
-      unsigned long long v[kFoldBatch];
-#pragma unroll
-      for (int u = 0; u < kFoldBatch; u++) {
-        const int q = q0 + 8 * u;
-        v[u] = q < a.slices ? g8[(size_t)q * (kRecWords / 2)] : 0ull;   // +0.0 / 0: neutral in both readings
-      }
+    for (int q0 = part;;) {
 #pragma unroll
       for (int u = 0; u < kFoldBatch; u++) {
         cs += __longlong_as_double((long long)v[u]);
         is += (long long)(slot == 27 ? (v[u] & 0xffffffffull) : v[u]);   // slot 27: n_valid in the low word
+      }
+      q0 += 8 * kFoldBatch;
+      if (q0 >= a.slices) break;
+#pragma unroll
+      for (int u = 0; u < kFoldBatch; u++) {
+        const int q = q0 + 8 * u;
+        v[u] = q < a.slices ? g8[(size_t)q * (kRecWords / 2)] : 0ull;
       }
     }
     part_f[part][slot] = cs;
@@ -1321,7 +1330,7 @@ __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const u
       else if (tid == 29) sums[kAccFloats] = a.general ? fs : 0.0;
     }
   }
-  __syncthreads();
+  __builtin_amdgcn_wave_barrier();   // the sums were written by lanes of wave 0, which alone reads them
   EXP_STAMP(5);
   if (tid < 64) {   // wave 0 runs the tail together on the same (uniform) values
     if (live) {
@@ -1374,7 +1383,7 @@ __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const u
 __global__ __launch_bounds__(kUpdateBlock) void k_gn_update(const UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kUpdateLdsBytes];
   const int pair = (int)blockIdx.x + a.pair_base;
-  const PairState st = update_compute(a, a.partials + (size_t)pair * a.slices * kRecWords, a.state[pair], lds, true);
+  const PairState st = update_compute(a, a.partials + (size_t)pair * a.slices * kRecWords, &a.state[pair], lds, true);
   if (threadIdx.x == 0) a.state[pair] = st;
 }
 
@@ -1413,7 +1422,7 @@ __device__ __forceinline__ PairState iterate_state(const IterArgs& ia, int pair,
     st.n_valid = 0;
     return st;
   }
-  st = update_compute(ia.u, ia.u.partials + (size_t)pair * ia.u.slices * kRecWords, ia.state_in[pair], lds, count_active);
+  st = update_compute(ia.u, ia.u.partials + (size_t)pair * ia.u.slices * kRecWords, &ia.state_in[pair], lds, count_active);
   if (ia.mode == 2) {   // end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
     // with early exit a level ends only through its exit test (which fires at the last iteration at the latest)
     if (ia.cut_short && ia.u.early_exit && !st.level_done && st.status == 0 && count_active && threadIdx.x == 0)
