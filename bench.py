@@ -128,6 +128,35 @@ def streaming_figure(capi, params, frames, depth, P, rounds, resident_poses):
                     "pipeline's fill (first upload) and drain (last alignment)"}
 
 
+def latency_figure(capi, params, frames, depth, resident_pose, reps=200):
+    """Secondary figure (never `value`): the drop-in use, one pair per synchronous call (Tracker::EstimatePose on a frame
+    pair whose pyramids and gradients are in place, src/System.cpp:193-223) — the bench's own schedule, and the reference's
+    (5 levels, iterate 4..1, early exit).  A context of its own; pose of the bench schedule checked against the batch's."""
+    h, w = frames.shape[1:]
+    out = {"unit": "ms per alignment, one pair per call", "calls_timed": reps}
+    keep = {k: getattr(params, k) for k in ("n_levels", "first_level", "last_level", "max_iters", "early_exit", "has_depth",
+                                            "accumulate_f64", "device")}
+    for name in ("bench_schedule", "reference_schedule"):
+        over = dict(keep) if name == "bench_schedule" else dict(has_depth=keep["has_depth"], accumulate_f64=keep["accumulate_f64"], device=keep["device"])
+        if name == "reference_schedule" and (w % 16 or h % 16):
+            continue
+        ctx = capi.Context(capi.default_params(w, h, params.fx, params.fy, params.cx, params.cy, max_frames=2, max_pairs=1, **over))
+        ctx.upload_frames(0, frames[0:2], depth[0:2] if depth is not None else None)
+        ctx.build_pyramids(0, 2)
+        ctx.apply_gradient(0, 2)
+        for _ in range(10):
+            poses, stats = ctx.estimate_pose_batch([0], [1])
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            poses, stats = ctx.estimate_pose_batch([0], [1])
+        out[name + "_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+        out[name + "_evaluations"] = int(stats[0]["iterations"])
+        if name == "bench_schedule":
+            out["pose_bit_identical_to_batch"] = bool(np.array_equal(poses[0].view(np.uint32), resident_pose.view(np.uint32)))
+        ctx.close()
+    return out
+
+
 def main(args):
     # A stalled run ends with every thread's Python traceback instead of sitting there until the caller's clock runs out.
     faulthandler.dump_traceback_later(int(os.environ.get("UWT_BENCH_WATCHDOG_S", "1500")), exit=True)
@@ -266,6 +295,10 @@ def main(args):
     # per-kernel statistics that are compared with roofline.avg_launch_ms)
     if not args.no_profile and world == 1 and not args.reference_schedule and not _under_profiler():
         streaming = streaming_figure(capi, params, frames, depth, P, max(3, args.steps // 2), gpu_poses)   # 2 batches per round
+    latency = None
+    if not args.no_profile and world == 1 and not args.reference_schedule and not args.bilinear and args.weights == "identity" \
+            and not _under_profiler():
+        latency = latency_figure(capi, params, frames, depth, gpu_poses[0])
 
     value = total * args.steps / dt
     px_per_align = sum((w >> l) * (h >> l) for l in range(args.levels))
@@ -308,6 +341,8 @@ def main(args):
                                 "note": "one blocking upload of the rank's resident batch from pageable host memory + one step"}
         if streaming:
             out["streaming"] = streaming
+        if latency:
+            out["single_pair_latency"] = latency
         if res_launches:
             facts = {}
             if os.path.exists(PROFILE_FACTS):
