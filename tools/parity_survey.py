@@ -15,6 +15,7 @@ ap.add_argument("--h", type=int, default=96)
 ap.add_argument("--mode", default="fixed")
 ap.add_argument("--depth", type=int, default=0)
 ap.add_argument("--seed0", type=int, default=1000)
+ap.add_argument("--single", type=int, default=0, help="1: one pair per synchronous call (the chained k_iterate flow)")
 a = ap.parse_args()
 w, h = a.w, a.h
 f = 525.0 * w / 640.0
@@ -40,7 +41,14 @@ for s in range(n):
 t_cpu = time.time() - t0
 ctx.upload_frames(0, np.stack(frames), np.stack(depths) if a.depth else None)
 ctx.build_pyramids(0, 2 * n); ctx.apply_gradient(0, 2 * n)
-poses, stats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1)
+if a.single:
+    poses, stats = [], []
+    for i in range(n):
+        p1, s1 = ctx.estimate_pose_batch([2 * i], [2 * i + 1])
+        poses.append(p1[0].copy()); stats.append(s1[0])
+    poses = np.stack(poses)
+else:
+    poses, stats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1)
 def rot_angle(qa, qb):
     qa, qb = qa.astype(np.float64), qb.astype(np.float64)
     wv = abs(float(np.dot(qa, qb)))
@@ -50,7 +58,7 @@ dr = np.array([rot_angle(poses[i][:4], cpu[i][1][:4]) for i in range(n)])
 dt = np.array([np.linalg.norm(poses[i][4:].astype(np.float64) - cpu[i][1][4:]) for i in range(n)])
 bit = sum(np.array_equal(poses[i].view(np.uint32), cpu[i][1].view(np.uint32)) for i in range(n))
 it_eq = sum(stats[i]["iterations"] == cpu[i][2] for i in range(n))
-print("mode %s %dx%d depth=%d n=%d: bit-identical %d, iterations equal %d, status!=0 %d" % (a.mode, w, h, a.depth, n, bit, it_eq, sum(s["status"] != 0 for s in stats)))
+print("mode %s%s %dx%d depth=%d n=%d: bit-identical %d, iterations equal %d, status!=0 %d" % (a.mode, " (one pair per call)" if a.single else " (one batch)", w, h, a.depth, n, bit, it_eq, sum(s["status"] != 0 for s in stats)))
 print("  rot  diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dr), np.percentile(dr, 90), dr.max(), (dr > 1e-4).sum()))
 print("  trans diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dt), np.percentile(dt, 90), dt.max(), (dt > 1e-4).sum()))
 print("  |t| median %.2e ; cpu time/pair %.3fs" % (np.median([np.linalg.norm(c[1][4:]) for c in cpu]), t_cpu / n))
