@@ -284,7 +284,11 @@ class Tracker {
     return L;
   }
   uwt_ctx* ctx() {
-    if (!ctx_) check(uwt_create(&params_, &ctx_), "uwt_create");
+    if (!ctx_) {
+      check(uwt_create(&params_, &ctx_), "uwt_create");
+      // the per-frame sequence (upload + pyramid in bind(), ApplyGradient, EstimatePose) waits once, in EstimatePose
+      check(uwt_set_deferred(ctx_, 1), "uwt_set_deferred");
+    }
     return ctx_;
   }
 

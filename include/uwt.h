@@ -168,6 +168,13 @@ int uwt_track_batch_host_async(uwt_ctx* ctx, int32_t first_slot, int32_t n_frame
 /* blocks until the call that returned `ticket` (and its result copy) has completed; later calls keep running */
 int uwt_wait_ticket(uwt_ctx* ctx, int64_t ticket);
 int uwt_sync(uwt_ctx* ctx);
+/* Deferred stage calls (off by default).  on = 1: uwt_build_pyramids and uwt_apply_gradient return once their kernels are
+ * enqueued on the context's stream; every later call of the context runs behind them, and the calls that hand results to
+ * the host (uwt_estimate_pose_*, uwt_get_plane, uwt_sync, ...) wait as before — the per-frame sequence of
+ * System::AddFrame + System::Tracking (src/System.cpp:193-251) then waits once per frame, in EstimatePose, instead of
+ * three times.  A kernel failure of a deferred call is reported by the next waiting call.  A consumer that reads
+ * uwt_plane_device_ptr planes on a stream of its own must uwt_sync first. */
+int uwt_set_deferred(uwt_ctx* ctx, int32_t on);
 /* the HIP stream (hipStream_t) the context launches on, for event timing by the caller */
 int uwt_stream(uwt_ctx* ctx, void** out);
 /* average device time in ms of the residual/Jacobian/reduction kernel launches and their count since the last

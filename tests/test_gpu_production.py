@@ -207,6 +207,36 @@ def test_two_pairs_with_slots_in_the_kernel_arguments(capi, O, synth, mode):
     ctx.close()
 
 
+def test_deferred_stage_calls_wait_once_per_frame(capi, O, synth):
+    """uwt_set_deferred(1): uwt_build_pyramids / uwt_apply_gradient only enqueue; a plane read right behind them and the
+    alignment that follows deliver what the synchronous calls deliver — a sliding sequence of frames through two slots."""
+    w, h = 320, 240
+    intr = (262.5, 262.5, 159.5, 119.5)
+    seq = [synth.render_pair(w, h, *intr, seed=7700 + i, max_t=0.01, max_deg=0.5, with_depth=True)[:3] for i in range(3)]
+    frames = [seq[0][0], seq[0][1], seq[1][1], seq[2][1]]       # unrelated textures after the first pair: poses still defined
+    dep = seq[0][2]
+    po = O.default_params(w, h, *intr, has_depth=1)
+    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, has_depth=1))
+    ctx.set_deferred(True)
+    ctx.upload_frames(0, frames[0][None], dep[None])
+    ctx.build_pyramids(0, 1)
+    for i in range(1, len(frames)):
+        cur, prev = i % 2, (i + 1) % 2
+        ctx.upload_frames(cur, frames[i][None], dep[None])
+        ctx.build_pyramids(cur, 1)
+        ctx.apply_gradient(prev, 1)
+        if i == 1:   # read straight behind the deferred calls
+            gx, gy = O.scharr3(O.halve_u8(frames[0]))
+            assert np.array_equal(ctx.get_plane(prev, 1, capi.PLANE_GRADX), gx)
+            assert np.array_equal(ctx.get_plane(cur, 2, capi.PLANE_IMAGE), O.halve_u8(O.halve_u8(frames[1])))
+        poses, stats = ctx.estimate_pose_batch([prev], [cur])
+        st, pose_cpu, tr = O.align_pair(po, frames[i - 1], frames[i], dep, want_trace=True)
+        assert stats[0]["status"] == st
+        if st == 0:
+            assert np.array_equal(poses[0].view(np.uint32), pose_cpu.view(np.uint32)) and stats[0]["iterations"] == len(tr)
+    ctx.close()
+
+
 # ------------------------------------------------------------------ launch paths of bench.py
 
 def _run(cmd, extra_env=None, timeout=540):

@@ -45,7 +45,7 @@ class Accum(C.Structure):
 SYMBOLS = [
     "uwt_abi_version", "uwt_status_string", "uwt_last_error", "uwt_default_params", "uwt_create", "uwt_destroy",
     "uwt_level_info", "uwt_set_frame", "uwt_upload_frames", "uwt_upload_frames_async", "uwt_host_alloc", "uwt_host_free", "uwt_plane_device_ptr", "uwt_get_plane",
-    "uwt_build_pyramids", "uwt_apply_gradient", "uwt_estimate_pose_batch", "uwt_track_batch_async", "uwt_track_batch_host_async", "uwt_wait_ticket", "uwt_sync",
+    "uwt_build_pyramids", "uwt_apply_gradient", "uwt_estimate_pose_batch", "uwt_track_batch_async", "uwt_track_batch_host_async", "uwt_wait_ticket", "uwt_sync", "uwt_set_deferred",
     "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_profile_clock", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
     "uwt_warp", "uwt_residual_jacobian", "uwt_ls_accumulate", "uwt_se3_exp", "uwt_se3_mul", "uwt_se3_matrix",
     "uwt_se3_handoff", "uwt_solve_delta", "uwt_accumulate_trajectory", "uwt_accumulate_trajectory_scan",
@@ -274,6 +274,10 @@ class Context:
 
     def sync(self):
         self._chk(lib().uwt_sync(self._h))
+
+    def set_deferred(self, on=True):
+        """build_pyramids / apply_gradient return once enqueued; the calls that deliver results wait as before."""
+        self._chk(lib().uwt_set_deferred(self._h, int(on)))
 
     def stream(self):
         out = C.c_void_p()

@@ -81,6 +81,7 @@ struct uwt_ctx {
   SmallResults* h_small = nullptr;      // pinned, device-visible
   SmallResults* d_small = nullptr;      // its device address
   bool inline_pairs = false;
+  bool deferred = false;                // uwt_set_deferred: stage calls return once enqueued
   int pair_slots[4] = {0, 0, 0, 0};
   int first_poll = 3;                   // evaluations of a level before the first early-exit read-back
   int chained = -1;                     // -1: chained flow for n_pairs <= 2; UWT_CHAINED=1 / 0: always / never (A/B runs)
@@ -1001,6 +1002,12 @@ static int enqueue_gradients(uwt_ctx* c, int first_slot, int n, const int* d_slo
   return UWT_OK;
 }
 
+int uwt_set_deferred(uwt_ctx* c, int32_t on) {
+  if (!c) return UWT_ERR_INVALID_ARG;
+  c->deferred = on != 0;
+  return UWT_OK;
+}
+
 int uwt_build_pyramids(uwt_ctx* c, int32_t first_slot, int32_t n) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_build_pyramids: bad range");
@@ -1008,7 +1015,7 @@ int uwt_build_pyramids(uwt_ctx* c, int32_t first_slot, int32_t n) {
   if (st) return st;
   st = enqueue_pyramids(c, first_slot, n);
   if (st) return st;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!c->deferred) HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
 }
 
@@ -1019,7 +1026,7 @@ int uwt_apply_gradient(uwt_ctx* c, int32_t first_slot, int32_t n) {
   if (st) return st;
   st = enqueue_gradients(c, first_slot, n);
   if (st) return st;
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  if (!c->deferred) HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
 }
 

@@ -56,6 +56,7 @@ class Tracker:
         over.update(self._over)
         p = capi.default_params(int(_width), int(_height), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), **over)
         self._ctx = capi.Context(p)
+        self._ctx.set_deferred(True)   # one wait per frame, in EstimatePose (pyramids and gradients are enqueued only)
         lv = [self._ctx.level_info(l) for l in range(p.n_levels)]
         self.w_ = [L.w for L in lv]
         self.h_ = [L.h for L in lv]
