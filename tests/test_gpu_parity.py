@@ -115,6 +115,40 @@ def test_batched_pyramids_and_gradients_in_slots(capi, O, synth):
     assert np.array_equal(ctx.get_plane(1, 0, capi.PLANE_DEPTH), depth[3])
 
 
+@pytest.mark.parametrize("shape", [(160, 96, 5), (640, 480, 5), (640, 480, 4), (72, 56, 3), (200, 120, 4), (1280, 960, 5), (192, 128, 7),
+                                   (70, 50, 2), (36, 20, 3)])
+@pytest.mark.parametrize("fused", [True, False])
+def test_one_launch_pyramid_and_gradient_forms(capi, O, synth, monkeypatch, shape, fused):
+    """A frame or a few take their whole pyramid in one launch per plane (k_pyramid_all) and the gradients of every level in
+    one launch (k_scharr3_levels); larger sets take a launch per level (UWT_NO_FUSED_STAGES forces that form).  Same
+    integers either way: tile borders (sizes that are no multiple of 64 / 128), levels whose width is no multiple of 4
+    (scalar gradient tile), 2 to 7 levels, frame ranges and the slot-list form used by the tracker."""
+    w, h, levels = shape
+    if not fused:
+        monkeypatch.setenv("UWT_NO_FUSED_STAGES", "1")
+    f = 525.0 * w / 640.0
+    ctx = capi.Context(capi.default_params(w, h, f, f, w / 2 - 0.5, h / 2 - 0.5, n_levels=levels, first_level=levels - 1,
+                                           last_level=0, max_frames=4, max_pairs=2, has_depth=1))
+    rng = np.random.default_rng(w + levels)
+    frames = np.stack([synth.texture(w, h, seed=300 + s) for s in range(4)])
+    frames[3] = rng.integers(0, 256, (h, w)).astype(np.uint8)       # white noise: every rounding case of the 2x2 mean
+    depth = rng.integers(0, 65536, frames.shape).astype(np.uint16)
+    ctx.upload_frames(0, frames, depth)
+    ctx.build_pyramids(1, 3)          # a range that does not start at slot 0
+    ctx.apply_gradient(1, 3)
+    for s in range(1, 4):
+        im, dp = frames[s], depth[s]
+        for l in range(levels):
+            if l:
+                im, dp = O.halve_u8(im), O.halve_u16(dp)
+            assert np.array_equal(ctx.get_plane(s, l, capi.PLANE_IMAGE), im), (s, l)
+            assert np.array_equal(ctx.get_plane(s, l, capi.PLANE_DEPTH), dp), (s, l)
+            gx, gy = O.scharr3(im)
+            assert np.array_equal(ctx.get_plane(s, l, capi.PLANE_GRADX), gx), (s, l)
+            assert np.array_equal(ctx.get_plane(s, l, capi.PLANE_GRADY), gy), (s, l)
+    ctx.close()
+
+
 def test_level_info_matches_oracle(capi, O):
     ctx = make_ctx(capi, 640, 480, TUM)
     p = O.default_params(640, 480, *TUM)

@@ -172,6 +172,26 @@ int launch_halve(uwt_ctx* c, const T* src, T* dst, int w_out, int h_out, size_t 
   return UWT_OK;
 }
 
+constexpr int kFewFrames = 8;   // up to here a frame set takes the one-launch forms (k_pyramid_all, k_scharr3_levels)
+
+template <typename T>
+void launch_pyramid_all(uwt_ctx* c, T* const* planes_in, T* const* planes, int n, const int* d_slots, int first_slot) {
+  PyramidArgs<T> a;
+  std::memset(&a, 0, sizeof(a));
+  a.src = planes_in[0];
+  for (int l = 0; l < c->p.n_levels; l++) {
+    a.dst[l] = planes[l];
+    a.stride[l] = c->lv[l].n;
+  }
+  a.w = c->lv[0].w;
+  a.h = c->lv[0].h;
+  a.n_levels = c->p.n_levels;
+  a.slots = d_slots;
+  a.first_slot = first_slot;
+  const int tiles = ((a.w + 63) / 64) * ((a.h + 63) / 64);
+  hipLaunchKernelGGL(k_pyramid_all<T>, dim3(tiles, n), dim3(kBlock), 0, c->stream, a);
+}
+
 // src/gx/gy point at slot 0 of the level planes; the frames processed are slots[0..n) if given, else first_slot..+n
 int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int w, int h, size_t fs, int n_frames,
                   const int* d_slots = nullptr, int first_slot = 0, hipStream_t on = nullptr) {
@@ -977,6 +997,17 @@ int uwt_get_plane(uwt_ctx* c, int32_t slot, int32_t lvl, int32_t plane, void* ho
 // restricts the depth pyramids to those slots: only a pair's reference frame is ever read through its depth
 // (src/Tracker.cpp:1266-1272).
 static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n, const int* depth_slots = nullptr, int n_depth = 0) {
+  const bool fused = n <= kFewFrames && c->p.n_levels >= 3 && c->p.n_levels <= kPyrMaxLevels && c->lv[0].w % 4 == 0 &&
+                     c->lv[0].h % 4 == 0 && !std::getenv("UWT_NO_FUSED_STAGES");
+  if (fused) {   // the whole pyramid of each plane in one launch
+    if (n) launch_pyramid_all<uint8_t>(c, c->img, c->img, n, nullptr, first_slot);
+    if (c->p.has_depth) {
+      if (depth_slots) { if (n_depth) launch_pyramid_all<uint16_t>(c, c->depth, c->depth, n_depth, depth_slots, 0); }
+      else if (n) launch_pyramid_all<uint16_t>(c, c->depth, c->depth, n, nullptr, first_slot);
+    }
+    HIPCHK(c, hipGetLastError());
+    return UWT_OK;
+  }
   for (int l = 1; l < c->p.n_levels; l++) {
     const size_t ns = c->lv[l - 1].n, nd = c->lv[l].n;
     int st = launch_halve<uint8_t>(c, c->img[l - 1], c->img[l], c->lv[l].w, c->lv[l].h, ns, nd, n, nullptr, first_slot);
@@ -995,6 +1026,24 @@ static int enqueue_gradient_level(uwt_ctx* c, int l, int first_slot, int n, cons
 }
 
 static int enqueue_gradients(uwt_ctx* c, int first_slot, int n, const int* d_slots = nullptr) {
+  if (n && n <= kFewFrames && c->p.n_levels <= kGradMaxLevels && !std::getenv("UWT_NO_FUSED_STAGES")) {   // every level in one launch
+    GradLevelsArgs a;
+    std::memset(&a, 0, sizeof(a));
+    int tiles = 0;
+    for (int l = 0; l < c->p.n_levels; l++) {
+      a.src[l] = c->img[l]; a.gx[l] = c->gx[l]; a.gy[l] = c->gy[l];
+      a.w[l] = c->lv[l].w; a.h[l] = c->lv[l].h; a.stride[l] = c->lv[l].n;
+      tiles += a.w[l] % 4 == 0 ? ((a.w[l] + kGradVW - 1) / kGradVW) * ((a.h[l] + kGradVRows - 1) / kGradVRows)
+                               : ((a.w[l] + kGradTW - 1) / kGradTW) * ((a.h[l] + kGradTH - 1) / kGradTH);
+      a.tile_end[l] = tiles;
+    }
+    a.n_levels = c->p.n_levels;
+    a.slots = d_slots;
+    a.first_slot = first_slot;
+    hipLaunchKernelGGL(k_scharr3_levels, dim3(tiles, n), dim3(kBlock), 0, c->stream, a);
+    HIPCHK(c, hipGetLastError());
+    return UWT_OK;
+  }
   for (int l = 0; l < c->p.n_levels; l++) {
     int st = enqueue_gradient_level(c, l, first_slot, n, d_slots);
     if (st) return st;

@@ -86,6 +86,76 @@ __global__ __launch_bounds__(kBlock) void k_halve(const T* __restrict__ src, T* 
   }
 }
 
+// The whole pyramid of a frame in one launch (a frame or a few on their own: the live per-frame sequence, where a launch
+// per level and plane is all latency).  The 2x2 mean is tile-local, so a block takes a 64x64 tile of level 0 down every
+// level: a thread reads its 4x4 patch, keeps levels 1 and 2 in registers, levels 3.. go through LDS (16x16 -> 8x8 -> ..).
+// Needs 3 <= n_levels <= 7 and level-0 sizes divisible by 4 (by 2^(n_levels-1) anyway); same integers as k_halve.
+constexpr int kPyrMaxLevels = 7;
+template <typename T>
+struct PyramidArgs {
+  const T* src;                 // level 0, slot 0
+  T* dst[kPyrMaxLevels];        // dst[l]: level l, slot 0 (dst[0] unused)
+  size_t stride[kPyrMaxLevels]; // pixels per frame at level l
+  int w, h;                     // level 0
+  int n_levels;
+  const int* slots;
+  int first_slot;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pyramid_all(const PyramidArgs<T> a) {
+  __shared__ uint32_t lv[2][16][16];
+  const size_t frame = a.slots ? a.slots[blockIdx.y] : a.first_slot + (int)blockIdx.y;
+  const int tiles_x = (a.w + 63) / 64;
+  const int tyb = blockIdx.x / tiles_x, txb = blockIdx.x - tyb * tiles_x;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int x = txb * 64 + 4 * tx, y = tyb * 64 + 4 * ty;   // level-0 corner of this thread's 4x4 patch
+  uint32_t p2 = 0;
+  if (x < a.w && y < a.h) {
+    uint32_t px[4][4];
+    const T* s = a.src + frame * a.stride[0] + (size_t)y * a.w + x;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      T row[4];
+      if constexpr (sizeof(T) == 1) *reinterpret_cast<uint32_t*>(row) = *reinterpret_cast<const uint32_t*>(s + (size_t)r * a.w);
+      else *reinterpret_cast<uint2*>(row) = *reinterpret_cast<const uint2*>(s + (size_t)r * a.w);
+#pragma unroll
+      for (int c = 0; c < 4; c++) px[r][c] = row[c];
+    }
+    uint32_t p1[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+#pragma unroll
+      for (int c = 0; c < 2; c++) p1[r][c] = (px[2 * r][2 * c] + px[2 * r][2 * c + 1] + px[2 * r + 1][2 * c] + px[2 * r + 1][2 * c + 1] + 2u) >> 2;
+    const int w1 = a.w >> 1;
+    T* d1 = a.dst[1] + frame * a.stride[1] + (size_t)(y >> 1) * w1 + (x >> 1);
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      T o[2] = {(T)p1[r][0], (T)p1[r][1]};
+      if constexpr (sizeof(T) == 1) *reinterpret_cast<uint16_t*>(d1 + (size_t)r * w1) = *reinterpret_cast<uint16_t*>(o);
+      else *reinterpret_cast<uint32_t*>(d1 + (size_t)r * w1) = *reinterpret_cast<uint32_t*>(o);
+    }
+    p2 = (p1[0][0] + p1[0][1] + p1[1][0] + p1[1][1] + 2u) >> 2;
+    a.dst[2][frame * a.stride[2] + (size_t)(y >> 2) * (a.w >> 2) + (x >> 2)] = (T)p2;
+  }
+  if (a.n_levels <= 3) return;   // block-uniform
+  lv[0][ty][tx] = p2;
+  // level l (3..): 2^(6-l) x 2^(6-l) elements per tile, element (ex, ey) from the four level l-1 elements in LDS
+#pragma unroll
+  for (int l = 3; l < kPyrMaxLevels; l++) {
+    if (l >= a.n_levels) break;   // block-uniform
+    __syncthreads();
+    const int side = 64 >> l;     // elements per tile side at this level: 8, 4, 2, 1
+    const int b = (l - 3) & 1;
+    if (tx < side && ty < side) {
+      const uint32_t v = (lv[b][2 * ty][2 * tx] + lv[b][2 * ty][2 * tx + 1] + lv[b][2 * ty + 1][2 * tx] + lv[b][2 * ty + 1][2 * tx + 1] + 2u) >> 2;
+      lv[b ^ 1][ty][tx] = v;
+      const int ex = txb * side + tx, ey = tyb * side + ty, wl = a.w >> l, hl = a.h >> l;
+      if (ex < wl && ey < hl) a.dst[l][frame * a.stride[l] + (size_t)ey * wl + ex] = (T)v;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // gradients: 3 x Scharr, reflect-101 border, exact in int (src/Tracker.cpp:1133-1134).
 // A 64x16 output tile per block; the (64+2)x(16+2) u8 source patch is staged in LDS once, every output then
@@ -100,13 +170,15 @@ __device__ inline int reflect101(int i, int n) {
   return i;
 }
 
-__global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
-                                                    int16_t* __restrict__ gy, int w, int h, size_t frame_stride) {
-  __shared__ uint8_t tile[kGradTH + 2][kGradTW + 4];
+// one 64x16 output tile (`tile_id` of frame `frame`); lds: (kGradTH + 2) x (kGradTW + 4) bytes
+__device__ __forceinline__ void scharr_tile_scalar(unsigned char* __restrict__ lds, const uint8_t* __restrict__ src,
+                                                   int16_t* __restrict__ gx, int16_t* __restrict__ gy, int w, int h,
+                                                   size_t frame_stride, size_t frame, int tile_id) {
+  uint8_t(*tile)[kGradTW + 4] = reinterpret_cast<uint8_t(*)[kGradTW + 4]>(lds);
   const int tiles_x = (w + kGradTW - 1) / kGradTW;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
   const int x0 = tx * kGradTW, y0 = ty * kGradTH;
-  const uint8_t* img = src + (size_t)blockIdx.y * frame_stride;
+  const uint8_t* img = src + frame * frame_stride;
   for (int i = threadIdx.x; i < (kGradTH + 2) * (kGradTW + 2); i += kBlock) {
     const int ly = i / (kGradTW + 2), lx = i - ly * (kGradTW + 2);
     const int sy = reflect101(min(y0 + ly - 1, h), h), sx = reflect101(min(x0 + lx - 1, w), w);
@@ -124,11 +196,17 @@ __global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ 
       const int g = tile[ly + 2][lx], hh = tile[ly + 2][lx + 1], k = tile[ly + 2][lx + 2];
       const int sx = 3 * (3 * (c - a) + 10 * (f - d) + 3 * (k - g));
       const int sy = 3 * (3 * (g - a) + 10 * (hh - b) + 3 * (k - c));
-      const size_t o = (size_t)blockIdx.y * frame_stride + (size_t)y * w + x;
+      const size_t o = frame * frame_stride + (size_t)y * w + x;
       gx[o] = (int16_t)sx;  // |s| <= 48*255*... = 12240 < 32767: never saturates
       gy[o] = (int16_t)sy;
     }
   }
+}
+
+__global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
+                                                    int16_t* __restrict__ gy, int w, int h, size_t frame_stride) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(kGradTH + 2) * (kGradTW + 4)];
+  scharr_tile_scalar(lds, src, gx, gy, w, h, frame_stride, blockIdx.y, (int)blockIdx.x);
 }
 
 // Vector variant for level widths that are multiples of 4: a 128 x (8·RPT) output tile per block, the source patch (tile
@@ -138,15 +216,15 @@ __global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ 
 // `slots` (optional) lists the frame slots to process.
 constexpr int kGradVW = 128, kGradVRows = 8;  // columns per tile; thread rows per tile (x RPT output rows each)
 
+// one 128 x (8·RPT) output tile; lds: (8·RPT + 2) x (kGradVW / 4 + 2) words
 template <int RPT>
-__global__ __launch_bounds__(kBlock) void k_scharr3_v4(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
-                                                       int16_t* __restrict__ gy, int w, int h, size_t frame_stride,
-                                                       const int* __restrict__ slots, int first_slot) {
+__device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, const uint8_t* __restrict__ src,
+                                               int16_t* __restrict__ gx, int16_t* __restrict__ gy, int w, int h,
+                                               size_t frame_stride, int slot, int tile_id) {
   constexpr int TH = kGradVRows * RPT;
-  __shared__ uint32_t tile[TH + 2][kGradVW / 4 + 2];  // word 0: left halo in its top byte; word 33: right halo in its low byte
-  const int slot = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;
+  uint32_t(*tile)[kGradVW / 4 + 2] = reinterpret_cast<uint32_t(*)[kGradVW / 4 + 2]>(lds);  // word 0: left halo in its top byte; word 33: right halo in its low byte
   const int tiles_x = (w + kGradVW - 1) / kGradVW;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
   const int x0 = tx * kGradVW, y0 = ty * TH;
   const uint8_t* img = src + (size_t)slot * frame_stride;
   const int tw = min(kGradVW, w - x0);  // valid width of this tile (multiple of 4)
@@ -201,6 +279,49 @@ __global__ __launch_bounds__(kBlock) void k_scharr3_v4(const uint8_t* __restrict
       for (int j = 0; j < 6; j++) { p[0][j] = p[1][j]; p[1][j] = p[2][j]; }
     }
   }
+}
+
+template <int RPT>
+__global__ __launch_bounds__(kBlock) void k_scharr3_v4(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
+                                                       int16_t* __restrict__ gy, int w, int h, size_t frame_stride,
+                                                       const int* __restrict__ slots, int first_slot) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[(kGradVRows * RPT + 2) * (kGradVW / 4 + 2) * 4];
+  const int slot = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;
+  scharr_tile_v4<RPT>(lds, src, gx, gy, w, h, frame_stride, slot, (int)blockIdx.x);
+}
+
+// The gradients of every level of a frame (or a few) in one launch: block -> (level, tile) through the levels' tile
+// counts; the 128x8 vector tile where the level's width is a multiple of 4, the scalar 64x16 tile elsewhere.
+constexpr int kGradMaxLevels = 8;
+struct GradLevelsArgs {
+  const uint8_t* src[kGradMaxLevels];
+  int16_t* gx[kGradMaxLevels];
+  int16_t* gy[kGradMaxLevels];
+  int w[kGradMaxLevels], h[kGradMaxLevels];
+  size_t stride[kGradMaxLevels];
+  int tile_end[kGradMaxLevels];   // running sum of the levels' tile counts
+  int n_levels;
+  const int* slots;
+  int first_slot;
+};
+
+__global__ __launch_bounds__(kBlock) void k_scharr3_levels(const GradLevelsArgs a) {
+  constexpr int kV4Bytes = (kGradVRows + 2) * (kGradVW / 4 + 2) * 4, kScBytes = (kGradTH + 2) * (kGradTW + 4);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kV4Bytes > kScBytes ? kV4Bytes : kScBytes];
+  const int slot = a.slots ? a.slots[blockIdx.y] : a.first_slot + (int)blockIdx.y;
+  const int b = (int)blockIdx.x;
+  // the level's parameters by selects over the (by-value) table: an indexed read would go through scratch memory
+  const uint8_t* src = a.src[0];
+  int16_t *gx = a.gx[0], *gy = a.gy[0];
+  int w = a.w[0], h = a.h[0], tile0 = 0;
+  size_t stride = a.stride[0];
+#pragma unroll
+  for (int l = 1; l < kGradMaxLevels; l++)
+    if (l < a.n_levels && b >= a.tile_end[l - 1]) {
+      src = a.src[l]; gx = a.gx[l]; gy = a.gy[l]; w = a.w[l]; h = a.h[l]; stride = a.stride[l]; tile0 = a.tile_end[l - 1];
+    }
+  if (w % 4 == 0) scharr_tile_v4<1>(lds, src, gx, gy, w, h, stride, slot, b - tile0);
+  else scharr_tile_scalar(lds, src, gx, gy, w, h, stride, (size_t)slot, b - tile0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
