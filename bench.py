@@ -420,8 +420,13 @@ def main(args):
             t_mt = time.perf_counter() - t0
             out["cpu_baseline_all_cores"] = {"value": round(n_mt / t_mt, 4), "unit": "alignments/s", "cores": cores,
                                              "kind": "port", "sample": "%d alignments, thread pool, %.1f s" % (n_mt, t_mt)}
+            # every resident pair repeats one of the U distinct inputs: all P poses are covered by comparing each with its original
+            tiled_same = int(sum(np.array_equal(gpu_poses[i].view(np.uint32), gpu_poses[i % U].view(np.uint32)) for i in range(P)))
             out["parity"] = {"pairs": len(cpu_poses), "max_rot_rad": float(np.max(dr)), "max_trans_m": float(np.max(dtr)),
-                             "bit_identical_poses": bit, "tolerance": "1e-4 rad / 1e-4 m"}
+                             "bit_identical_poses": bit, "tolerance": "1e-4 rad / 1e-4 m",
+                             "resident_pairs_equal_to_their_distinct_original": tiled_same, "resident_pairs": P}
+            assert tiled_same == P, "tiled copies of a pair differ within the batch"
+
         print(json.dumps(out), flush=True)
     ctx.close()
     if use_dist:

@@ -237,6 +237,36 @@ def test_deferred_stage_calls_wait_once_per_frame(capi, O, synth):
     ctx.close()
 
 
+@pytest.mark.parametrize("mode", ["identity", "huber"])
+def test_split_batch_on_two_streams_gives_the_same_poses(capi, O, synth, monkeypatch, mode):
+    """Fixed-schedule batches of 16 pairs or more run as two parts on two streams (UWT_SPLIT=1: one stream).  21 pairs (an
+    odd count: parts of 10 and 11), pyramids and gradients through uwt_track_batch_async: same poses bit for bit either way,
+    and the oracle's on the pairs checked."""
+    w, h, n, distinct = 320, 240, 21, 5
+    intr = (262.5, 262.5, 159.5, 119.5)
+    over = dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0, has_depth=1)
+    if mode == "huber":
+        over["weights"] = 2
+    pairs = [synth.render_pair(w, h, *intr, seed=6100 + s, max_t=0.012, max_deg=0.6, with_depth=True)[:3] for s in range(distinct)]
+    results = []
+    for split in ("2", "1"):
+        monkeypatch.setenv("UWT_SPLIT", split)
+        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
+        for i in range(n):
+            ref, tgt, dep = pairs[i % distinct]
+            ctx.upload_frames(2 * i, np.stack([ref, tgt]), np.stack([dep, dep]))
+        ref_s = np.arange(n, dtype=np.int32) * 2
+        poses, stats = _track_batch(ctx, 2 * n, ref_s, ref_s + 1)
+        assert all(s["status"] == 0 and s["iterations"] == 24 for s in stats)
+        results.append(poses.copy())
+        ctx.close()
+    assert np.array_equal(results[0].view(np.uint32), results[1].view(np.uint32))
+    po = O.default_params(w, h, *intr, **over)
+    for i in (0, 9, 10, 11, 20):       # both parts and their seam
+        st, pose_cpu, _ = O.align_pair(po, *pairs[i % distinct])
+        assert st == 0 and np.array_equal(results[0][i].view(np.uint32), pose_cpu.view(np.uint32)), i
+
+
 # ------------------------------------------------------------------ launch paths of bench.py
 
 def _run(cmd, extra_env=None, timeout=540):

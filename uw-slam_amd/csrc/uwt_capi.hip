@@ -30,6 +30,11 @@ struct uwt_ctx {
   // Side stream of uwt_track_batch_async: the gradients of the finer levels (HBM-bound) run beside the first, coarse
   // iterations of the alignment (VALU-bound), which only read the coarsest iterated level.  UWT_OVERLAP_GRAD=0: off.
   hipStream_t side = nullptr;
+  static constexpr int kMaxParts = 4;
+  hipStream_t part_stream[kMaxParts] = {};   // compute streams of parts 1.. of a split batch (part 0: `stream`)
+  hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {};
+  int split = 2;                        // parts a fixed-schedule batch is cut into (UWT_SPLIT; 1 = one stream)
+  int split_min = 8;                    // pairs per part at least (UWT_SPLIT_MIN)
   hipEvent_t ev_pyramids = nullptr, ev_side_done = nullptr, ev_level[UWT_MAX_LEVELS] = {};
   bool overlap_gradients = true;
   uint8_t* img[UWT_MAX_LEVELS] = {};
@@ -550,27 +555,42 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   const uwt_params& p = c->p;
   if (takes_chained_flow(c, n_pairs)) return enqueue_estimate_chained(c, n_pairs, d_poses, d_stats, level_ready);
   const int tb = 128;
-  hipLaunchKernelGGL(k_init_state, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs,
-                     p.initial_error);
-  HIPCHK(c, hipGetLastError());
   const bool general = p.sampler != 0 || p.weights != 0;
-  {
+  // Slicing follows the batch: the create-time slicing (kGroupsPerThread) gives a single pair enough blocks to spread
+  // over the chip; a batch that fills it alone runs fewer, longer blocks (less reduction overhead per pixel, fewer
+  // records to fold), still at least target_blocks per launch.
+  auto slicing = [&](int lvl, int& groups_per_block, int& slices) {
+    const int n_groups = c->lv[lvl].n / c->vec;
+    int want = (c->target_blocks + n_pairs - 1) / n_pairs;
+    want = std::max(1, std::min(want, c->slices[lvl]));
+    const int gpt = (n_groups + want * kBlock - 1) / (want * kBlock);
+    groups_per_block = gpt * kBlock;
+    slices = (n_groups + groups_per_block - 1) / groups_per_block;
+  };
+  int smax = 1;
+  for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
+    int gpb, sl;
+    slicing(lvl, gpb, sl);
+    smax = std::max(smax, sl);
+  }
+  // the schedule for pairs [base, base + cnt) of a batch of n_pairs, on c->stream
+  auto run = [&](int base, int cnt) -> int {
+    hipLaunchKernelGGL(k_init_state, dim3((cnt + tb - 1) / tb), dim3(tb), 0, c->stream, c->state + base, cnt, p.initial_error);
+    HIPCHK(c, hipGetLastError());
     for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
       if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(c->stream, level_ready[lvl], 0));  // its gradients
       ResidualArgs ra = residual_args(c, lvl);
       UpdateArgs ua = update_args(c, lvl);
-      // Slicing follows the batch: the create-time slicing (kGroupsPerThread) gives a single pair enough blocks to spread
-      // over the chip; a batch that fills it alone runs fewer, longer blocks (less reduction overhead per pixel, fewer
-      // records to fold), still at least target_blocks per launch.
-      {
-        const int n_groups = c->lv[lvl].n / c->vec;
-        int want = (c->target_blocks + n_pairs - 1) / n_pairs;
-        want = std::max(1, std::min(want, c->slices[lvl]));
-        const int gpt = (n_groups + want * kBlock - 1) / (want * kBlock);
-        ra.groups_per_block = gpt * kBlock;
-        ra.slices = (n_groups + ra.groups_per_block - 1) / ra.groups_per_block;
-        ua.slices = ra.slices;
-      }
+      ra.pair_base = base;
+      ua.pair_base = base;
+      slicing(lvl, ra.groups_per_block, ra.slices);
+      ua.slices = ra.slices;
+      // A pair's records sit at (pair * slices + slice): the place depends on the level's slice count, and the parts of a
+      // split batch are at different levels at times.  Part `base` is shifted so that its records start at base * smax
+      // whatever the level — behind everything the parts before it can touch, inside the buffer (slices <= smax).
+      const size_t shift = (size_t)base * (size_t)(smax - ra.slices) * kRecWords;
+      ra.partials = c->partials + shift;
+      ua.partials = c->partials + shift;
       // Early exit: the host reads back how many pairs are still iterating after the update of evaluation first_poll - 1,
       // then after twice as many, ...  With the reference's constants a level ends at its third evaluation as a rule
       // (error rises or stalls, src/Tracker.cpp:508), so the first look comes after three (UWT_FIRST_POLL).
@@ -582,22 +602,22 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
           if (st) return st;
           ra.probe = 1;
           c->prof_slices = ra.slices;
-          c->prof_pairs = n_pairs;
+          c->prof_pairs = cnt;
           c->prof_records = c->partials;
         }
-        int st = general ? launch_general(c, ra, n_pairs) : launch_residual(c, ra, n_pairs, false);
+        int st = general ? launch_general(c, ra, cnt) : launch_residual(c, ra, cnt, false);
         if (st) return st;
         if (c->profiling) {
           HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
           c->prof_launches += 1;
-          c->prof_pixels += (long long)n_pairs * c->lv[lvl].n;
+          c->prof_pixels += (long long)cnt * c->lv[lvl].n;
         }
         if (general) ua.general = 1;
         ua.k = k;
         const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
         ua.active = poll ? c->d_active : nullptr;
         if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_gn_update, dim3(n_pairs), dim3(kUpdateBlock), 0, c->stream, ua);
+        hipLaunchKernelGGL(k_gn_update, dim3(cnt), dim3(kUpdateBlock), 0, c->stream, ua);
         HIPCHK(c, hipGetLastError());
         if (poll) {  // reference-mode early exit: stop launching once every pair has left this level
           HIPCHK(c, hipMemcpyAsync(c->h_active, c->d_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -606,15 +626,40 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
           next_poll *= 2;
         }
       }
-      hipLaunchKernelGGL(k_level_end, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs, lvl,
+      hipLaunchKernelGGL(k_level_end, dim3((cnt + tb - 1) / tb), dim3(tb), 0, c->stream, c->state + base, cnt, lvl,
                          p.handoff_scale_t, p.initial_error);
       HIPCHK(c, hipGetLastError());
     }
+    hipLaunchKernelGGL(k_write_out, dim3((cnt + tb - 1) / tb), dim3(tb), 0, c->stream, c->state + base, cnt, d_poses + 7 * (size_t)base,
+                       d_stats ? d_stats + base : nullptr);
+    HIPCHK(c, hipGetLastError());
+    return UWT_OK;
+  };
+  // A batch is cut into two parts that run the same schedule on streams of their own (fixed schedules, 16 pairs or more):
+  // the launches of one part run in the gaps of the other's — the tail of a residual launch, the update launch, the kernel
+  // boundaries: +1..3 % at 256..1024 pairs, +7..9 % at 32..64; three parts gain nothing more, four lose (measured).
+  // Results do not depend on it (a pair's blocks, records and state are its own; the slicing is the whole batch's).
+  int parts = std::min(c->split, n_pairs / std::max(1, c->split_min));
+  if (p.early_exit || c->profiling || parts < 2) return run(0, n_pairs);
+  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  hipStream_t main_stream = c->stream;
+  int st = UWT_OK;
+  for (int i = 0; i < parts && st == UWT_OK; i++) {
+    const int base = (int)((long long)n_pairs * i / parts), end = (int)((long long)n_pairs * (i + 1) / parts);
+    if (i) {
+      HIPCHK(c, hipStreamWaitEvent(c->part_stream[i], c->ev_fork, 0));
+      c->stream = c->part_stream[i];      // every launch helper enqueues on c->stream
+    }
+    st = run(base, end - base);
+    if (i) {
+      c->stream = main_stream;
+      if (st == UWT_OK) {
+        HIPCHK(c, hipEventRecord(c->ev_join[i], c->part_stream[i]));
+        HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join[i], 0));
+      }
+    }
   }
-  hipLaunchKernelGGL(k_write_out, dim3((n_pairs + tb - 1) / tb), dim3(tb), 0, c->stream, c->state, n_pairs, d_poses,
-                     d_stats);
-  HIPCHK(c, hipGetLastError());
-  return UWT_OK;
+  return st;
 }
 
 // ---- slot-range dependencies between the context stream and the copy stream --------------------------------------
@@ -784,6 +829,13 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipSetDevice(p->device));
   CREATE_CHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   CREATE_CHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  for (int i = 1; i < uwt_ctx::kMaxParts; i++) {
+    CREATE_CHK(hipStreamCreateWithFlags(&c->part_stream[i], hipStreamNonBlocking));
+    CREATE_CHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
+  }
+  CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+  if (const char* e = std::getenv("UWT_SPLIT")) c->split = std::max(1, std::min(uwt_ctx::kMaxParts, std::atoi(e)));
+  if (const char* e = std::getenv("UWT_SPLIT_MIN")) c->split_min = std::max(1, std::atoi(e));
   CREATE_CHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
   for (int i = 0; i < uwt_ctx::kDeps; i++) {
     CREATE_CHK(hipEventCreateWithFlags(&c->busy[i].ev, hipEventDisableTiming));
@@ -857,6 +909,11 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->scratch) (void)hipFree(c->scratch);
   for (hipEvent_t e : c->ev_pool) (void)hipEventDestroy(e);
   if (c->side) (void)hipStreamDestroy(c->side);
+  for (int i = 1; i < uwt_ctx::kMaxParts; i++) {
+    if (c->part_stream[i]) (void)hipStreamDestroy(c->part_stream[i]);
+    if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+  }
+  if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
   if (c->copy) (void)hipStreamDestroy(c->copy);
   for (int i = 0; i < uwt_ctx::kDeps; i++) {
     if (c->busy[i].ev) (void)hipEventDestroy(c->busy[i].ev);
