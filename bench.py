@@ -203,6 +203,10 @@ def main(args):
     if args.reference_schedule:
         over.update(n_levels=5, first_level=4, last_level=1, max_iters=50, early_exit=1)
     params = capi.default_params(w, h, *intr, max_frames=2 * P, max_pairs=P, device=local_rank, **over)
+    if _under_profiler():
+        # per-kernel statistics are to describe whole-batch launches, one at a time: the two-halves-on-two-streams form of a
+        # batch overlaps launches of half the size, whose durations a trace cannot tell apart from waiting
+        os.environ.setdefault("UWT_SPLIT", "1")
     ctx = capi.Context(params)
 
     U = min(args.unique, P)
@@ -362,6 +366,8 @@ def main(args):
                 "traffic_source": facts.get("hbm_bytes_source") if traffic_px else None,
                 "launches": int(res_launches), "avg_launch_ms": round(res_ms / res_launches, 5),
                 "algorithmic_bytes_per_launch_avg": int(alg_bytes / res_launches),
+                "launch_form": "whole-batch launches, one at a time (the profiled step after the timed region; the timed steps "
+                               "run the batch as two halves on two streams, whose overlapping launches have no duration of their own)",
                 "whole_job_effective_GBs": round(value / world * (ALG_BYTES_PER_PIXEL_ITER * px_per_align * args.iters
                                                                   + 5 * px_per_align + 2.5 * px_per_align) / 1e9, 1),
             }

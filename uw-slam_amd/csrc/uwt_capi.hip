@@ -72,7 +72,8 @@ struct uwt_ctx {
   unsigned int* hist = nullptr;         // general path: [pair][2][kHistBins]
   PairScale* scale = nullptr;           // general path: [pair]
   int* d_active = nullptr;              // early-exit polling counters
-  int target_blocks = 4096;             // blocks per residual launch the batch-dependent slicing aims at (UWT_TARGET_BLOCKS)
+  int target_blocks = 0;                // blocks per residual launch the batch-dependent slicing aims at (UWT_TARGET_BLOCKS);
+                                        // 0: 1024 for a batch that runs as two halves (one block per slot of the chip), else 4096
   int* h_active = nullptr;              // pinned
   void* scratch = nullptr;              // per-stage entry points
   size_t scratch_bytes = 0;
@@ -476,7 +477,7 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
     ra.state = nullptr;
     {  // slicing follows the batch, as in enqueue_estimate
       const int n_groups = c->lv[lvl].n / c->vec;
-      int want = (c->target_blocks + n_pairs - 1) / n_pairs;
+      int want = ((c->target_blocks ? c->target_blocks : 4096) + n_pairs - 1) / n_pairs;
       want = std::max(1, std::min(want, c->slices[lvl]));
       const int gpt = (n_groups + want * kBlock - 1) / (want * kBlock);
       ra.groups_per_block = gpt * kBlock;
@@ -559,9 +560,11 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   // Slicing follows the batch: the create-time slicing (kGroupsPerThread) gives a single pair enough blocks to spread
   // over the chip; a batch that fills it alone runs fewer, longer blocks (less reduction overhead per pixel, fewer
   // records to fold), still at least target_blocks per launch.
+  const int parts = (p.early_exit || c->profiling) ? 1 : std::min(c->split, n_pairs / std::max(1, c->split_min));
+  const int target_blocks = c->target_blocks ? c->target_blocks : (parts >= 2 ? 1024 : 4096);
   auto slicing = [&](int lvl, int& groups_per_block, int& slices) {
     const int n_groups = c->lv[lvl].n / c->vec;
-    int want = (c->target_blocks + n_pairs - 1) / n_pairs;
+    int want = (target_blocks + n_pairs - 1) / n_pairs;
     want = std::max(1, std::min(want, c->slices[lvl]));
     const int gpt = (n_groups + want * kBlock - 1) / (want * kBlock);
     groups_per_block = gpt * kBlock;
@@ -639,8 +642,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   // the launches of one part run in the gaps of the other's — the tail of a residual launch, the update launch, the kernel
   // boundaries: +1..3 % at 256..1024 pairs, +7..9 % at 32..64; three parts gain nothing more, four lose (measured).
   // Results do not depend on it (a pair's blocks, records and state are its own; the slicing is the whole batch's).
-  int parts = std::min(c->split, n_pairs / std::max(1, c->split_min));
-  if (p.early_exit || c->profiling || parts < 2) return run(0, n_pairs);
+  if (parts < 2) return run(0, n_pairs);
   HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
   hipStream_t main_stream = c->stream;
   int st = UWT_OK;
