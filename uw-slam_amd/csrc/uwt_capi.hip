@@ -90,7 +90,7 @@ struct uwt_ctx {
   bool deferred = false;                // uwt_set_deferred: stage calls return once enqueued
   int pair_slots[4] = {0, 0, 0, 0};
   int first_poll = 3;                   // evaluations of a level before the first early-exit read-back
-  int chained = -1;                     // -1: chained flow for n_pairs <= 2; UWT_CHAINED=1 / 0: always / never (A/B runs)
+  int chained = -1;                     // -1: chained flow for a few pairs (takes_chained_flow); UWT_CHAINED=1 / 0: always / never (A/B runs)
   const uint32_t* prof_records = nullptr;
   bool compute_only = false;            // uwt_profile_enable(ctx, 2): residual launches run their no-memory diagnostic twin
   std::vector<hipEvent_t> ev_pool;      // start/stop pairs
@@ -546,10 +546,12 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
 
 // Tracker::EstimatePose for a batch, enqueued on the context's stream (src/Tracker.cpp:362-597)
 // The chained flow pays where an alignment is bound by kernel boundaries and dependent round trips, not by arithmetic: a
-// pair or two on their own (the drop-in call).  In a batch every block would repeat its pair's update (UWT_CHAINED=1 / 0
-// force it on / off for A/B runs).
+// few pairs on their own (the drop-in call).  In a batch every block would repeat its pair's update.  Measured at 640x480
+// (tools/exp/latency_small_batches.py): ahead up to 6 pairs in fixed schedules, up to 16 in early-exit schedules (half
+// the launches between two read-backs), level from there on (UWT_CHAINED=1 / 0 force it on / off for A/B runs).
 static bool takes_chained_flow(const uwt_ctx* c, int n_pairs) {
-  return c->vec == 4 && c->p.sampler == 0 && c->p.weights == 0 && (c->chained > 0 || (c->chained < 0 && n_pairs <= 2));
+  const int few = c->p.early_exit ? 16 : 6;
+  return c->vec == 4 && c->p.sampler == 0 && c->p.weights == 0 && (c->chained > 0 || (c->chained < 0 && n_pairs <= few));
 }
 
 int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats, const hipEvent_t* level_ready = nullptr) {
