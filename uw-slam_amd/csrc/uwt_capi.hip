@@ -426,8 +426,11 @@ template <bool DEPTH, bool UNIT>
 void launch_iterate_t(hipStream_t s, const ResidualArgs& a, const IterArgs& ia, int n_pairs, bool acc64, bool compute_only) {
   const dim3 grid(a.slices, n_pairs), blk(kBlock);
   const bool square = a.L.fx == a.L.fy;
+  const bool wide = n_pairs > 3;   // four blocks per CU (two-pass reduction) instead of blocks alone on their CUs
   if (acc64 && square && UNIT && compute_only) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, true, true>), grid, blk, 0, s, a, ia);
+  else if (acc64 && square && UNIT && wide) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, true, false, 14>), grid, blk, 0, s, a, ia);
   else if (acc64 && square && UNIT) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, true>), grid, blk, 0, s, a, ia);
+  else if (acc64 && wide) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, false, false, 14>), grid, blk, 0, s, a, ia);
   else if (acc64) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, false>), grid, blk, 0, s, a, ia);
   else hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, float, false>), grid, blk, 0, s, a, ia);
 }

@@ -596,7 +596,7 @@ __device__ uint32_t g_exp_stamps[16];
 // CU to itself and the reduction's latency is on the critical path (k_iterate).
 constexpr int reduce_lds_bytes(int pass) { return pass * kBlock * 8 + 2 * kBlock * 8 + (kAccFloats + 3) * 8 * 8; }
 constexpr int kReduceLdsBytes = reduce_lds_bytes(14);   // 34688
-constexpr int kIteratePass = kAccFloats;                // k_iterate: one pass, 61312 B
+constexpr int kIteratePass = kAccFloats;                // k_iterate, up to 3 pairs (blocks alone on their CUs): one pass, 61312 B
 
 template <typename AccT, bool HAS_EXTRA = false, int PASS = 14>
 __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict__ lds, const AccT acc[kAccFloats],
@@ -825,7 +825,7 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
 // by register arithmetic — results are meaningless, its duration is the kernel's own instruction-issue floor.
 // residual_core evaluates one slice of one pair at `pose`; `lds` (optional) is the caller's buffer for the block reduction.
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, bool EXT_LDS = false>
+          bool COMPUTE_ONLY = false, int EXT_LDS = 0>   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first = nullptr, int ref_slot = -1,
                                               int tgt_slot = -1);
@@ -857,7 +857,7 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
 }
 
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
-          bool EXT_LDS>
+          int EXT_LDS>
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot) {
   WarpK K;
@@ -1018,7 +1018,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 #ifdef UWT_EXP_STAMPS
   if (threadIdx.x == 0) out_rec[62] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
-  if constexpr (EXT_LDS) block_reduce_store_at<AccT, GENERAL, kIteratePass>(lds, acc, sum_r2, n_valid, out_rec, err);   // the caller's bytes: k_iterate
+  if constexpr (EXT_LDS != 0) block_reduce_store_at<AccT, GENERAL, EXT_LDS>(lds, acc, sum_r2, n_valid, out_rec, err);   // the caller's bytes: k_iterate
   else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err);
   if (a.probe && threadIdx.x == 0) {
     uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
@@ -1557,11 +1557,14 @@ __device__ __forceinline__ PairState iterate_state(const IterArgs& ia, int pair,
   return st;
 }
 
-constexpr int kIterateLdsBytes = kUpdateLdsBytes > reduce_lds_bytes(kIteratePass) ? kUpdateLdsBytes : reduce_lds_bytes(kIteratePass);
+constexpr int iterate_lds_bytes(int pass) { return kUpdateLdsBytes > reduce_lds_bytes(pass) ? kUpdateLdsBytes : reduce_lds_bytes(pass); }
 
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, bool COMPUTE_ONLY = false>
+// PASS: rows per LDS pass of the block reduction — kIteratePass (one pass, 60 KB) while the blocks have their CUs to
+// themselves (up to 3 pairs: 0.40 against 0.42 ms for one), 14 (two passes, 34 KB, four blocks per CU) from 4 pairs on
+// (6 pairs: 0.49 against 0.52 ms).
+template <int VEC, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, bool COMPUTE_ONLY = false, int PASS = kIteratePass>
 __global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterArgs ia) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kIterateLdsBytes];   // the update's staging, then the reduction's image
+  __shared__ __attribute__((aligned(16))) unsigned char lds[iterate_lds_bytes(PASS)];   // the update's staging, then the reduction's image
   const int pair = (int)blockIdx.y + a.pair_base, slice = (int)blockIdx.x;
   // the first group's reference planes do not depend on the pose: their (cold) loads travel while the update runs
   RefGroup<VEC> first;
@@ -1585,7 +1588,7 @@ __global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterAr
   }
   if (st.level_done || st.status) return;
   __syncthreads();   // the staging bytes become the reduction's
-  residual_core<VEC, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, COMPUTE_ONLY, true>(a, pair, slice, st.pose, lds, &first, ref_slot, tgt_slot);
+  residual_core<VEC, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, COMPUTE_ONLY, PASS>(a, pair, slice, st.pose, lds, &first, ref_slot, tgt_slot);
 #ifdef UWT_EXP_STAMPS
   if (threadIdx.x == 0) {   // experiment: 100 MHz wall stamps of this block's phases in the record's spare words
     uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
