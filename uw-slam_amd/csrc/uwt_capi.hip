@@ -1211,6 +1211,8 @@ static int track_batch_enqueue(uwt_ctx* c, int32_t first_slot, int32_t n_frames,
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !d_poses_out || !slot_range_ok(c, first_slot, n_frames))
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_track_batch_async: bad argument");
+  c->inline_pairs = false;   // (only the synchronous small call hands slots over in kernel arguments or speculates)
+  c->speculate = false;
   int st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
   if (st) return st;
   st = compute_begin(c, first_slot, n_frames);   // behind the asynchronous uploads into these slots
