@@ -249,6 +249,7 @@ def test_split_batch_on_two_streams_gives_the_same_poses(capi, O, synth, monkeyp
         over["weights"] = 2
     pairs = [synth.render_pair(w, h, *intr, seed=6100 + s, max_t=0.012, max_deg=0.6, with_depth=True)[:3] for s in range(distinct)]
     results = []
+    monkeypatch.setenv("UWT_SPLIT_MIN_PX", "1")     # the test's batch is smaller than the size from which the split pays
     for split in ("2", "1"):
         monkeypatch.setenv("UWT_SPLIT", split)
         ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
@@ -265,6 +266,38 @@ def test_split_batch_on_two_streams_gives_the_same_poses(capi, O, synth, monkeyp
     for i in (0, 9, 10, 11, 20):       # both parts and their seam
         st, pose_cpu, _ = O.align_pair(po, *pairs[i % distinct])
         assert st == 0 and np.array_equal(results[0][i].view(np.uint32), pose_cpu.view(np.uint32)), i
+
+
+def test_split_batch_small_images_parts_at_different_levels(capi, synth, monkeypatch):
+    """Small images make the two parts of a split batch drift apart by whole levels (launches of a few microseconds): the
+    second part's records must not land where the first part's live (they are placed independently of the level).  160x96,
+    80 pairs, split forced: poses bit-identical to the one-stream run, statuses clean — repeated, as the drift varies."""
+    import torch
+    w, h, n = 160, 96, 80
+    f = 525.0 * w / 640.0
+    intr = (f, f, w / 2 - 0.5, h / 2 - 0.5)
+    over = dict(n_levels=4, first_level=3, last_level=0, max_iters=5, early_exit=0)
+    frames = []
+    for s in range(n):
+        ref, tgt, _, _, _ = synth.render_pair(w, h, *intr, seed=3000 + s)
+        frames += [ref, tgt]
+    frames = np.stack(frames)
+    ref_s = np.arange(n, dtype=np.int32) * 2
+    monkeypatch.setenv("UWT_SPLIT_MIN_PX", "1")
+    out = {}
+    for split in ("1", "2"):
+        monkeypatch.setenv("UWT_SPLIT", split)
+        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
+        ctx.upload_frames(0, frames)
+        runs = []
+        for rep in range(1 if split == "1" else 6):
+            poses, stats = _track_batch(ctx, 2 * n, ref_s, ref_s + 1)
+            assert all(s["status"] == 0 and s["iterations"] == 20 for s in stats), (split, rep)
+            runs.append(poses.copy())
+        out[split] = runs
+        ctx.close()
+    for rep, poses in enumerate(out["2"]):
+        assert np.array_equal(poses.view(np.uint32), out["1"][0].view(np.uint32)), rep
 
 
 # ------------------------------------------------------------------ launch paths of bench.py

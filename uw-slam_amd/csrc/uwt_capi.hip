@@ -35,6 +35,8 @@ struct uwt_ctx {
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {};
   int split = 2;                        // parts a fixed-schedule batch is cut into (UWT_SPLIT; 1 = one stream)
   int split_min = 8;                    // pairs per part at least (UWT_SPLIT_MIN)
+  long long split_min_px = 32LL * 640 * 480;   // level-0 pixels of the batch at least: below, a launch is too short for a
+                                        // second stream to pay (the host enqueues twice as many) (UWT_SPLIT_MIN_PX)
   hipEvent_t ev_pyramids = nullptr, ev_side_done = nullptr, ev_level[UWT_MAX_LEVELS] = {};
   bool overlap_gradients = true;
   uint8_t* img[UWT_MAX_LEVELS] = {};
@@ -566,7 +568,8 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   // over the chip; a batch that fills it alone runs fewer, longer blocks (less reduction overhead per pixel, fewer
   // records to fold), still at least target_blocks per launch.
   // (early-exit schedules stay on one stream: interleaving the two halves' read-backs was built and gave +1.7 %)
-  const int parts = (p.early_exit || c->profiling) ? 1 : std::min(c->split, n_pairs / std::max(1, c->split_min));
+  const int parts = (p.early_exit || c->profiling || (long long)n_pairs * c->lv[0].n < c->split_min_px)
+                        ? 1 : std::min(c->split, n_pairs / std::max(1, c->split_min));
   const int target_blocks = c->target_blocks ? c->target_blocks : (parts >= 2 ? 1024 : 4096);
   auto slicing = [&](int lvl, int& groups_per_block, int& slices) {
     const int n_groups = c->lv[lvl].n / c->vec;
@@ -644,30 +647,72 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
     HIPCHK(c, hipGetLastError());
     return UWT_OK;
   };
-  // A batch is cut into two parts that run the same schedule on streams of their own (fixed schedules, 16 pairs or more):
-  // the launches of one part run in the gaps of the other's — the tail of a residual launch, the update launch, the kernel
-  // boundaries: +1..3 % at 256..1024 pairs, +7..9 % at 32..64; three parts gain nothing more, four lose (measured).
-  // Results do not depend on it (a pair's blocks, records and state are its own; the slicing is the whole batch's).
+  // A batch is cut into two parts that run the same schedule on streams of their own (fixed schedules; 16 pairs and the
+  // pixels of 32 640x480 pairs or more): the launches of one part run in the gaps of the other's — the tail of a residual
+  // launch, the update launch, the kernel boundaries: +2..4 % at 256..1024 pairs, +7..9 % at 32..64 in a pipeline of calls;
+  // three parts gain nothing more, four lose (measured).  Results do not depend on it (a pair's blocks, records and state
+  // are its own; the slicing is the whole batch's).
   if (parts < 2) return run(0, n_pairs);
-  HIPCHK(c, hipEventRecord(c->ev_fork, c->stream));
+  // (fixed schedule, not profiled: no read-backs, no events around launches).  The parts' launches are enqueued in turns,
+  // iteration by iteration, so that both streams have work from the start.
+  struct Part { int base, cnt; hipStream_t s; ResidualArgs ra; UpdateArgs ua; };
+  Part pt[uwt_ctx::kMaxParts];
   hipStream_t main_stream = c->stream;
+  HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
+  for (int i = 0; i < parts; i++) {
+    Part& q = pt[i];
+    q.base = (int)((long long)n_pairs * i / parts);
+    q.cnt = (int)((long long)n_pairs * (i + 1) / parts) - q.base;
+    q.s = i ? c->part_stream[i] : main_stream;
+    if (i) HIPCHK(c, hipStreamWaitEvent(q.s, c->ev_fork, 0));
+    hipLaunchKernelGGL(k_init_state, dim3((q.cnt + tb - 1) / tb), dim3(tb), 0, q.s, c->state + q.base, q.cnt, p.initial_error);
+  }
+  HIPCHK(c, hipGetLastError());
   int st = UWT_OK;
-  for (int i = 0; i < parts && st == UWT_OK; i++) {
-    const int base = (int)((long long)n_pairs * i / parts), end = (int)((long long)n_pairs * (i + 1) / parts);
-    if (i) {
-      HIPCHK(c, hipStreamWaitEvent(c->part_stream[i], c->ev_fork, 0));
-      c->stream = c->part_stream[i];      // every launch helper enqueues on c->stream
+  for (int lvl = p.first_level; lvl >= p.last_level && st == UWT_OK; lvl--) {
+    for (int i = 0; i < parts; i++) {
+      Part& q = pt[i];
+      if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(q.s, level_ready[lvl], 0));  // its gradients
+      q.ra = residual_args(c, lvl);
+      q.ua = update_args(c, lvl);
+      q.ra.pair_base = q.ua.pair_base = q.base;
+      slicing(lvl, q.ra.groups_per_block, q.ra.slices);
+      q.ua.slices = q.ra.slices;
+      // A pair's records sit at (pair * slices + slice): the place depends on the level's slice count, and the parts are at
+      // different levels at times.  A part's records are shifted so that they start at base * smax whatever the level —
+      // behind everything the parts before it can touch, inside the buffer (slices <= smax).
+      const size_t shift = (size_t)q.base * (size_t)(smax - q.ra.slices) * kRecWords;
+      q.ra.partials = c->partials + shift;
+      q.ua.partials = c->partials + shift;
+      if (general) q.ua.general = 1;
     }
-    st = run(base, end - base);
-    if (i) {
-      c->stream = main_stream;
-      if (st == UWT_OK) {
-        HIPCHK(c, hipEventRecord(c->ev_join[i], c->part_stream[i]));
-        HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join[i], 0));
+    for (int k = 0; k < p.max_iters && st == UWT_OK; k++)
+      for (int i = 0; i < parts && st == UWT_OK; i++) {
+        Part& q = pt[i];
+        c->stream = q.s;      // every launch helper enqueues on c->stream
+        st = general ? launch_general(c, q.ra, q.cnt) : launch_residual(c, q.ra, q.cnt, false);
+        c->stream = main_stream;
+        if (st) break;
+        q.ua.k = k;
+        q.ua.active = nullptr;
+        hipLaunchKernelGGL(k_gn_update, dim3(q.cnt), dim3(kUpdateBlock), 0, q.s, q.ua);
       }
+    if (st) return st;
+    for (int i = 0; i < parts; i++)
+      hipLaunchKernelGGL(k_level_end, dim3((pt[i].cnt + tb - 1) / tb), dim3(tb), 0, pt[i].s, c->state + pt[i].base, pt[i].cnt, lvl,
+                         p.handoff_scale_t, p.initial_error);
+    HIPCHK(c, hipGetLastError());
+  }
+  for (int i = 0; i < parts; i++) {
+    hipLaunchKernelGGL(k_write_out, dim3((pt[i].cnt + tb - 1) / tb), dim3(tb), 0, pt[i].s, c->state + pt[i].base, pt[i].cnt,
+                       d_poses + 7 * (size_t)pt[i].base, d_stats ? d_stats + pt[i].base : nullptr);
+    if (i) {
+      HIPCHK(c, hipEventRecord(c->ev_join[i], pt[i].s));
+      HIPCHK(c, hipStreamWaitEvent(main_stream, c->ev_join[i], 0));
     }
   }
-  return st;
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
 }
 
 // ---- slot-range dependencies between the context stream and the copy stream --------------------------------------
@@ -844,6 +889,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   if (const char* e = std::getenv("UWT_SPLIT")) c->split = std::max(1, std::min(uwt_ctx::kMaxParts, std::atoi(e)));
   if (const char* e = std::getenv("UWT_SPLIT_MIN")) c->split_min = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("UWT_SPLIT_MIN_PX")) c->split_min_px = std::max(1LL, std::atoll(e));
   CREATE_CHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
   for (int i = 0; i < uwt_ctx::kDeps; i++) {
     CREATE_CHK(hipEventCreateWithFlags(&c->busy[i].ev, hipEventDisableTiming));
