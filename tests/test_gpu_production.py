@@ -300,6 +300,32 @@ def test_split_batch_small_images_parts_at_different_levels(capi, synth, monkeyp
         assert np.array_equal(poses.view(np.uint32), out["1"][0].view(np.uint32)), rep
 
 
+@pytest.mark.parametrize("mode", ["reference", "fixed"])
+def test_coarse_levels_in_one_launch_match_the_per_launch_form(capi, O, synth, monkeypatch, mode):
+    """The coarsest levels of a lone pair (those one block evaluates) run to their end in one launch, k_coarse — exit test
+    and hand-offs on the device; UWT_NO_COARSE=1 keeps a launch per evaluation.  Same poses and iteration counts, the
+    oracle's; 5 levels of 320x240: three coarse levels, then k_iterate; a pair of unrelated frames included (many
+    evaluations per level, the level limit of 50 in reach)."""
+    w, h = 320, 240
+    intr = (262.5, 262.5, 159.5, 119.5)
+    over = dict(has_depth=1) if mode == "reference" else dict(has_depth=1, n_levels=5, first_level=4, last_level=0, max_iters=7, early_exit=0)
+    pairs = [synth.render_pair(w, h, *intr, seed=8800 + i, max_t=0.02, max_deg=1.0, with_depth=True)[:3] for i in range(3)]
+    pairs.append((pairs[0][0], pairs[1][1], pairs[0][2]))      # unrelated frames
+    po = O.default_params(w, h, *intr, **over)
+    want = [O.align_pair(po, r, t, d, want_trace=True) for r, t, d in pairs]
+    for no_coarse in (False, True):
+        if no_coarse:
+            monkeypatch.setenv("UWT_NO_COARSE", "1")
+        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, **over))
+        for (r, t, d), (st, pose_cpu, tr) in zip(pairs, want):
+            _upload_pair(ctx, r, t, d)
+            poses, stats = ctx.estimate_pose_batch([0], [1])
+            assert stats[0]["status"] == st and stats[0]["iterations"] == len(tr), (no_coarse, stats[0], len(tr))
+            if st == 0:
+                assert np.array_equal(poses[0].view(np.uint32), pose_cpu.view(np.uint32)), no_coarse
+        ctx.close()
+
+
 # ------------------------------------------------------------------ launch paths of bench.py
 
 def _run(cmd, extra_env=None, timeout=540):

@@ -90,6 +90,7 @@ struct uwt_ctx {
   SmallResults* d_small = nullptr;      // its device address
   bool inline_pairs = false;
   bool deferred = false;                // uwt_set_deferred: stage calls return once enqueued
+  bool coarse = true;                   // k_coarse for the coarsest levels of the chained flow (UWT_NO_COARSE=1: off)
   int pair_slots[4] = {0, 0, 0, 0};
   int first_poll = 3;                   // evaluations of a level before the first early-exit read-back
   int chained = -1;                     // -1: chained flow for a few pairs (takes_chained_flow); UWT_CHAINED=1 / 0: always / never (A/B runs)
@@ -476,7 +477,40 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
   if (speculate) c->h_small->cut = 0;   // host store into page-locked memory, ahead of the launches that may set it
   ia.inline_pairs = c->inline_pairs ? 1 : 0;
   for (int i = 0; i < 4; i++) ia.pair_slots[i] = c->pair_slots[i];
-  for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
+  // The coarsest levels — those a single block evaluates — run to their end in one launch (k_coarse): default constants
+  // of the dense path only (f64 sums, unit factors, square pixels), at least one finer level left for k_iterate.
+  int start_lvl = p.first_level;
+  bool after_coarse = false;
+  {
+    const LevelK& L0 = c->lv[p.first_level];
+    const bool plain = p.accumulate_f64 != 0 && p.z_factor == 1.0f && p.angle_factor == 1.0f && L0.fx == L0.fy;
+    int nc = 0;
+    while (nc < kCoarseMaxLevels && start_lvl - nc > p.last_level && c->lv[start_lvl - nc].n <= kCoarseMaxPixels) nc++;
+    if (nc > 0 && plain && c->coarse && !c->profiling && !c->compute_only) {
+      CoarseArgs ca;
+      std::memset(&ca, 0, sizeof(ca));
+      for (int i = 0; i < nc; i++) {
+        const int lvl = p.first_level - i;
+        if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(c->stream, level_ready[lvl], 0));  // its gradients
+        ca.lv[i] = residual_args(c, lvl);
+        ca.lv[i].state = nullptr;
+        ca.level_id[i] = lvl;
+      }
+      ca.n_levels = nc;
+      ca.u = ia.u;
+      ca.state_out = states[sp ^ 1];     // where the first k_iterate launch looks for its state
+      ca.scale_t = ia.scale_t;
+      ca.initial_error = ia.initial_error;
+      ca.inline_pairs = ia.inline_pairs;
+      for (int i = 0; i < 4; i++) ca.pair_slots[i] = ia.pair_slots[i];
+      if (p.has_depth) hipLaunchKernelGGL((k_coarse<true, true, double, true>), dim3(n_pairs), dim3(kBlock), 0, c->stream, ca);
+      else hipLaunchKernelGGL((k_coarse<false, true, double, true>), dim3(n_pairs), dim3(kBlock), 0, c->stream, ca);
+      HIPCHK(c, hipGetLastError());
+      start_lvl = p.first_level - nc;
+      after_coarse = true;
+    }
+  }
+  for (int lvl = start_lvl; lvl >= p.last_level; lvl--) {
     if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(c->stream, level_ready[lvl], 0));  // its gradients
     ResidualArgs ra = residual_args(c, lvl);
     ra.state = nullptr;
@@ -491,7 +525,7 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
     int next_poll = c->first_poll;   // see enqueue_estimate
     int k = 0;
     for (; k < (speculate ? spec_iters : p.max_iters); k++) {
-      ia.mode = first ? 0 : (k == 0 ? 2 : 1);
+      ia.mode = first ? (after_coarse ? 3 : 0) : (k == 0 ? 2 : 1);
       ia.u.partials = recs[rp ^ 1];
       ia.u.slices = prev_slices;
       ia.u.k = prev_k;
@@ -888,6 +922,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   }
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   if (const char* e = std::getenv("UWT_SPLIT")) c->split = std::max(1, std::min(uwt_ctx::kMaxParts, std::atoi(e)));
+  if (std::getenv("UWT_NO_COARSE")) c->coarse = false;
   if (const char* e = std::getenv("UWT_SPLIT_MIN")) c->split_min = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("UWT_SPLIT_MIN_PX")) c->split_min_px = std::max(1LL, std::atoll(e));
   CREATE_CHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));

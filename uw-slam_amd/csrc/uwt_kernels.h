@@ -1521,7 +1521,8 @@ struct IterArgs {
   UpdateArgs u;               // the pending update: u.partials / u.slices / u.k describe the previous evaluation
   const PairState* state_in;
   PairState* state_out;
-  int mode;                   // 0: first evaluation of the alignment (fresh state); 1: update, evaluate; 2: update, hand-off, evaluate
+  int mode;                   // 0: first evaluation of the alignment (fresh state); 1: update, evaluate; 2: update, hand-off, evaluate;
+                              // 3: evaluate from state_in as it is (the launch behind k_coarse)
   int prev_lvl;               // level the pending update / hand-off belongs to (mode 2)
   int scale_t;
   float initial_error;
@@ -1543,6 +1544,7 @@ __device__ __forceinline__ PairState iterate_state(const IterArgs& ia, int pair,
     st.n_valid = 0;
     return st;
   }
+  if (ia.mode == 3) return ia.state_in[pair];   // behind k_coarse: the state is current, nothing is pending
   st = update_compute(ia.u, ia.u.partials + (size_t)pair * ia.u.slices * kRecWords, &ia.state_in[pair], lds, count_active);
   if (ia.mode == 2) {   // end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
     // with early exit a level ends only through its exit test (which fires at the last iteration at the latest)
@@ -1597,6 +1599,78 @@ __global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterAr
     rec[63] = (uint32_t)__builtin_amdgcn_s_memrealtime();
   }
 #endif
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_coarse: the coarsest levels of a lone pair's alignment in ONE launch.  A level of a few thousand pixels fits a single
+// block; evaluating it there — the record stays in LDS, the update reads it from there, the exit test is taken on the
+// device — removes the kernel boundary, the cross-CU round trip of the records and the re-launch per iteration (and, in
+// early-exit schedules, every speculative launch of these levels): about 5 us per evaluation instead of 10.  One block
+// per pair runs levels lv[0..n_levels) to their end (hand-offs included) and leaves the state for the first k_iterate
+// launch of the next level (mode 3).  Same device functions as k_iterate (residual_core with one slice, update_compute on
+// one record); the f64 sums are grouped differently, as between any two slicings.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kCoarseMaxLevels = 3;
+constexpr int kCoarseMaxPixels = 6144;   // a level up to here is evaluated by one block (24 pixels per thread)
+struct CoarseArgs {
+  ResidualArgs lv[kCoarseMaxLevels];   // coarsest first; partials / slices / groups_per_block are set by the kernel
+  int level_id[kCoarseMaxLevels];      // pyramid level of lv[i] (the hand-off is skipped behind level 0)
+  int n_levels;
+  UpdateArgs u;                        // max_iters, early_exit, epsilon, gain
+  PairState* state_out;
+  int scale_t;
+  float initial_error;
+  int inline_pairs;                    // see IterArgs
+  int pair_slots[4];
+};
+
+template <bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE>
+__global__ UWT_RESIDUAL_BOUNDS void k_coarse(const CoarseArgs ca) {
+  constexpr int kLds = iterate_lds_bytes(kIteratePass);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kLds + kRecWords * 4 + 64];
+  uint32_t* rec = reinterpret_cast<uint32_t*>(lds + kLds);                     // the evaluation's record
+  PairState* cur = reinterpret_cast<PairState*>(lds + kLds + kRecWords * 4);   // the state update_compute reads
+  const int lp = (int)blockIdx.x, pair = lp + ca.u.pair_base;
+  const int ref_slot = ca.inline_pairs ? (lp == 0 ? ca.pair_slots[0] : ca.pair_slots[2]) : ca.lv[0].ref_slots[pair];
+  const int tgt_slot = ca.inline_pairs ? (lp == 0 ? ca.pair_slots[1] : ca.pair_slots[3]) : ca.lv[0].tgt_slots[pair];
+  PairState st;
+  pose_identity(st.pose);  // src/Tracker.cpp:385
+  st.last_error = ca.initial_error;
+  st.error = 0.f;
+  st.level_done = 0;
+  st.status = 0;
+  st.iters = 0;
+  st.n_valid = 0;
+#pragma unroll
+  for (int li = 0; li < kCoarseMaxLevels; li++) {
+    if (li >= ca.n_levels) break;   // block-uniform
+    ResidualArgs a = ca.lv[li];
+    a.slices = 1;
+    a.groups_per_block = ((a.L.n / 4 + kBlock - 1) / kBlock) * kBlock;   // the whole level
+    a.partials = rec - (size_t)pair * kRecWords;                          // residual_core writes record (pair, slice 0)
+    a.probe = 0;
+    UpdateArgs u = ca.u;
+    u.slices = 1;
+    u.active = nullptr;
+    if (st.status == 0) {
+      for (int k = 0; k < u.max_iters; k++) {
+        __syncthreads();   // every thread has taken the state out of the update's LDS bytes: they become the reduction's
+        if (threadIdx.x == 0) *cur = st;
+        residual_core<4, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, false, kIteratePass>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot);
+        __syncthreads();   // the record and the state are in LDS; the reduction's image is free
+        u.k = k;
+        st = update_compute(u, rec, cur, lds, false);   // ends with a barrier: every thread has the new state
+        if (st.level_done || st.status) break;          // block-uniform (the exit test, src/Tracker.cpp:508)
+      }
+    }
+    // end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
+    if (st.status == 0 && ca.level_id[li] != 0) {
+      if (!se3_handoff(st.pose, ca.scale_t != 0)) st.status = 1;  // SOPHUS_ENSURE would abort
+    }
+    st.level_done = 0;
+    st.last_error = ca.initial_error;
+  }
+  if (threadIdx.x == 0) ca.state_out[pair] = st;
 }
 
 struct StatsOut { int status, iterations, n_valid; float error; };
