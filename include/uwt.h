@@ -141,7 +141,12 @@ int uwt_apply_gradient(uwt_ctx* ctx, int32_t first_slot, int32_t n);
 
 /* Tracker::EstimatePose(previous, current) (src/Tracker.cpp:362-597) for n_pairs independent pairs.
  * poses_out: n_pairs x 7 floats (qx qy qz qw tx ty tz) = previous_frame->rigid_transformation_ (:595).
- * Dense points (Tracker::ObtainAllPoints, :1259-1310) are implicit: the pixel grid is never materialised. */
+ * Dense points (Tracker::ObtainAllPoints, :1259-1310) are implicit: the pixel grid is never materialised.
+ * Synchronous.  How the launches are laid out follows the batch (same results either way): a few pairs per call take
+ * the chained flow (one launch per evaluation, the coarsest levels in one launch, results written straight into
+ * page-locked memory; one or two pairs of an early-exit schedule are launched without read-backs and redone the careful
+ * way if a level was cut short), batches take one residual and one update launch per evaluation, large fixed-schedule
+ * batches as two halves on two streams. */
 int uwt_estimate_pose_batch(uwt_ctx* ctx, int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
                             float* poses_out, uwt_stats* stats_out_or_null);
 
