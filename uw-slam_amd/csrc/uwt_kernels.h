@@ -1,12 +1,15 @@
 // uwt_kernels.h — gfx950 kernels of the direct SE(3) tracking path.
 //
-//   k_halve_*      System::AddFrame pyramid loop            (src/System.cpp:246-251)
-//   k_scharr3      Tracker::ApplyGradient                   (src/Tracker.cpp:1133-1134)
+//   k_halve, k_pyramid_all      System::AddFrame pyramid loop (a launch per level / every level of a few frames in one)
+//                               (src/System.cpp:246-251)
+//   k_scharr3*, k_scharr3_levels   Tracker::ApplyGradient (per level / every level of a few frames in one launch)
+//                               (src/Tracker.cpp:1133-1134)
 //   k_residual     WarpFunction + per-point loop + the 28-accumulator LS reduction, fused
 //                  (src/Tracker.cpp:1417-1471, 432-490; src/LeastSquares.cpp:148-209)
 //   k_gn_update    error / exit test / normal equations / solve / pose update (src/Tracker.cpp:495-574)
 //   k_level_end    level hand-off                           (src/Tracker.cpp:580-590)
-//   k_iterate, k_finish   the same loop chained: update + hand-off at the head of the next evaluation (one or two pairs)
+//   k_iterate, k_finish   the same loop chained: update + hand-off at the head of the next evaluation (a few pairs per call)
+//   k_coarse       the coarsest levels of such a call run to their end in one launch, one block per pair
 //   k_residual_points, k_residual_general, k_resid_hist*, k_scale_stage   explicit point tables; robust weights / bilinear
 //   k_grad_mag*, k_candidates_batch, k_scan_counts, k_patch_points, k_remap_crop, k_trajectory*   the rows next to the path
 //
