@@ -235,6 +235,23 @@ def test_deferred_stage_calls_wait_once_per_frame(capi, O, synth):
         if st == 0:
             assert np.array_equal(poses[0].view(np.uint32), pose_cpu.view(np.uint32)) and stats[0]["iterations"] == len(tr)
     ctx.close()
+    # a deferred call still in flight holds its slots: an asynchronous upload into them waits for it
+    big = capi.Context(capi.default_params(1280, 960, 1050.0, 1050.0, 639.5, 479.5, max_frames=1, max_pairs=1, n_levels=5,
+                                           first_level=4, last_level=0))
+    big.set_deferred(True)
+    old = synth.texture(1280, 960, seed=1)
+    new = capi.pinned_empty((1, 960, 1280), np.uint8)
+    new[0] = synth.texture(1280, 960, seed=2)
+    for _ in range(3):
+        big.upload_frames(0, old[None])
+        big.build_pyramids(0, 1)
+        big.apply_gradient(0, 1)                 # enqueued only
+        big.upload_frames_async(0, new)          # must land behind the gradient kernels that read the old level 0
+        big.sync()
+        gx, _ = O.scharr3(old)
+        assert np.array_equal(big.get_plane(0, 0, capi.PLANE_GRADX), gx)
+        assert np.array_equal(big.get_plane(0, 0, capi.PLANE_IMAGE), new[0])
+    big.close()
 
 
 @pytest.mark.parametrize("mode", ["identity", "huber"])

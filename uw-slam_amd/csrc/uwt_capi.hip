@@ -1211,6 +1211,7 @@ int uwt_build_pyramids(uwt_ctx* c, int32_t first_slot, int32_t n) {
   st = enqueue_pyramids(c, first_slot, n);
   if (st) return st;
   if (!c->deferred) HIPCHK(c, hipStreamSynchronize(c->stream));
+  else return compute_end(c, first_slot, n);   // still in flight: a later asynchronous upload into these slots waits for it
   return UWT_OK;
 }
 
@@ -1222,6 +1223,7 @@ int uwt_apply_gradient(uwt_ctx* c, int32_t first_slot, int32_t n) {
   st = enqueue_gradients(c, first_slot, n);
   if (st) return st;
   if (!c->deferred) HIPCHK(c, hipStreamSynchronize(c->stream));
+  else return compute_end(c, first_slot, n);   // still in flight: a later asynchronous upload into these slots waits for it
   return UWT_OK;
 }
 
