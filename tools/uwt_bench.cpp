@@ -22,6 +22,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <string>
+#include <atomic>
 #include <thread>
 #include <vector>
 
@@ -174,12 +175,21 @@ struct Barrier {   // std::barrier is C++20
   std::mutex m;
   std::condition_variable cv;
   int n, waiting = 0, phase = 0;
+  bool aborted = false;
   explicit Barrier(int n_) : n(n_) {}
-  void wait() {
+  // false: a device thread failed and called abort() — every waiter (now or later) gives up instead of waiting for it
+  bool wait() {
     std::unique_lock<std::mutex> lk(m);
+    if (aborted) return false;
     const int ph = phase;
     if (++waiting == n) { waiting = 0; phase++; cv.notify_all(); }
-    else cv.wait(lk, [&] { return phase != ph; });
+    else cv.wait(lk, [&] { return phase != ph || aborted; });
+    return !aborted;
+  }
+  void abort() {
+    std::lock_guard<std::mutex> lk(m);
+    aborted = true;
+    cv.notify_all();
   }
 };
 
@@ -254,12 +264,12 @@ int run_device(Shared& S, int dev) {
   for (int i = 0; i < S.warmup; i++)
     if (step()) return 1;
   CHK(uwt_sync(ctx));
-  S.bar->wait();
+  if (!S.bar->wait()) return 1;
   if (dev == 0) S.t_start = now_s();
   for (int i = 0; i < S.steps; i++)
     if (step()) return 1;
   CHK(uwt_sync(ctx));
-  S.bar->wait();                      // the job's time is that of its slowest device
+  if (!S.bar->wait()) return 1;       // the job's time is that of its slowest device
   if (dev == 0) S.t_end = now_s();
 
   S.own[dev].resize((size_t)7 * P);
@@ -310,8 +320,23 @@ int main(int argc, char** argv) {
   S.own.resize(S.n_dev);
   S.rc.assign(S.n_dev, 0);
   std::vector<std::thread> th;
-  for (int d = 1; d < S.n_dev; d++) th.emplace_back([&S, d] { S.rc[d] = run_device(S, d); if (S.rc[d]) std::exit(1); });
-  S.rc[0] = run_device(S, 0);
+  // a failing device thread aborts the barrier, so the others return instead of waiting for it; a peer stuck inside a
+  // collective the failed device never joins cannot be woken that way — after a grace period the process leaves through
+  // _Exit (no destructors racing live HIP / RCCL state)
+  std::atomic<int> done{0};
+  auto body = [&S, &done](int d) {
+    S.rc[d] = run_device(S, d);
+    if (S.rc[d]) S.bar->abort();
+    done++;
+  };
+  for (int d = 1; d < S.n_dev; d++) th.emplace_back(body, d);
+  body(0);
+  bool failed = false;
+  for (int d = 0; d < S.n_dev; d++) failed |= S.rc[d] != 0;
+  if (failed) {
+    for (int w = 0; w < 100 && done.load() < S.n_dev; w++) std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    if (done.load() < S.n_dev) { std::fprintf(stderr, "a device failed and a peer did not return: leaving\n"); std::_Exit(1); }
+  }
   for (auto& t : th) t.join();
   for (int d = 0; d < S.n_dev; d++)
     if (S.rc[d]) return 1;

@@ -31,6 +31,7 @@ struct uwt_ctx {
   // iterations of the alignment (VALU-bound), which only read the coarsest iterated level.  UWT_OVERLAP_GRAD=0: off.
   hipStream_t side = nullptr;
   static constexpr int kMaxParts = 4;
+  int dep_first = 0, dep_n = 0;         // slot range the running tracker call depends on (track_batch_enqueue)
   hipStream_t part_stream[kMaxParts] = {};   // compute streams of parts 1.. of a split batch (part 0: `stream`)
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {};
   int split = 2;                        // parts a fixed-schedule batch is cut into (UWT_SPLIT; 1 = one stream)
@@ -576,8 +577,9 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
   ia.u.active = nullptr;
   ia.prev_lvl = prev_lvl;
   ia.state_in = states[sp ^ 1];
-  ia.state_out = c->state;      // the final state always lands in the primary buffer
-  if (ia.state_in == ia.state_out) ia.state_out = c->state2;
+  // The final state lands in whichever of the two buffers the last evaluation did not read (that depends on the parity of
+  // the launch count); nothing reads either buffer after a chained call — results leave through d_poses / d_stats.
+  ia.state_out = ia.state_in == c->state ? c->state2 : c->state;
   hipLaunchKernelGGL(k_finish, dim3(n_pairs), dim3(kUpdateBlock), 0, c->stream, ia, d_poses, d_stats);
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
@@ -692,6 +694,16 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   struct Part { int base, cnt; hipStream_t s; ResidualArgs ra; UpdateArgs ua; };
   Part pt[uwt_ctx::kMaxParts];
   hipStream_t main_stream = c->stream;
+  // every early return below (a failed launch or event call) leaves part streams forked and not joined: drain them before
+  // the error reaches the caller, so that uwt_sync / uwt_destroy on the main stream really mean "nothing is running"
+  struct JoinGuard {
+    uwt_ctx* c; int parts; hipStream_t main; bool joined = false;
+    ~JoinGuard() {
+      if (joined) return;
+      c->stream = main;
+      for (int i = 1; i < parts; i++) (void)hipStreamSynchronize(c->part_stream[i]);
+    }
+  } guard{c, parts, main_stream};
   HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
   for (int i = 0; i < parts; i++) {
     Part& q = pt[i];
@@ -746,6 +758,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
     }
   }
   HIPCHK(c, hipGetLastError());
+  guard.joined = true;
   return UWT_OK;
 }
 
@@ -975,6 +988,8 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->side) (void)hipStreamSynchronize(c->side);  // an aborted uwt_track_batch_async may have left work there
   if (c->copy) (void)hipStreamSynchronize(c->copy);
+  for (int i = 1; i < uwt_ctx::kMaxParts; i++)
+    if (c->part_stream[i]) (void)hipStreamSynchronize(c->part_stream[i]);
   for (int l = 0; l < UWT_MAX_LEVELS; l++) {
     if (c->img[l]) (void)hipFree(c->img[l]);
     if (c->depth[l]) (void)hipFree(c->depth[l]);
@@ -1298,7 +1313,17 @@ static int track_batch_enqueue(uwt_ctx* c, int32_t first_slot, int32_t n_frames,
   c->speculate = false;
   int st = upload_pairs(c, n_pairs, ref_slots, tgt_slots);
   if (st) return st;
-  st = compute_begin(c, first_slot, n_frames);   // behind the asynchronous uploads into these slots
+  // The alignment reads every slot the pair lists name, and with grad_refs_only the reference slots lie "wherever they
+  // lie" (uwt.h): the dependency range of the call is the union of the prepared range and the pairs' slots, so that an
+  // asynchronous upload into ANY slot this call reads waits for it, and this call for any upload into them.
+  int lo = first_slot, hi = first_slot + n_frames;
+  for (int i = 0; i < n_pairs; i++) {
+    lo = std::min(lo, std::min(ref_slots[i], tgt_slots[i]));
+    hi = std::max(hi, std::max(ref_slots[i], tgt_slots[i]) + 1);
+  }
+  c->dep_first = lo;
+  c->dep_n = hi - lo;
+  st = compute_begin(c, c->dep_first, c->dep_n);   // behind the asynchronous uploads into these slots
   if (st) return st;
   // The tracker reads gradients and depth of the previous (reference) frame only (src/Tracker.cpp:407-408, 1266-1272).
   // grad_refs_only computes those planes — gradients of every level, depth levels 1.. — for the pairs' reference slots
@@ -1343,7 +1368,7 @@ int uwt_track_batch_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int3
                           const int32_t* ref_slots, const int32_t* tgt_slots, float* d_poses_out, uwt_stats* d_stats_out) {
   int st = track_batch_enqueue(c, first_slot, n_frames, grad_refs_only, n_pairs, ref_slots, tgt_slots, d_poses_out, d_stats_out);
   if (st) return st;
-  return compute_end(c, first_slot, n_frames);
+  return compute_end(c, c->dep_first, c->dep_n);
 }
 
 int uwt_track_batch_host_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only, int32_t n_pairs,
@@ -1358,7 +1383,7 @@ int uwt_track_batch_host_async(uwt_ctx* c, int32_t first_slot, int32_t n_frames,
   HIPCHK(c, hipMemcpyAsync(h_poses_out, c->d_poses, sizeof(float) * 7 * n_pairs, hipMemcpyDeviceToHost, c->stream));
   if (h_stats_out)
     HIPCHK(c, hipMemcpyAsync(h_stats_out, c->d_stats, sizeof(uwt_stats) * n_pairs, hipMemcpyDeviceToHost, c->stream));
-  st = compute_end(c, first_slot, n_frames);
+  st = compute_end(c, c->dep_first, c->dep_n);
   if (st) return st;
   *ticket_out = c->ticket_seq;
   return UWT_OK;

@@ -41,12 +41,12 @@ class Tracker:
 
     def __init__(self, _depth_available=False, max_frames=16, device=0, **params):
         self.depth_available_ = bool(_depth_available)
-        self._max_frames = max_frames
+        self._max_frames = max(2, int(max_frames))   # an alignment binds two frames at once (uw::Tracker clamps the same way)
         self._device = device
         self._over = params
         self._ctx = None
-        self._owner = [None] * max_frames          # slot -> Frame holding it
-        self._last_use = [0] * max_frames
+        self._owner = [None] * self._max_frames          # slot -> Frame holding it
+        self._last_use = [0] * self._max_frames
         self._clock = 0
 
     def InitializePyramid(self, _width, _height, _K):
@@ -225,9 +225,10 @@ class LS:
             A2, b2, e2, n2 = self._ctx.ls_accumulate_sse(np.concatenate(self._J4), np.concatenate(self._r4), np.concatenate(self._w4),
                                                          False, self.count_quirk)
             A, b, err, n = A + A2, b + b2, np.float32(err + np.float32(e2)), n + n2
-        if divide and n:
+        if divide:   # unconditional, as LS::finish (src/LeastSquares.cpp:141-146) and uw::LS::finish: an empty system gives NaN
             fn = np.float32(n)
-            A, b, err = A / fn, b / fn, np.float32(err / fn)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                A, b, err = A / fn, b / fn, np.float32(np.float32(err) / fn)
         self.A, self.b, self.error, self.num_constraints = A.astype(np.float32), b.astype(np.float32), float(err), n
 
     def finishNoDivide(self):
