@@ -339,6 +339,8 @@ def main(args):
             assert all_poses.shape == (total, 7)
             assert np.array_equal(all_poses[rank::world], gpu_poses), "gathered poses of rank 0 differ from its own"
             assert np.isfinite(all_poses).all() and (np.abs(np.linalg.norm(all_poses[:, :4], axis=1) - 1.0) < 1e-3).all()
+            out["config"]["gather"] = {"collective_ran": bool(gatherer.collective), "world": world,
+                                       "rank0_block_bitwise_equal_to_its_own_poses": True}
         # SURVEY §8(d) secondary figure: the same step with the batch's frames crossing PCIe first (never `value`)
         out["h2d_inclusive"] = {"value": round(P / (upload_s + dt / args.steps), 2), "unit": "alignments/s per GPU",
                                 "upload_ms": round(upload_s * 1e3, 2), "upload_GBs": round(upload_bytes / upload_s / 1e9, 2),

@@ -383,23 +383,52 @@ def test_bench_rccl_world_of_one_gathers_on_the_context_stream():
     assert r.returncode == 0, r.stderr.decode()[-2000:]
     d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
     assert d["n_gpus"] == 1 and "RCCL" in d["config"]["sharding"]
+    # the collective itself ran (a world of one no longer returns early) and rank 0 compared its block bit for bit
+    assert d["config"]["gather"] == {"collective_ran": True, "world": 1, "rank0_block_bitwise_equal_to_its_own_poses": True}
+
+
+def test_native_bench_rccl_allgather_on_the_one_device():
+    """tools/uwt_bench --gpus 1 --rccl: the native multi-GPU mode's ncclCommInitAll + ncclAllGather on the context's stream,
+    the gathered block compared with the device's own poses on the host."""
+    exe = os.path.join(ROOT, "tools", "uwt_bench")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools")])
+    r = _run([exe, "--pairs", "20", "--unique", "5", "--width", "160", "--height", "96", "--levels", "3", "--steps", "3", "--warmup", "1",
+              "--gpus", "1", "--rccl"], timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    d = json.loads(r.stdout.decode().strip().splitlines()[-1])
+    assert d["gathered_blocks_match"] is True and d["tiled_pairs_identical"] and d["poses_finite"] and d["n_gpus"] == 1
 
 
 def test_pose_gatherer_nccl_world_one_in_process_stream_order():
-    """PoseGatherer with the nccl backend (world 1) on a side stream behind a kernel that writes the poses."""
+    """PoseGatherer with the nccl backend (world 1) on a side stream behind a kernel that writes the poses: with a process
+    group the all_gather_into_tensor and the index_select really run (RCCL kernels on the caller's stream) — both the
+    direct form and the one staged through the padded send block that ranks with uneven shards use — and the gathered
+    tensor is the local one bit for bit, in a buffer of the gatherer's own."""
     code = r'''
 import os, importlib, torch, torch.distributed as dist
 os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29612", RANK="0", WORLD_SIZE="1")
 dev = torch.device("cuda", 0); torch.cuda.set_device(0)
 dist.init_process_group("nccl", device_id=dev)
 d = importlib.import_module("uw-slam_amd.dist")
-g = d.PoseGatherer(37, dev)
-s = torch.cuda.Stream()
-with torch.cuda.stream(s):
-    local = torch.arange(37 * 7, dtype=torch.float32, device=dev).reshape(37, 7) * 2.0
-    out = g.gather(local)
-s.synchronize()
-assert torch.equal(out, local)
+calls = []
+real = dist.all_gather_into_tensor
+def spy(*a, **k):
+    calls.append(1)
+    return real(*a, **k)
+dist.all_gather_into_tensor = spy
+for stage in (False, True):
+    g = d.PoseGatherer(37, dev, stage_send=stage)
+    assert g.collective
+    s = torch.cuda.Stream()
+    for rep in range(3):
+        with torch.cuda.stream(s):
+            local = (torch.arange(37 * 7, dtype=torch.float32, device=dev).reshape(37, 7) * 2.0 + rep) / 3.0
+            out = g.gather(local)
+        s.synchronize()
+        assert out.data_ptr() == g.out.data_ptr() != local.data_ptr()
+        assert torch.equal(out.view(torch.int32), local.view(torch.int32)), (stage, rep)
+assert len(calls) == 6, calls
 dist.destroy_process_group()
 print("ok")
 '''

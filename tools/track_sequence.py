@@ -55,14 +55,28 @@ def main():
     traj = trk.trajectory(poses)
     ref = trk.trajectory(poses, reference_visualiser=True)
     gt = None
+    bad = sum(s["status"] != 0 for s in stats)
+    metrics = dict(pairs=int(len(poses)), failed=int(bad), seconds=dt, crop_offset=[int(x0), int(y0)],
+                   iterations=[int(s["iterations"]) for s in stats])
     if a.groundtruth:
         ts, gtp = (T.read_groundtruth_euroc if a.euroc else T.read_groundtruth_tum)(a.groundtruth)
-        idx = T.ground_truth_indices(len(gtp), len(names), a.start, euroc=a.euroc)[1:]
-        gt = gtp[np.clip(idx, 0, len(gtp) - 1)]
-        print("ATE RMSE %.4f m over %d poses" % (S.ate_rmse(traj[:, 4:], gt[:, 4:]), len(traj)))
+        idx_all = np.clip(T.ground_truth_indices(len(gtp), len(names), a.start, euroc=a.euroc), 0, len(gtp) - 1)
+        gt = gtp[idx_all[1:]]
+        # ATE: accumulated estimate against the ground-truth poses of the same frames, relative to the first frame's, after
+        # a rigid alignment; RPE: per-pair relative translation against the ground truth's G_{k-1}^-1 G_k
+        g_rel = T.relative_poses(gtp[idx_all])
+        g_abs = T.compose_from(g_rel)
+        metrics["ate_rmse_m"] = S.ate_rmse(traj[:, 4:], g_abs[:, 4:])
+        metrics["rpe_trans_rmse_m"] = S.rpe_translation(poses[:, 4:], g_rel[:, 4:])
+        metrics["rpe_rot_rmse_rad"] = T.rpe_rotation(poses, g_rel)
+        print("ATE RMSE %.4f m, RPE %.5f m / %.5f rad over %d poses"
+              % (metrics["ate_rmse_m"], metrics["rpe_trans_rmse_m"], metrics["rpe_rot_rmse_rad"], len(traj)))
     T.write_reference_csv(a.out + "_reference.csv", ref, gt)
     T.write_tum(a.out + "_tum.txt", np.arange(len(traj), dtype=np.float64), traj)
-    bad = sum(s["status"] != 0 for s in stats)
+    np.save(a.out + "_poses.npy", poses)
+    import json
+    with open(a.out + "_metrics.json", "w") as f:
+        json.dump(metrics, f)
     print("%d pairs in %.3f s (%.1f pairs/s incl. upload), %d failed; wrote %s_reference.csv, %s_tum.txt"
           % (len(poses), dt, len(poses) / dt, bad, a.out, a.out))
 

@@ -21,10 +21,13 @@ class PoseGatherer:
     all_gather_into_tensor and one index_select per call, both enqueued on the caller's current stream; no host loop,
     no allocation, no synchronisation."""
 
-    def __init__(self, n_pairs, device, dtype=None, group=None):
+    def __init__(self, n_pairs, device, dtype=None, group=None, stage_send=False):
+        """stage_send: always go through the padded send block (what ranks with uneven shards do), so that a world of one
+        exercises that copy too."""
         import torch
         import torch.distributed as dist
         self.group = group
+        self.collective = dist.is_initialized()   # a process group exists: the collective runs, whatever the world size
         self.n_pairs = int(n_pairs)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -32,7 +35,7 @@ class PoseGatherer:
         sizes = shard_sizes(self.n_pairs, self.world)
         self.n_local = sizes[self.rank]
         self.m = max(sizes) if sizes else 0
-        self.even = all(s == self.m for s in sizes)
+        self.even = all(s == self.m for s in sizes) and not stage_send
         self.send = None if self.even else torch.zeros((self.m, 7), dtype=dtype, device=device)
         self.gathered = torch.empty((self.world * self.m, 7), dtype=dtype, device=device)
         i = torch.arange(self.n_pairs, dtype=torch.int64)
@@ -44,8 +47,10 @@ class PoseGatherer:
         global pair order (a buffer owned by the gatherer, overwritten by the next call)."""
         import torch
         import torch.distributed as dist
-        if self.world == 1:
+        if not self.collective:   # no process group (plain single-GPU run): nothing to exchange
             return local_poses
+        # With a process group the exchange runs even for a world of one, so that a one-GPU box executes the very calls
+        # (all_gather_into_tensor on the caller's stream, the un-shuffle) that N ranks do.
         block = local_poses
         if not self.even:
             self.send[: self.n_local].copy_(local_poses)

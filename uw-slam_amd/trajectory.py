@@ -69,3 +69,56 @@ def ground_truth_indices(n_gt, n_images, start_index, euroc=False):
     step = n_gt // max(n_images, 1)
     first = start_index * step + (600 if euroc else 0)
     return first + step * np.arange(n_images)
+
+
+def _qmul(a, b):
+    ax, ay, az, aw = a; bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx,
+                     aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def _qrot(q, v):
+    x, y, z, w = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return R @ v
+
+
+def relative_poses(abs_poses):
+    """rel[k] = abs[k]^-1 * abs[k+1] (float64) for n absolute poses in the library layout: the per-pair ground truth that
+    Visualizer::UpdateMessages' accumulation final = previous * SE3(q, t) (src/Visualizer.cpp:313) turns back into abs."""
+    P = np.asarray(abs_poses, np.float64).reshape(-1, 7)
+    out = np.zeros((max(len(P) - 1, 0), 7))
+    for k in range(len(P) - 1):
+        qa = P[k, :4] / np.linalg.norm(P[k, :4])
+        qb = P[k + 1, :4] / np.linalg.norm(P[k + 1, :4])
+        qi = qa * [-1, -1, -1, 1]
+        out[k, :4] = _qmul(qi, qb)
+        out[k, 4:] = _qrot(qi, P[k + 1, 4:] - P[k, 4:])
+    return out
+
+
+def compose_from(rel, start=None):
+    """abs[k] = start * rel[0] * ... * rel[k] (float64), one row per relative pose — the same product the library's
+    uwt_accumulate_trajectory forms in f32."""
+    rel = np.asarray(rel, np.float64).reshape(-1, 7)
+    q = np.array([0, 0, 0, 1.0]) if start is None else np.asarray(start[:4], np.float64)
+    t = np.zeros(3) if start is None else np.asarray(start[4:], np.float64)
+    out = np.zeros_like(rel)
+    for k, r in enumerate(rel):
+        t = t + _qrot(q, r[4:])
+        q = _qmul(q, r[:4] / np.linalg.norm(r[:4]))
+        out[k, :4], out[k, 4:] = q, t
+    return out
+
+
+def rpe_rotation(est_rel, gt_rel):
+    """RMSE of the angle of est^-1 * gt per pair (radians)."""
+    e = np.asarray(est_rel, np.float64).reshape(-1, 7)
+    g = np.asarray(gt_rel, np.float64).reshape(-1, 7)
+    ang = []
+    for a, b in zip(e, g):
+        d = _qmul(a[:4] * [-1, -1, -1, 1] / np.linalg.norm(a[:4]), b[:4] / np.linalg.norm(b[:4]))
+        ang.append(2.0 * np.arctan2(np.linalg.norm(d[:3]), abs(d[3])))
+    return float(np.sqrt(np.mean(np.square(ang)))) if ang else 0.0
