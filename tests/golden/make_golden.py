@@ -82,6 +82,7 @@ def main():
               dict(n_levels=3, first_level=2, last_level=0, max_iters=6, early_exit=0), max_t=0.02, max_deg=1.0)
     mid = (131.25, 131.25, 79.5, 47.5)
     pair_case("pair_160x96_ref5", 160, 96, mid, 13, dict())  # reference defaults: 5 levels, 4->1, 50 it, early exit
+    pair_case("pair_160x96_ref5_depth", 160, 96, mid, 17, dict(), with_depth=True, z=1.05)  # reference constants + depth plane
     pair_case("pair_160x96_fixed", 160, 96, mid, 14,
               dict(n_levels=4, first_level=3, last_level=0, max_iters=10, early_exit=0))
     pair_case("pair_160x96_depth", 160, 96, mid, 15,
