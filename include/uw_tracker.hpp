@@ -12,8 +12,9 @@
 //     tracker_->EstimatePose(previous_frame_, current_frame_);   // -> previous_frame_->rigid_transformation_
 //
 // OpenCV / Eigen / Sophus are not required: images are passed as uw::ImageView (data, rows, cols, step — the four
-// cv::Mat fields the path reads); define UW_WITH_OPENCV before including to get the cv::Mat overloads, UW_WITH_EIGEN for
-// Eigen::Map views of LS::A / LS::b.
+// cv::Mat fields the path reads); define UW_WITH_OPENCV before including to get the cv::Mat overloads, UW_WITH_EIGEN to make
+// uw::Mat61f / uw::Mat66f (LS::A, LS::b, LS::update's Jacobian) the reference's Eigen types instead of the stand-ins below.
+// Neither branch has been compiled in the image this repository is developed in (it has no OpenCV and no Eigen).
 // Every numeric step runs in libuwt_hip.so on the GPU; a non-zero status becomes a std::runtime_error (the reference
 // surfaces misuse as cv::Exception / SOPHUS_ENSURE aborts).
 #pragma once
@@ -34,6 +35,7 @@
 #include <opencv2/core.hpp>
 #endif
 #ifdef UW_WITH_EIGEN
+#include <Eigen/Cholesky>
 #include <Eigen/Core>
 #endif
 
@@ -49,6 +51,63 @@ struct SE3 {
   float* data() { return q; }
 };
 static_assert(sizeof(SE3) == 7 * sizeof(float), "SE3 must be 7 packed floats");
+
+namespace detail {
+// The context a default-constructed LS folds on ("LS ls;", src/Tracker.cpp:537): LS::bind(ctx), the first Tracker's
+// context, or — when neither exists — a minimal context created for the reductions alone.
+inline uwt_ctx*& ls_default_ctx() { static uwt_ctx* c = nullptr; return c; }
+inline uwt_ctx* ls_context() {
+  uwt_ctx*& d = ls_default_ctx();
+  if (!d) {   // nothing bound and no tracker yet: a minimal context for the reductions (lives for the process)
+    uwt_params p;
+    int st = uwt_default_params(&p, 64, 48, 64.f, 64.f, 31.5f, 23.5f);
+    if (st == UWT_OK) {
+      p.n_levels = 1; p.first_level = 0; p.last_level = 0; p.max_frames = 2; p.max_pairs = 1;
+      st = uwt_create(&p, &d);
+    }
+    if (st != UWT_OK) throw std::runtime_error(std::string("LS: no context: ") + uwt_status_string(st));
+  }
+  return d;
+}
+}  // namespace detail
+
+// include/Options.h:146-147.  With UW_WITH_EIGEN these ARE the reference's Eigen types; without Eigen, stand-ins with the
+// members the path's code uses (operator(), data(), unary minus, ldlt().solve()).  The stand-in's solve() is the library's
+// 6x6 solve on the GPU (uwt_solve_delta: the LU inverse of the live path, src/Tracker.cpp:564) — no host factorisation.
+#ifdef UW_WITH_EIGEN
+typedef Eigen::Matrix<float, 6, 1> Mat61f;
+typedef Eigen::Matrix<float, 6, 6> Mat66f;
+#else
+struct Mat61f {
+  float v[6] = {0, 0, 0, 0, 0, 0};
+  float& operator()(int i) { return v[i]; }
+  float operator()(int i) const { return v[i]; }
+  float& operator[](int i) { return v[i]; }
+  float operator[](int i) const { return v[i]; }
+  float* data() { return v; }
+  const float* data() const { return v; }
+  Mat61f operator-() const { Mat61f r; for (int i = 0; i < 6; i++) r.v[i] = -v[i]; return r; }
+};
+struct Mat66f {
+  float v[36] = {};   // row-major (A is symmetric: reads the same column-major)
+  float& operator()(int r, int c) { return v[6 * r + c]; }
+  float operator()(int r, int c) const { return v[6 * r + c]; }
+  float& operator[](int i) { return v[i]; }
+  float operator[](int i) const { return v[i]; }
+  float* data() { return v; }
+  const float* data() const { return v; }
+  struct Solver {
+    const Mat66f* A;
+    Mat61f solve(const Mat61f& b) const {
+      Mat61f x;
+      const int st = uwt_solve_delta(detail::ls_context(), A->v, b.v, x.v, nullptr, nullptr);
+      if (st != UWT_OK) throw std::runtime_error(std::string("Mat66f::ldlt().solve: ") + uwt_status_string(st));
+      return x;
+    }
+  };
+  Solver ldlt() const { return Solver{this}; }
+};
+#endif
 
 struct ImageView {
   const void* data = nullptr;
@@ -106,6 +165,7 @@ class Tracker {
   ~Tracker() {
     for (Frame* f : owner_)
       if (f) { f->slot_ = -1; f->tracker_ = nullptr; f->obtained_gradients_ = false; }
+    if (ctx_ && detail::ls_default_ctx() == ctx_) detail::ls_default_ctx() = nullptr;
     if (ctx_) uwt_destroy(ctx_);
   }
   // a frame that goes away (System::FreeFrames, src/System.cpp:352-355) gives its slot back
@@ -152,6 +212,32 @@ class Tracker {
           "uwt_warp");
     return out;
   }
+  // include/Tracker.h:126 (src/Tracker.cpp:599-629): the N x 4 table followed by the patch cells around every point
+  // (patch_size_ = 5, :274).  Its only call in the reference is commented out (:672).
+  std::vector<float> AddPatchPointsFeatures(const std::vector<float>& candidatePoints, int lvl) {
+    const int n = (int)(candidatePoints.size() / 4), cap = n * patch_size_ * patch_size_;
+    std::vector<float> out((size_t)(cap > 0 ? cap : 1) * 4);
+    int32_t count = 0;
+    check(uwt_add_patch_points(ctx(), lvl, candidatePoints.data(), n, patch_size_, out.data(), cap, &count), "uwt_add_patch_points");
+    out.resize((size_t)(count < cap ? count : cap) * 4);
+    return out;
+  }
+  // include/Tracker.h:178 (src/Tracker.cpp:1596-1605): 6 x 1 [w1 w2 w3 x1 x2 x3] -> SE3(SO3::exp(w), x); the translation
+  // is taken as it is (not through V(w)), so the rotation is exp's of the tangent (0, w) and t is copied.
+  SE3 Mat2SE3(const float _input[6]) {
+    const float xi[6] = {0.f, 0.f, 0.f, _input[0], _input[1], _input[2]};
+    SE3 T;
+    check(uwt_se3_exp(ctx(), xi, T.data()), "uwt_se3_exp");
+    T.t[0] = _input[3]; T.t[1] = _input[4]; T.t[2] = _input[5];
+    return T;
+  }
+#ifdef UW_WITH_OPENCV
+  SE3 Mat2SE3(const cv::Mat& _input) {
+    const float v[6] = {_input.at<float>(0, 0), _input.at<float>(1, 0), _input.at<float>(2, 0),
+                        _input.at<float>(3, 0), _input.at<float>(4, 0), _input.at<float>(5, 0)};
+    return Mat2SE3(v);
+  }
+#endif
   // include/Tracker.h:122
   void EstimatePose(Frame* _previous_frame, Frame* _current_frame) {
     const int32_t a = bind(_previous_frame), b = bind(_current_frame);
@@ -288,6 +374,7 @@ class Tracker {
       check(uwt_create(&params_, &ctx_), "uwt_create");
       // the per-frame sequence (upload + pyramid in bind(), ApplyGradient, EstimatePose) waits once, in EstimatePose
       check(uwt_set_deferred(ctx_, 1), "uwt_set_deferred");
+      if (!detail::ls_default_ctx()) detail::ls_default_ctx() = ctx_;   // "LS ls;" inside the tracking loop folds here
     }
     return ctx_;
   }
@@ -328,6 +415,7 @@ class Tracker {
     return slot;
   }
   bool depth_available_;
+  int patch_size_ = 5;                 // src/Tracker.cpp:274
   int max_frames_, device_;
   std::vector<Frame*> owner_;          // slot -> frame holding it
   std::vector<uint64_t> last_use_;
@@ -353,9 +441,12 @@ struct f4 {
 // num_constraints counts 6 per updateSSE call like the reference (:201) unless count_quirk is switched off.
 class LS {
  public:
+  // "LS ls;" as the reference writes it (src/Tracker.cpp:537): folds on the default context (LS::bind / the first Tracker's)
+  LS() : ctx_(nullptr) { initialize(0); }
   explicit LS(uwt_ctx* ctx) : ctx_(ctx) { initialize(0); }
-  float A[36];
-  float b[6];
+  static void bind(uwt_ctx* ctx) { detail::ls_default_ctx() = ctx; }
+  Mat66f A;   // include/LeastSquares.h:34-35 (row-major storage; A is symmetric)
+  Mat61f b;
   float error;
   int num_constraints;
   bool count_quirk = true;
@@ -363,8 +454,8 @@ class LS {
   void initialize(const int /*max_num_constraints*/) {
     J_.clear(); r_.clear(); w_.clear();
     J4_.clear(); r4_.clear(); w4_.clear();
-    std::memset(A, 0, sizeof(A));
-    std::memset(b, 0, sizeof(b));
+    for (int i = 0; i < 36; i++) A.data()[i] = 0.f;
+    for (int i = 0; i < 6; i++) b.data()[i] = 0.f;
     error = 0.f;
     num_constraints = 0;
   }
@@ -373,6 +464,8 @@ class LS {
     r_.push_back(res);
     w_.push_back(weight);
   }
+  // include/LeastSquares.h:40: update(const Mat61f& J, const float& res, const float& weight)
+  void update(const Mat61f& J, const float& res, const float& weight) { update(J.data(), res, weight); }
   // four points at once: J1..J6 hold Jacobian component k of the four points (include/LeastSquares.h:42-43)
   void updateSSE(const f4& J1, const f4& J2, const f4& J3, const f4& J4, const f4& J5, const f4& J6, const f4& res,
                  const f4& weight) {
@@ -392,18 +485,12 @@ class LS {
     updateSSE(a[0], a[1], a[2], a[3], a[4], a[5], a[6], a[7]);
   }
 #endif
-#ifdef UW_WITH_EIGEN
-  // the reference's Mat66f / Mat61f views of A and b (include/LeastSquares.h:34-35): A is symmetric, so the row-major
-  // storage reads the same either way
-  Eigen::Map<Eigen::Matrix<float, 6, 6, Eigen::RowMajor>> A_eigen() { return Eigen::Map<Eigen::Matrix<float, 6, 6, Eigen::RowMajor>>(A); }
-  Eigen::Map<Eigen::Matrix<float, 6, 1>> b_eigen() { return Eigen::Map<Eigen::Matrix<float, 6, 1>>(b); }
-#endif
   void finishNoDivide() { fold(); }
   void finish() {
     fold();
     const float n = (float)num_constraints;   // src/LeastSquares.cpp:141-146
-    for (float& x : A) x /= n;
-    for (float& x : b) x /= n;
+    for (int i = 0; i < 36; i++) A.data()[i] /= n;
+    for (int i = 0; i < 6; i++) b.data()[i] /= n;
     error /= n;
   }
 
@@ -411,18 +498,20 @@ class LS {
   void fold() {
     float A1[36] = {}, b1[6] = {}, e1 = 0.f, A2[36] = {}, b2[6] = {}, e2 = 0.f;
     int32_t n1 = 0, n2 = 0;
-    if (!r_.empty()) chk(uwt_ls_accumulate(ctx_, J_.data(), r_.data(), w_.data(), (int)r_.size(), 0, A1, b1, &e1, &n1), "uwt_ls_accumulate");
+    uwt_ctx* c = context();
+    if (!r_.empty()) chk(uwt_ls_accumulate(c, J_.data(), r_.data(), w_.data(), (int)r_.size(), 0, A1, b1, &e1, &n1), "uwt_ls_accumulate");
     if (!r4_.empty())
-      chk(uwt_ls_accumulate_sse(ctx_, J4_.data(), r4_.data(), w4_.data(), (int)r4_.size(), 0, count_quirk ? 1 : 0, A2, b2, &e2, &n2),
+      chk(uwt_ls_accumulate_sse(c, J4_.data(), r4_.data(), w4_.data(), (int)r4_.size(), 0, count_quirk ? 1 : 0, A2, b2, &e2, &n2),
           "uwt_ls_accumulate_sse");
-    for (int i = 0; i < 36; i++) A[i] = A1[i] + A2[i];
-    for (int i = 0; i < 6; i++) b[i] = b1[i] + b2[i];
+    for (int i = 0; i < 36; i++) A.data()[i] = A1[i] + A2[i];
+    for (int i = 0; i < 6; i++) b.data()[i] = b1[i] + b2[i];
     error = e1 + e2;
     num_constraints = n1 + n2;
   }
   static void chk(int st, const char* what) {
     if (st != UWT_OK) throw std::runtime_error(std::string(what) + ": " + uwt_status_string(st));
   }
+  uwt_ctx* context() { return ctx_ ? ctx_ : detail::ls_context(); }
   uwt_ctx* ctx_;
   std::vector<float> J_, r_, w_, J4_, r4_, w4_;
 };

@@ -268,6 +268,13 @@ int uwt_obtain_candidate_points_batch(uwt_ctx* ctx, int32_t first_slot, int32_t 
 /* Tracker::ObtainPatchesPoints (src/Tracker.cpp:1178-1257): 11x11 level-0 patches around <= 200 key points (x, y). */
 int uwt_obtain_patch_points(uwt_ctx* ctx, int32_t slot, const float* keypoints_xy, int32_t n_keypoints, float* pts_out,
                             int32_t cap, int32_t* count_out);
+/* Tracker::AddPatchPointsFeatures(candidatePoints, lvl) (src/Tracker.cpp:599-629; include/Tracker.h:126; its only call,
+ * :672, is commented out in the reference): the N x 4 table followed, point by point, by the cells of the patch_size x
+ * patch_size patch around each rounded point that lie inside the level (i > 0, j > 0) and are not the centre, with the
+ * point's z and w = 1.  The reference's patch_size_ is 5 (:274).  count_out: the full count (n_pts + cells), of which at
+ * most cap rows are written. */
+int uwt_add_patch_points(uwt_ctx* ctx, int32_t lvl, const float* pts, int32_t n_pts, int32_t patch_size, float* pts_out,
+                         int32_t cap, int32_t* count_out);
 
 /* ---- next to the path: frame ingest ---------------------------------------------------------------- */
 

@@ -341,6 +341,14 @@ def patch_points(kp, depth0, w, h, cap=200 * 144):
     return pts[:min(n, cap)].copy(), n
 
 
+def add_patch_points(pts, w, h, patch_size=5, cap=None):
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 4)
+    cap = pts.shape[0] * patch_size * patch_size if cap is None else cap
+    out = np.empty((max(cap, 1), 4), np.float32)
+    n = lib().uwo_add_patch_points(_p(pts, C.c_float), pts.shape[0], w, h, patch_size, _p(out, C.c_float), cap)
+    return out[:min(n, cap)].copy(), n
+
+
 def candidate_points(mag, depth=None, threshold=20.0):
     mag = np.ascontiguousarray(mag, np.uint8)
     h, w = mag.shape

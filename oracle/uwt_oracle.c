@@ -760,6 +760,27 @@ int uwo_patch_points(const float* kp, int n_kp, const uint16_t* depth0, int w, i
   return n;
 }
 
+/* Tracker::AddPatchPointsFeatures, Tracker.cpp:599-629: clone of the table (:601), then per point the patch cells around
+ * (round(x), round(y)) (:607-608), x outer / y inner (:611-612), strictly inside the level and not the centre (:613), with the
+ * point's z and w = 1 (Mat::ones, :614-617).  start_point = (patch_size_ - 1) / 2 (:602; patch_size_ = 5, :274).
+ * Returns the full count; at most cap rows are written. */
+int uwo_add_patch_points(const float* pts_in, int n, int w, int h, int patch_size, float* pts, int cap) {
+  const int start_point = (patch_size - 1) / 2;
+  int m = 0;
+  for (int q = 0; q < n; q++, m++)
+    if (m < cap) memcpy(pts + 4 * (size_t)m, pts_in + 4 * (size_t)q, 16);
+  for (int q = 0; q < n; q++) {
+    const float x = roundf(pts_in[4 * q]), y = roundf(pts_in[4 * q + 1]), z = pts_in[4 * q + 2];
+    for (int i = (int)(x - (float)start_point); (float)i <= x + (float)start_point; i++)
+      for (int j = (int)(y - (float)start_point); (float)j <= y + (float)start_point; j++)
+        if (i > 0 && i < w && j > 0 && j < h && !((float)i == x && (float)j == y)) {
+          if (m < cap) { pts[4 * m] = (float)i; pts[4 * m + 1] = (float)j; pts[4 * m + 2] = z; pts[4 * m + 3] = 1.0f; }
+          m++;
+        }
+  }
+  return m;
+}
+
 /* Tracker::ObtainCandidatePoints, Tracker.cpp:1314-1398, one level: mask = gradient_ > mean(gradient_) + threshold
  * (cuda::meanStdDev + cuda::threshold THRESH_BINARY, :1324-1329), points pushed x-major (x outer, y inner, :1334-1335),
  * z = 1 without depth.  With depth the reference indexes the 16-bit image through at<uchar> (:1339, :1344): byte x of

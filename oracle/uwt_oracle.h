@@ -164,6 +164,7 @@ int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const u
                              float pose_out[7], uwo_trace* trace, int32_t* n_trace);
 /* Tracker::ObtainPatchesPoints (Tracker.cpp:1178-1257) and ObtainCandidatePoints (:1314-1398, one level) */
 int uwo_patch_points(const float* kp, int n_kp, const uint16_t* depth0_or_null, int w, int h, float* pts, int cap);
+int uwo_add_patch_points(const float* pts_in, int n, int w, int h, int patch_size, float* pts, int cap);  /* Tracker.cpp:599-629 */
 int uwo_candidate_points(const uint8_t* mag, const uint16_t* depth_or_null, int w, int h, double threshold, float* pts, int cap);
 
 /* convenience: level-0 images in, pyramid + gradients + EstimatePose; (the CPU-baseline unit of work) */

@@ -53,6 +53,27 @@ def test_shim_sequence_matches_oracle(O, synth, tmp_path):
     assert np.array_equal(np.array([float(v) for v in ft[:7]], np.float32), pose_f)
     ls = lines["LS"]
     assert float(ls[0]) == 1.0 and float(ls[1]) == -3.0 and float(ls[2]) == 2.0 and int(ls[3]) == 1
+    # the reference's commented "DSO-way" block (src/Tracker.cpp:537-550) compiled as written: LS ls; update(Mat61f, ..);
+    # finish(); A.ldlt().solve(-b) — against the oracle's LS on the same rows
+    Jm = np.array([[np.float32(0.5) * np.float32(((i + 1) * (k + 2) * 7) % 13) - np.float32(2.0) + (np.float32(4.0) if i % 6 == k else np.float32(0.0))
+                    for k in range(6)] for i in range(12)], np.float32)
+    rv = np.array([0.75 - 1.5 * (i % 5) for i in range(12)], np.float32)
+    wv = np.array([1.0 + 0.25 * (i % 5) for i in range(12)], np.float32)
+    o = O.ls_new()
+    for i in range(12):
+        O.ls_update(o, Jm[i], rv[i], wv[i])
+    A, bvec, err, cnt = O.ls_finish(o, divide=True)
+    dso = lines["DSO"]
+    assert int(dso[0]) == cnt == 12 and int(dso[3]) == 1
+    assert np.allclose([float(dso[1]), float(dso[2])], [A[2, 3], bvec[4]], rtol=1e-5, atol=1e-5)
+    # Tracker::Mat2SE3 and Tracker::AddPatchPointsFeatures
+    m2 = np.array([float(v) for v in lines["MAT2SE3"]], np.float32)
+    assert np.array_equal(m2[:4], O.se3_exp(np.array([0, 0, 0, 0.02, -0.01, 0.03], np.float32))[:4])
+    assert np.array_equal(m2[4:], np.array([0.5, -0.25, 0.125], np.float32))
+    tab = np.array([[3.4, 2.6, 0.7, 1.0], [0.2, 0.4, 1.5, 1.0], [40.5, 20.5, 1.1, 1.0]], np.float32)
+    want_pts, n_pts = O.add_patch_points(tab, w // 2, h // 2)
+    ap = lines["ADDPATCH"]
+    assert int(ap[0]) == n_pts and float(ap[1]) == pytest.approx(float(want_pts.astype(np.float64).sum()), rel=1e-6)
     # LS::updateSSE twice + finish(): the oracle's 4-wide LS on the same operands (count quirk: 6 per call)
     o = O.ls_new()
     for call in range(2):

@@ -47,7 +47,7 @@ def test_system_tracking_sequences(O, synth):
     mag = O.gradient_mag(*O.scharr3(ref))
     assert np.array_equal(previous_frame_.candidatePoints_[0], O.candidate_points(mag)[0])
     # LS mirror
-    ls = T.LS(tracker_._ctx)
+    ls = T.LS()                              # default-constructed, as the reference writes it (src/Tracker.cpp:537)
     ls.initialize(4)
     J = rng.normal(0, 5, (4, 6)).astype(np.float32)
     for i in range(4):
@@ -58,6 +58,20 @@ def test_system_tracking_sequences(O, synth):
         O.ls_update(o, J[i], float(i - 1), 0.5)
     A, b, e, n = O.ls_finish(o, True)
     assert ls.num_constraints == n == 4 and np.allclose(ls.A, A, rtol=1e-5, atol=1e-5) and np.allclose(ls.b, b, rtol=1e-5, atol=1e-5)
+    empty = T.LS()
+    empty.finish()                           # LS::finish divides by num_constraints = 0 unconditionally (src/LeastSquares.cpp:141-146)
+    assert empty.num_constraints == 0 and np.isnan(empty.A).all() and np.isnan(empty.b).all()
+    # Tracker::AddPatchPointsFeatures (src/Tracker.cpp:599-629) and Tracker::Mat2SE3 (:1596-1605)
+    tab = np.array([[3.4, 2.6, 0.7, 1.0], [0.2, 0.4, 1.5, 1.0], [w - 1.2, h - 0.6, 0.9, 1.0], [40.5, 20.5, 1.1, 1.0]], np.float32)
+    for lvl in (0, 2):
+        L = tracker_._ctx.level_info(lvl)
+        got = tracker_.AddPatchPointsFeatures(tab, lvl)
+        want, n = O.add_patch_points(tab, L.w, L.h)
+        assert n == len(want) and np.array_equal(got.view(np.uint32), want.view(np.uint32)), lvl
+    assert np.array_equal(got[:4], tab) and len(tracker_.AddPatchPointsFeatures(tab[3:], 0)) == 25
+    v = np.array([0.02, -0.01, 0.03, 0.5, -0.25, 0.125], np.float32)
+    se3 = tracker_.Mat2SE3(v.reshape(6, 1))
+    assert np.array_equal(se3[:4], O.se3_exp(np.array([0, 0, 0, 0.02, -0.01, 0.03], np.float32))[:4]) and np.array_equal(se3[4:], v[3:])
     with pytest.raises(RuntimeError):
         tracker_.EstimatePose(T.Frame(ref), current_frame_)       # ApplyGradient not called on the new frame
     # FastEstimatePose: EstimatePose's terms under the prototype's schedule (4 -> 0, <= 50 iterations, gain 50)

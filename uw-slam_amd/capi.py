@@ -50,7 +50,7 @@ SYMBOLS = [
     "uwt_warp", "uwt_residual_jacobian", "uwt_ls_accumulate", "uwt_se3_exp", "uwt_se3_mul", "uwt_se3_matrix",
     "uwt_se3_handoff", "uwt_solve_delta", "uwt_accumulate_trajectory", "uwt_accumulate_trajectory_scan",
     "uwt_residual_jacobian_weighted", "uwt_estimate_pose_points", "uwt_gradient_magnitude",
-    "uwt_obtain_candidate_points", "uwt_obtain_candidate_points_batch", "uwt_obtain_patch_points",
+    "uwt_obtain_candidate_points", "uwt_obtain_candidate_points_batch", "uwt_obtain_patch_points", "uwt_add_patch_points",
     "uwt_ingest_create", "uwt_ingest_destroy", "uwt_ingest_maps", "uwt_ingest_undistort", "uwt_ingest_calculate_roi",
     "uwt_ingest_frame", "uwt_update_params", "uwt_get_params", "uwt_ls_accumulate_sse", "uwt_robust_weights",
 ]
@@ -478,6 +478,16 @@ class Context:
         self._chk(lib().uwt_obtain_patch_points(self._h, slot, _p(kp, C.c_float), kp.shape[0], _p(pts, C.c_float), cap,
                                                 C.byref(cnt)))
         return pts[:min(cnt.value, cap)].copy(), cnt.value
+
+    def add_patch_points(self, lvl, pts, patch_size=5, cap=None):
+        """Tracker::AddPatchPointsFeatures (src/Tracker.cpp:599-629).  Returns (table, full count)."""
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 4)
+        cap = pts.shape[0] * patch_size * patch_size if cap is None else cap
+        out = np.empty((max(cap, 1), 4), np.float32)
+        cnt = C.c_int32()
+        self._chk(lib().uwt_add_patch_points(self._h, lvl, _p(pts, C.c_float), pts.shape[0], patch_size, _p(out, C.c_float), cap,
+                                             C.byref(cnt)))
+        return out[:min(cnt.value, cap)].copy(), cnt.value
 
     def residual_jacobian_weighted(self, ref_slot, tgt_slot, lvl, pose):
         pose = np.ascontiguousarray(pose, np.float32)

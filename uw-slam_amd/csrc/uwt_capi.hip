@@ -1944,6 +1944,35 @@ int uwt_obtain_patch_points(uwt_ctx* c, int32_t slot, const float* kp, int32_t n
   return UWT_OK;
 }
 
+int uwt_add_patch_points(uwt_ctx* c, int32_t lvl, const float* pts, int32_t n_pts, int32_t patch_size, float* pts_out,
+                         int32_t cap, int32_t* count_out) {
+  if (c) (void)hipSetDevice(c->p.device);
+  if (!c || !count_out || lvl < 0 || lvl >= c->p.n_levels || n_pts < 0 || (n_pts > 0 && !pts) || cap < 0 || (cap > 0 && !pts_out) ||
+      patch_size < 1)
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_add_patch_points");
+  const int start = (patch_size - 1) / 2;   // src/Tracker.cpp:602
+  const size_t in_bytes = (size_t)n_pts * 16, out_bytes = (size_t)cap * 16;
+  int st = ensure_scratch(c, 4096 + in_bytes + out_bytes + 64);
+  if (st) return st;
+  int* d_cnt = (int*)c->scratch;
+  float4* d_in = (float4*)((uint8_t*)c->scratch + 4096);
+  float4* d_out = (float4*)((uint8_t*)c->scratch + 4096 + in_bytes);
+  if (n_pts) HIPCHK(c, hipMemcpyAsync(d_in, pts, in_bytes, hipMemcpyHostToDevice, c->stream));
+  hipLaunchKernelGGL(k_add_patch_points, dim3(1), dim3(256), 0, c->stream, d_in, n_pts, c->lv[lvl].w, c->lv[lvl].h, start, d_out, cap,
+                     d_cnt);
+  HIPCHK(c, hipGetLastError());
+  int cnt = 0;
+  HIPCHK(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  *count_out = cnt;
+  const int m = std::min(cnt, (int)cap);
+  if (m > 0) {
+    HIPCHK(c, hipMemcpyAsync(pts_out, d_out, (size_t)m * 16, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+  }
+  return UWT_OK;
+}
+
 /* ---- frame ingest ------------------------------------------------------------------------------------------------- */
 
 struct uwt_ingest {

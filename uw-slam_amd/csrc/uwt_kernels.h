@@ -2055,6 +2055,52 @@ __global__ __launch_bounds__(256) void k_patch_points(const float2* __restrict__
         }
 }
 
+
+// Tracker::AddPatchPointsFeatures (src/Tracker.cpp:599-629): the table itself, then for every point, in table order, the
+// cells of the (2 * start + 1)^2 patch around its rounded position (x outer, y inner) that lie strictly inside the level
+// (i > 0, j > 0) and are not the centre, each carrying the point's z and w = 1.  One block: chunks of 256 points, the
+// cells of a chunk counted per point and scanned in point order, so that the output order is the reference's push_back order.
+__global__ __launch_bounds__(256) void k_add_patch_points(const float4* __restrict__ pts, int n, int w, int h, int start,
+                                                          float4* __restrict__ out, int cap, int* __restrict__ count) {
+  __shared__ int cnt[256];
+  __shared__ int base;
+  const int q = threadIdx.x;
+  for (int i = q; i < n; i += 256)
+    if (i < cap) out[i] = pts[i];   // candidatePoints.clone() (:601)
+  if (q == 0) base = n;
+  __syncthreads();
+  for (int c0 = 0; c0 < n; c0 += 256) {
+    const int idx = c0 + q;
+    float x = 0.f, y = 0.f, z = 0.f;
+    int k = 0;
+    if (idx < n) {
+      const float4 p = pts[idx];
+      x = roundf(p.x); y = roundf(p.y); z = p.z;   // :607-609
+      for (int i = (int)(x - (float)start); (float)i <= x + (float)start; i++)
+        for (int j = (int)(y - (float)start); (float)j <= y + (float)start; j++)
+          if (i > 0 && i < w && j > 0 && j < h && !((float)i == x && (float)j == y)) k++;
+    }
+    cnt[q] = k;
+    __syncthreads();
+    if (q == 0) {
+      int run = base;
+      for (int i = 0; i < 256; i++) { const int v = cnt[i]; cnt[i] = run; run += v; }
+      base = run;
+    }
+    __syncthreads();
+    int o = cnt[q];
+    if (idx < n)
+      for (int i = (int)(x - (float)start); (float)i <= x + (float)start; i++)
+        for (int j = (int)(y - (float)start); (float)j <= y + (float)start; j++)
+          if (i > 0 && i < w && j > 0 && j < h && !((float)i == x && (float)j == y)) {
+            if (o < cap) out[o] = make_float4((float)i, (float)j, z, 1.0f);   // Mat::ones(1, 4): w = 1 (:614-617)
+            o++;
+          }
+    __syncthreads();
+  }
+  if (q == 0) *count = base;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // frame ingest: cv::remap(raw, undistorted, map1, map2, INTER_LINEAR) + ROI crop of System::AddFrame
 // (src/System.cpp:231-235) fused: each output pixel of the crop window gathers its 2x2 source patch through the

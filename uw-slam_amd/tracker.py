@@ -56,6 +56,8 @@ class Tracker:
         over.update(self._over)
         p = capi.default_params(int(_width), int(_height), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), **over)
         self._ctx = capi.Context(p)
+        if LS._default_ctx is None:
+            LS.bind(self._ctx)                  # `LS ls;` inside the tracking loop folds on the tracker's context
         self._ctx.set_deferred(True)   # one wait per frame, in EstimatePose (pyramids and gradients are enqueued only)
         lv = [self._ctx.level_info(l) for l in range(p.n_levels)]
         self.w_ = [L.w for L in lv]
@@ -145,6 +147,18 @@ class Tracker:
         _previous_frame.candidatePoints_[0] = self._ctx.obtain_patch_points(slot, _previous_frame.keypoints_)[0]
         _previous_frame.obtained_candidatePoints_ = True
 
+    def AddPatchPointsFeatures(self, candidatePoints, lvl, patch_size=5):
+        """src/Tracker.cpp:599-629 (include/Tracker.h:126): the N x 4 table plus the patch cells around every point."""
+        return self._ctx.add_patch_points(lvl, candidatePoints, patch_size)[0]
+
+    def Mat2SE3(self, _input):
+        """src/Tracker.cpp:1596-1605 (include/Tracker.h:178): 6 x 1 [w1 w2 w3 x1 x2 x3] -> SE3(SO3::exp(w), x) — the
+        translation is taken as it is, not through V(w).  Returns qx qy qz qw tx ty tz."""
+        v = np.asarray(_input, np.float32).reshape(6)
+        pose = self._ctx.se3_exp(np.array([0, 0, 0, v[0], v[1], v[2]], np.float32))   # rotation part of exp; V(w) * 0 = 0
+        pose[4:] = v[3:]
+        return pose
+
     def EstimatePoseFeatures(self, _previous_frame, _current_frame):
         """src/Tracker.cpp:632-872 — the reference's live variant (constants :634-640, :834, :856)."""
         a, b = self._bind(_previous_frame), self._bind(_current_frame)
@@ -191,10 +205,26 @@ class LS:
     their products differently, src/LeastSquares.cpp:151-153 vs :205), the two added as finishNoDivide adds the lane sums
     onto A, b, error (:39-139)."""
 
-    def __init__(self, ctx, count_quirk=True):
-        self._ctx = ctx
+    _default_ctx = None                         # the context `LS()` folds on: LS.bind(ctx), else a small one of its own
+
+    @classmethod
+    def bind(cls, ctx):
+        """The context a default-constructed LS uses (the reference writes `LS ls;`, src/Tracker.cpp:537)."""
+        cls._default_ctx = ctx
+
+    def __init__(self, ctx=None, count_quirk=True):
+        self._ctx_arg = ctx
         self.count_quirk = count_quirk          # "num_constraints += 6" per updateSSE call (src/LeastSquares.cpp:201)
         self.initialize(0)
+
+    @property
+    def _ctx(self):
+        if self._ctx_arg is not None:
+            return self._ctx_arg
+        if LS._default_ctx is None:             # nothing bound: a minimal context just for the reductions
+            LS._default_ctx = capi.Context(capi.default_params(64, 48, 64.0, 64.0, 31.5, 23.5, n_levels=1, first_level=0,
+                                                               last_level=0, max_frames=2, max_pairs=1))
+        return LS._default_ctx
 
     def initialize(self, max_num_constraints):
         self._J, self._r, self._w = [], [], []
