@@ -335,6 +335,17 @@ template <int VEC, bool DEPTH, bool UNIT>
 void launch_general_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sampler, int weights) {
   const dim3 grid(a.slices, n_pairs), blk(kBlock);
   const int key = sampler * 3 + weights;
+  if constexpr (VEC == 4 && UNIT) {
+    if (a.L.fx == a.L.fy) {   // SQUARE: the Jacobian's coinciding products once (pixel_jacobian), as on the identity path
+      switch (key) {
+        case 1: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, true, 0, 1>), grid, blk, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, true, 0, 2>), grid, blk, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, true, 1, 0>), grid, blk, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, true, 1, 2>), grid, blk, 0, s, a); break;
+      }
+      return;
+    }
+  }
   switch (key) {
     case 1: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, false, 0, 1>), grid, blk, 0, s, a); break;
     case 2: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, false, 0, 2>), grid, blk, 0, s, a); break;
@@ -349,21 +360,20 @@ int launch_general(uwt_ctx* c, const ResidualArgs& ra, int n_pairs) {
   const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f);
   GeneralArgs ga = general_args(c);
   if (ga.weights) {
-    HIPCHK(c, hipMemsetAsync(c->hist + (size_t)ra.pair_base * kHistBins, 0, sizeof(unsigned int) * kHistBins * n_pairs, c->stream));
+    // the scale pass: residual histograms per pair, the scale derived in the tail of the pair's last block; the histograms
+    // are all-zero before and after (cleared once per alignment call, enqueue_estimate)
     const dim3 grid(ra.slices, n_pairs), blk(kBlock);
     const int hk = (c->vec == 4 ? 4 : 0) | (depth ? 2 : 0) | (ga.sampler ? 1 : 0);
     switch (hk) {
-      case 0: hipLaunchKernelGGL((k_resid_hist_v<1, false, 0>), grid, blk, 0, c->stream, ra, c->hist); break;
-      case 1: hipLaunchKernelGGL((k_resid_hist_v<1, false, 1>), grid, blk, 0, c->stream, ra, c->hist); break;
-      case 2: hipLaunchKernelGGL((k_resid_hist_v<1, true, 0>), grid, blk, 0, c->stream, ra, c->hist); break;
-      case 3: hipLaunchKernelGGL((k_resid_hist_v<1, true, 1>), grid, blk, 0, c->stream, ra, c->hist); break;
-      case 4: hipLaunchKernelGGL((k_resid_hist_v<4, false, 0>), grid, blk, 0, c->stream, ra, c->hist); break;
-      case 5: hipLaunchKernelGGL((k_resid_hist_v<4, false, 1>), grid, blk, 0, c->stream, ra, c->hist); break;
-      case 6: hipLaunchKernelGGL((k_resid_hist_v<4, true, 0>), grid, blk, 0, c->stream, ra, c->hist); break;
-      default: hipLaunchKernelGGL((k_resid_hist_v<4, true, 1>), grid, blk, 0, c->stream, ra, c->hist); break;
+      case 0: hipLaunchKernelGGL((k_resid_hist_v<1, false, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 1: hipLaunchKernelGGL((k_resid_hist_v<1, false, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 2: hipLaunchKernelGGL((k_resid_hist_v<1, true, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 3: hipLaunchKernelGGL((k_resid_hist_v<1, true, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 4: hipLaunchKernelGGL((k_resid_hist_v<4, false, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 5: hipLaunchKernelGGL((k_resid_hist_v<4, false, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 6: hipLaunchKernelGGL((k_resid_hist_v<4, true, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      default: hipLaunchKernelGGL((k_resid_hist_v<4, true, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
     }
-    HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_scale_stage, dim3((n_pairs + 3) / 4), dim3(256), 0, c->stream, ga, ra.state, n_pairs, ra.pair_base);
     HIPCHK(c, hipGetLastError());
   }
   const int key = (c->vec == 4 ? 4 : 0) | (depth ? 2 : 0) | (unit ? 1 : 0);
@@ -621,6 +631,10 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
     slicing(lvl, gpb, sl);
     smax = std::max(smax, sl);
   }
+  // robust weights: the per-pair residual histograms (and the ticket word of each) start an alignment all-zero; every scale
+  // pass leaves them so (k_resid_hist_v)
+  if (general && p.weights)
+    HIPCHK(c, hipMemsetAsync(c->hist, 0, sizeof(unsigned int) * kHistBins * n_pairs, c->stream));
   // the schedule for pairs [base, base + cnt) of a batch of n_pairs, on c->stream
   auto run = [&](int base, int cnt) -> int {
     hipLaunchKernelGGL(k_init_state, dim3((cnt + tb - 1) / tb), dim3(tb), 0, c->stream, c->state + base, cnt, p.initial_error);

@@ -582,6 +582,30 @@ __device__ __forceinline__ void accumulate_weighted(AccT acc[kAccFloats], AccT& 
   for (int i = 0; i < 6; i++) acc[21 + i] = (AccT)__builtin_fma(Jd[i], (double)rw, (double)acc[21 + i]);
 }
 
+// the same sums from a row that has been weighted already: wJ[k] = w * J[k] (f32), rwd = (double)((r * gain) * w)
+__device__ __forceinline__ void accumulate_preweighted(double acc[kAccFloats], const float wJ[6], double rwd) {
+  double Jd[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) Jd[k] = (double)wJ[k];
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++, s++) acc[s] = __builtin_fma(Jd[i], Jd[j], acc[s]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) acc[21 + i] = __builtin_fma(Jd[i], rwd, acc[21 + i]);
+}
+__device__ __forceinline__ void accumulate_preweighted(float acc[kAccFloats], const float wJ[6], double rwd) {
+  const float rw = (float)rwd;   // exact: rwd was converted from this float
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = i; j < 6; j++, s++) acc[s] = (float)__builtin_fma((double)wJ[i], (double)wJ[j], (double)acc[s]);
+#pragma unroll
+  for (int i = 0; i < 6; i++) acc[21 + i] = (float)__builtin_fma((double)wJ[i], (double)rw, (double)acc[21 + i]);
+}
+
 #ifdef UWT_EXP_STAMPS
 __device__ uint32_t g_exp_stamps[16];
 #define EXP_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_exp_stamps[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
@@ -717,6 +741,34 @@ __device__ __forceinline__ float robust_weight(int mode, float rf, float inv_mad
   return 1.0f;
 }
 
+// With the nearest-neighbour sampler a residual is an integer in [-255, 255], so everything the weighted accumulation
+// derives from (r, scale) alone takes at most 511 values per pair and evaluation: the weight w(r), the gained and weighted
+// residual (r * gain) * w that multiplies wJ (src/Tracker.cpp:559-561) and the error term r * (r * w) (:499-502).  A block
+// evaluates them once per value into LDS (the same float sequence as the per-pixel form: robust_weight on (float)r, then
+// the two products) and every pixel reads its entry — one 16-byte and one 8-byte LDS read in place of a float division
+// (Huber) or two f64 operations (Tukey), two multiplies and three conversions.  The table occupies the bytes of the block
+// reduction's image, which is not live before the loop ends.
+struct WeightEntry {
+  double rwd;    // (double)((r * gain) * w)
+  double e;      // (double)r * (double)(r * w): the pixel's term of the error numerator (exact product)
+  float w;       // robust weight of this residual value
+  float pad[3];
+};
+static_assert(sizeof(WeightEntry) == 32, "one ds_read_b32 (w) and, later, one ds_read_b128 (rwd, e) per pixel");
+constexpr int kWeightTabBytes = 511 * (int)sizeof(WeightEntry);
+
+__device__ __forceinline__ void fill_weight_table(WeightEntry* __restrict__ tab, int mode, float inv_mad, float gain) {
+  for (int i = threadIdx.x; i < 511; i += kBlock) {
+    const float rf = (float)(i - 255);
+    const float w = robust_weight(mode, rf, inv_mad);
+    const float rw1 = rf * w;
+    WeightEntry t;
+    t.w = w; t.pad[0] = t.pad[1] = t.pad[2] = 0.f;
+    t.rwd = (double)((rf * gain) * w);
+    t.e = (double)rf * (double)rw1;
+    tab[i] = t;
+  }
+}
 
 // Tracker::MedianMat / MedianAbsoluteDeviation / IdentityWeights / TukeyFunctionWeights on an explicit N x 1 residual
 // vector (src/Tracker.cpp:1571-1654).  One block: a 256-bin LDS histogram of the saturated, rounded values gives the
@@ -893,6 +945,15 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   AccT err = (AccT)0;                                      // Σ r·(r·w), the error numerator on the general path
   float inv_mad = 1.f;
   if constexpr (WEIGHTS != 0) inv_mad = a.scale[pair].inv_mad;
+  // robust weights over integer residuals: the per-value table (see WeightEntry) in the bytes of the reduction's image
+  constexpr bool TABLE = WEIGHTS != 0 && SAMPLER == 0;
+  static_assert(!TABLE || EXT_LDS == 0, "the weighted path reduces in its own LDS");
+  __shared__ __attribute__((aligned(16))) unsigned char tlds[TABLE ? kReduceLdsBytes : 16];
+  static_assert(!TABLE || kWeightTabBytes <= kReduceLdsBytes, "table fits the reduction image");
+  if constexpr (TABLE) {
+    fill_weight_table(reinterpret_cast<WeightEntry*>(tlds), WEIGHTS, inv_mad, a.gain);
+    __syncthreads();
+  }
 
   const int n_groups = L.n / VEC;
   const int g_begin = slice * a.groups_per_block;
@@ -981,6 +1042,36 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
       pixel_jacobian<UNIT_FACTORS, SQUARE, DUMP, F>(L, a.zf, a.af, x2[u], y2[u], iz[u], g0[u], g1[u], J[u]);
     __builtin_amdgcn_sched_barrier(0);
     // phase 4: residuals and accumulation
+    if constexpr (TABLE) {
+      // weights from the per-value table; J <- w * J over packed pairs (src/Tracker.cpp:554-557)
+      // (one packed unit at a time, the table offset computed once per pixel: short live ranges keep the kernel at 4 waves / SIMD)
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+        uint32_t off[N];
+        F wv;
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+          const int j = u * N + c;
+          const int ri = keep_i(i2[j] - (int)i1[j], okm[j]);
+          sum_r2 += (uint32_t)__mul24(ri, ri);
+          n_valid_wave += (uint32_t)__builtin_popcountll(okm[j]);
+          off[c] = (uint32_t)(ri + 255) * (uint32_t)sizeof(WeightEntry);
+          put(wv, c, *reinterpret_cast<const float*>(tlds + off[c] + 16));
+        }
+#pragma unroll
+        for (int k = 0; k < 6; k++) J[u][k] = wv * J[u][k];
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+          float Jp[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) Jp[k] = get(J[u][k], c);
+          const double2 re = *reinterpret_cast<const double2*>(tlds + off[c]);   // rwd, e
+          err += (AccT)re.y;
+          accumulate_preweighted(acc, Jp, re.x);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       float Jp[6];
@@ -1010,6 +1101,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
         }
       }
     }
+    }
     xf0 += step_xf;
     yf += step_yf;
     const bool wrap = xf0 >= wf;
@@ -1022,7 +1114,10 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   if (threadIdx.x == 0) out_rec[62] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
   if constexpr (EXT_LDS != 0) block_reduce_store_at<AccT, GENERAL, EXT_LDS>(lds, acc, sum_r2, n_valid, out_rec, err);   // the caller's bytes: k_iterate
-  else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err);
+  else if constexpr (TABLE) {
+    __syncthreads();   // every wave has read its last table entry: the bytes become the reduction's image
+    block_reduce_store_at<AccT, true>(tlds, acc, sum_r2, n_valid, out_rec, err);
+  } else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err);
   if (a.probe && threadIdx.x == 0) {
     uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
     rec[60] = (uint32_t)(__builtin_amdgcn_s_memtime() - clk0);
@@ -1107,94 +1202,6 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist(const ResidualArgs a, con
     if (h[i]) atomicAdd(&gh[i], h[i]);
 }
 
-// Vector form used by the alignment loop: same group walk as residual_block (VEC pixels per step, planes prefetched),
-// and kHistRep lane-interleaved replicas of the LDS histogram — residuals pile up around 0, and same-address LDS
-// atomics of one wave serialise.
-constexpr int kHistRep = 8;
-
-template <int VEC, bool DEPTH, int SAMPLER>
-__global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, unsigned int* __restrict__ hist) {
-  const int pair = blockIdx.y + a.pair_base;
-  const PairState st = a.state[pair];
-  if (st.level_done || st.status) return;
-  __shared__ unsigned int h[kHistRep][kHistBins];
-  for (int i = threadIdx.x; i < kHistRep * kHistBins; i += kBlock) (&h[0][0])[i] = 0;
-  __syncthreads();
-  WarpK K;
-  pose_to_T12(st.pose, K.T);
-#pragma unroll
-  for (int i = 0; i < 12; i++) K.T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(K.T[i])));
-  const LevelK L = a.L;
-  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
-  const uint8_t* __restrict__ I1 = a.img + ref_off;
-  const uint8_t* __restrict__ I2 = a.img + tgt_off;
-  const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
-  unsigned int* myh = h[threadIdx.x & (kHistRep - 1)];
-  const int n_groups = L.n / VEC;
-  const int g_begin = blockIdx.x * a.groups_per_block, g_end = min(g_begin + a.groups_per_block, n_groups);
-  for (int g = g_begin + (int)threadIdx.x; g < g_end; g += kBlock) {
-    const uint32_t idx = (uint32_t)g * VEC;
-    const uint32_t y = __umulhi(idx, L.magic), x = idx - y * L.w;
-    uint8_t i1[VEC];
-    uint16_t dp[VEC];
-    if constexpr (VEC == 4) {
-      *reinterpret_cast<uint32_t*>(i1) = *reinterpret_cast<const uint32_t*>(I1 + idx);
-      if constexpr (DEPTH) *reinterpret_cast<uint2*>(dp) = *reinterpret_cast<const uint2*>(DP + idx);
-    } else {
-      i1[0] = I1[idx];
-      if constexpr (DEPTH) dp[0] = DP[idx];
-    }
-    // pairs of adjacent pixels through the packed float sequence (see v2f), as in the accumulation kernel
-    constexpr int N = (VEC % 2 == 0) ? 2 : 1;
-    using F = typename std::conditional<N == 2, v2f, float>::type;
-    float x2[VEC], y2[VEC];
-    bool ok[VEC];
-    uint32_t gidx[VEC];
-#pragma unroll
-    for (int u = 0; u < VEC / N; u++) {
-      F z = bc<F>(1.0f), xf, x2u, y2u, izu;
-      unsigned long long okin_m[N], okm[N];
-#pragma unroll
-      for (int c = 0; c < N; c++) {
-        const int j = u * N + c;
-        bool okin = true;
-        if constexpr (DEPTH) {
-          const int d = (int)(int16_t)dp[j];
-          okin = d > 0;
-          put(z, c, (float)d);
-        }
-        okin_m[c] = __builtin_amdgcn_ballot_w64(okin);
-        put(xf, c, (float)x + (float)j);
-      }
-      if constexpr (DEPTH) z = z * bc<F>(L.zscale);
-      pixel_warp<F>(L, K, xf, bc<F>((float)y), z, okin_m, x2u, y2u, izu, okm, &gidx[u * N]);
-#pragma unroll
-      for (int c = 0; c < N; c++) {
-        x2[u * N + c] = get(x2u, c);
-        y2[u * N + c] = get(y2u, c);
-        ok[u * N + c] = lane_bit(okm[c]);
-      }
-    }
-    float rf[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; j++) {
-      if constexpr (SAMPLER == 0) rf[j] = (float)((int)I2[gidx[j]] - (int)i1[j]);
-      else rf[j] = sample_bilinear(I2, L, x2[j], y2[j]) - (float)i1[j];
-    }
-#pragma unroll
-    for (int j = 0; j < VEC; j++)
-      if (ok[j]) atomicAdd(&myh[(int)rintf(rf[j]) + 255], 1u);
-  }
-  __syncthreads();
-  unsigned int* gh = hist + (size_t)pair * kHistBins;
-  for (int i = threadIdx.x; i < kHistBins; i += kBlock) {
-    unsigned int t = 0;
-#pragma unroll
-    for (int r = 0; r < kHistRep; r++) t += h[r][i];
-    if (t) atomicAdd(&gh[i], t);
-  }
-}
-
 // Scale from the signed residual histogram alone (residuals are integers, or are binned by their rounded value):
 //   median by the reference's rule (MedianMat, src/Tracker.cpp:1575-1591: first bin whose cumulative count exceeds
 //   (float)(n / 2)); the reference Tukey saturates negatives to 0 first (:1572-1573), Huber keeps the sign;
@@ -1225,23 +1232,13 @@ __device__ __forceinline__ int first_crossing(const unsigned int v[8], float m, 
   return idx;   // 0x7fffffff: no bin crosses
 }
 
-__global__ __launch_bounds__(256) void k_scale_stage(const GeneralArgs ga, const PairState* state, int n_pairs, int pair_base) {
-  __shared__ unsigned int sh[4][kHistBins];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 4 + wave;
-  if (i >= n_pairs) return;
-  const int pair = i + pair_base;
-  const PairState st = state[pair];
-  if (st.level_done || st.status) return;
-  const unsigned int* gh = ga.hist + (size_t)pair * kHistBins;
-  unsigned int* h = sh[wave];
-  const bool tukey = ga.weights == kWeightsTukeyRef;
-  unsigned int mine[8], n = 0;
+// one wave: the pair's scale from its 511 signed bins; lane l holds bins 8l .. 8l+7 in `mine`, `h` is a 512-word LDS
+// scratch of this wave
+__device__ __forceinline__ PairScale wave_scale(const unsigned int mine[8], unsigned int* __restrict__ h, bool tukey, int lane) {
+  unsigned int n = 0;
 #pragma unroll
   for (int k = 0; k < 8; k++) {
-    const int b = lane * 8 + k;
-    mine[k] = b < 511 ? gh[b] : 0u;
-    h[b] = mine[k];
+    h[lane * 8 + k] = mine[k];
     n += mine[k];
   }
   __builtin_amdgcn_wave_barrier();   // h is written and read by this wave alone (LDS operations of a wave stay in order)
@@ -1292,16 +1289,199 @@ __global__ __launch_bounds__(256) void k_scale_stage(const GeneralArgs ga, const
     const int idx = first_crossing(v, m, lane);
     dmed = idx == 0x7fffffff ? dmax : idx;
   }
-  if (lane == 0) {
-    PairScale sc;
-    sc.med0 = (float)med;
-    sc.n_valid = (int)n;
-    sc.pad = 0;
-    float mad = 1.4826f * (float)dmed;
-    if (!n || mad == 0.f) mad = 1.f;
-    sc.inv_mad = (float)(1.0 / (double)mad);
-    ga.scale[pair] = sc;
+  PairScale sc;
+  sc.med0 = (float)med;
+  sc.n_valid = (int)n;
+  sc.pad = 0;
+  float mad = 1.4826f * (float)dmed;
+  if (!n || mad == 0.f) mad = 1.f;
+  sc.inv_mad = (float)(1.0 / (double)mad);
+  return sc;
+}
+
+__global__ __launch_bounds__(256) void k_scale_stage(const GeneralArgs ga, const PairState* state, int n_pairs, int pair_base) {
+  __shared__ unsigned int sh[4][kHistBins];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= n_pairs) return;
+  const int pair = i + pair_base;
+  const PairState st = state[pair];
+  if (st.level_done || st.status) return;
+  const unsigned int* gh = ga.hist + (size_t)pair * kHistBins;
+  unsigned int mine[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int b = lane * 8 + k;
+    mine[k] = b < 511 ? gh[b] : 0u;
   }
+  const PairScale sc = wave_scale(mine, sh[wave], ga.weights == kWeightsTukeyRef, lane);
+  if (lane == 0) ga.scale[pair] = sc;
+}
+
+// Vector form used by the alignment loop: same group walk as residual_block (VEC pixels per step), and kHistRep
+// replicas of the LDS histogram interleaved by bin (word = bin * kHistRep + replica): residuals pile up around 0,
+// same-address LDS atomics of one wave serialise, and the replicas of the crowded bins spread over the banks.
+//
+// The scale stage rides in the tail (round 3: no launch of its own, no per-evaluation clearing of the histograms): every
+// block adds its counts to the pair's global bins, then takes a ticket from the pair's counter (word 511 of its
+// histogram, which has 511 bins); the block that draws the last ticket reads-and-clears the bins (atomic exchange — the
+// counts of the other blocks, made on other XCDs, are at the device's coherence point, not in this XCD's L2), derives the
+// scale (wave_scale) and clears the counter.  The histograms are therefore all-zero between evaluations; the context
+// clears them once per alignment call.
+constexpr int kHistRep = 8;
+constexpr int kHistTicketWord = kHistBins - 1;
+
+template <int VEC, bool DEPTH, int SAMPLER>
+__global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, unsigned int* __restrict__ hist, PairScale* __restrict__ scale_out,
+                                                         int weights) {
+  const int pair = blockIdx.y + a.pair_base;
+  const PairState st = a.state[pair];
+  if (st.level_done || st.status) return;
+  __shared__ unsigned int h[kHistBins * kHistRep];
+  __shared__ int s_last;
+  for (int i = threadIdx.x; i < kHistRep * kHistBins; i += kBlock) h[i] = 0;
+  __syncthreads();
+  WarpK K;
+  pose_to_T12(st.pose, K.T);
+#pragma unroll
+  for (int i = 0; i < 12; i++) K.T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(K.T[i])));
+  const LevelK L = a.L;
+  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
+  const uint8_t* __restrict__ I1 = a.img + ref_off;
+  const uint8_t* __restrict__ I2 = a.img + tgt_off;
+  const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
+  // bin q of this thread's replica: myh[q * kHistRep]; an invalid pixel counts into the unused 512th bin (no branch)
+  unsigned int* myh = h + 255 * kHistRep + (threadIdx.x & (kHistRep - 1));
+  constexpr int kTrash = (kHistBins - 1) - 255;
+  const int n_groups = L.n / VEC;
+  const int g_begin = blockIdx.x * a.groups_per_block, g_end = min(g_begin + a.groups_per_block, n_groups);
+  // the planes of a thread's next group are requested behind this group's gathers, as in residual_core
+  uint8_t i1n[VEC];
+  uint16_t dpn[VEC];
+  auto load_planes = [&](int g) {
+    const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
+    if constexpr (VEC == 4) {
+      *reinterpret_cast<uint32_t*>(i1n) = *reinterpret_cast<const uint32_t*>(I1 + idx);
+      if constexpr (DEPTH) *reinterpret_cast<uint2*>(dpn) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(DP) + idx * 2u);
+    } else {
+      i1n[0] = I1[idx];
+      if constexpr (DEPTH) dpn[0] = DP[idx];
+    }
+  };
+  load_planes(g_begin + (int)threadIdx.x);
+#ifdef UWT_EXP_HIST_NOATOMIC
+  unsigned exp_sink = 0;
+#endif
+  for (int g = g_begin + (int)threadIdx.x; g < g_end; g += kBlock) {
+    const uint32_t idx = (uint32_t)g * VEC;
+    const uint32_t y = __umulhi(idx, L.magic), x = idx - y * L.w;
+    uint8_t i1[VEC];
+    uint16_t dp[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) { i1[j] = i1n[j]; if constexpr (DEPTH) dp[j] = dpn[j]; }
+    // pairs of adjacent pixels through the packed float sequence (see v2f), as in the accumulation kernel
+    constexpr int N = (VEC % 2 == 0) ? 2 : 1;
+    using F = typename std::conditional<N == 2, v2f, float>::type;
+    float x2[VEC], y2[VEC];
+    unsigned long long okv[VEC];
+    uint32_t gidx[VEC];
+#pragma unroll
+    for (int u = 0; u < VEC / N; u++) {
+      F z = bc<F>(1.0f), xf, x2u, y2u, izu;
+      unsigned long long okin_m[N], okm[N];
+#pragma unroll
+      for (int c = 0; c < N; c++) {
+        const int j = u * N + c;
+        okin_m[c] = ~0ull;
+        if constexpr (DEPTH) {
+          const int d = (int)(int16_t)dp[j];
+          okin_m[c] = __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
+          put(z, c, (float)d);
+        }
+        put(xf, c, (float)x + (float)j);
+      }
+      if constexpr (DEPTH) z = z * bc<F>(L.zscale);
+      // the reciprocal's clamp and its select are of no use here: only x2, y2 (the sample position) are read
+      pixel_warp_raw<F>(L, K, xf, bc<F>((float)y), z, okin_m, x2u, y2u, izu, okm);
+#pragma unroll
+      for (int c = 0; c < N; c++) {
+        put(x2u, c, keep_f(get(x2u, c), okm[c]));
+        put(y2u, c, keep_f(get(y2u, c), okm[c]));
+      }
+      pixel_gather_index<F>(L, x2u, y2u, &gidx[u * N]);
+#pragma unroll
+      for (int c = 0; c < N; c++) {
+        x2[u * N + c] = get(x2u, c);
+        y2[u * N + c] = get(y2u, c);
+        okv[u * N + c] = okm[c];
+      }
+    }
+    if constexpr (SAMPLER == 0) {
+      int q[VEC];
+#pragma unroll
+#ifdef UWT_EXP_HIST_NOGATHER
+      for (int j = 0; j < VEC; j++) q[j] = (int)(gidx[j] & 255u);
+#else
+      for (int j = 0; j < VEC; j++) q[j] = (int)I2[gidx[j]];
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+      load_planes(g + kBlock);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        int b = q[j] - (int)i1[j];
+        asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(b) : "v"(kTrash), "s"(okv[j]));   // valid ? r : the spare bin
+#ifdef UWT_EXP_HIST_NOATOMIC
+        exp_sink += (unsigned)b;
+#else
+        atomicAdd(&myh[b * kHistRep], 1u);
+#endif
+      }
+    } else {
+      float rf[VEC];
+#pragma unroll
+      for (int j = 0; j < VEC; j++) rf[j] = sample_bilinear(I2, L, x2[j], y2[j]) - (float)i1[j];
+      __builtin_amdgcn_sched_barrier(0);
+      load_planes(g + kBlock);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < VEC; j++) {
+        int b = (int)rintf(rf[j]);
+        asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(b) : "v"(kTrash), "s"(okv[j]));
+        atomicAdd(&myh[b * kHistRep], 1u);
+      }
+    }
+  }
+#ifdef UWT_EXP_HIST_NOATOMIC
+  atomicAdd(&h[(exp_sink & 255u) * kHistRep], 1u);
+#endif
+  __syncthreads();
+  unsigned int* gh = hist + (size_t)pair * kHistBins;
+  // This block's counts must be performed (at the device's coherence point, where atomics execute) before its ticket is
+  // drawn.  No fence: a release fence writes back the XCD's whole L2 (and 256 threads issuing one each took the scale
+  // pass from 41 to 265 us per launch) — instead the adds RETURN their old values, which come from the coherence point, so
+  // a thread that holds them has its adds performed; the barrier collects all threads.
+  unsigned int seen = 0;
+  for (int i = threadIdx.x; i < kHistBins - 1; i += kBlock) {
+    const uint4 lo = *reinterpret_cast<const uint4*>(&h[i * kHistRep]), hi = *reinterpret_cast<const uint4*>(&h[i * kHistRep + 4]);
+    const unsigned int t = lo.x + lo.y + lo.z + lo.w + hi.x + hi.y + hi.z + hi.w;
+    if (t) seen |= atomicAdd(&gh[i], t);
+  }
+  if (seen == 0xffffffffu) s_last = 0;   // (never true: a use the compiler cannot drop, so the returns are waited for)
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&gh[kHistTicketWord], 1u) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (!s_last || threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  unsigned int mine[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int b = lane * 8 + k;
+    mine[k] = b < 511 ? atomicExch(&gh[b], 0u) : 0u;   // read at the coherence point, leave the bin cleared
+  }
+  if (lane == 0) atomicExch(&gh[kHistTicketWord], 0u);
+  const PairScale sc = wave_scale(mine, h, weights == kWeightsTukeyRef, lane);   // (h: every wave of the block is past its flush)
+  if (lane == 0) scale_out[pair] = sc;
 }
 
 // weighted / bilinear accumulation: J <- w·J, r <- gain·r, A = Σ(wJ)(wJ)ᵀ, jtr = Σ(wJ)·((gain r)·w) (src/Tracker.cpp:554-561),
