@@ -48,7 +48,11 @@ def parse_args(argv=None):
                     help="resident frame pairs per GPU (BASELINE config 4: 8192 pairs over 8 GPUs = 1024 per GPU); weak scaling")
     ap.add_argument("--total-pairs", type=int, default=0,
                     help="total pairs of the job, split round-robin over the GPUs (strong scaling); overrides --pairs")
-    ap.add_argument("--unique", type=int, default=32, help="distinct synthetic pairs generated per rank (tiled to its shard)")
+    ap.add_argument("--unique", type=int, default=128, help="distinct synthetic pairs generated per rank (tiled to its shard); "
+                    "every one of them is checked against the CPU oracle after the timed region")
+    ap.add_argument("--generator", choices=["cpp", "numpy"], default="cpp",
+                    help="cpp: the deterministic C++ generator shared with tools/uwt_bench (tools/uwt_gen.h through "
+                         "tools/libuwt_gen.so; SURVEY.md §8d); numpy: uw-slam_amd/synth.py")
     ap.add_argument("--width", type=int, default=640)
     ap.add_argument("--height", type=int, default=480)
     ap.add_argument("--levels", type=int, default=4)
@@ -211,10 +215,14 @@ def main(args):
 
     U = min(args.unique, P)
     refs, tgts, deps = [], [], []
+    gen = _cpp_generator() if args.generator == "cpp" else None
     for u in range(U):
         gid = int(my_pairs[u])
-        ref, tgt, dep, _, _ = synth.render_pair(w, h, *intr, seed=gid, z=0.8 + 0.4 * ((gid * 7) % 11) / 10.0,
-                                                with_depth=bool(has_depth))
+        if gen is not None:                                 # same pair ids -> same inputs as tools/uwt_bench
+            ref, tgt, dep = gen(w, h, intr, gid, bool(has_depth))
+        else:
+            ref, tgt, dep, _, _ = synth.render_pair(w, h, *intr, seed=gid, z=0.8 + 0.4 * ((gid * 7) % 11) / 10.0,
+                                                    with_depth=bool(has_depth))
         refs.append(ref); tgts.append(tgt); deps.append(dep)
     idx = np.arange(P) % U
     frames = np.empty((2 * P, h, w), np.uint8)
@@ -273,6 +281,7 @@ def main(args):
     # floor).  Each is preceded by untimed steps of the same kind: the chip holds a lower clock for the first
     # milliseconds after the pause of the copy above, and the durations should be those of the sustained state.
     res_ms = res_launches = res_pixels = 0
+    res_levels = []
     co_ms = 0.0
     clock_ghz = 0.0
     if not args.no_profile:
@@ -282,6 +291,7 @@ def main(args):
         step()
         fence()
         res_ms, res_launches, res_pixels = ctx.profile_read()
+        res_levels = ctx.profile_read_levels()
         clock_ghz = ctx.profile_clock()
         if not (args.bilinear or args.weights != "identity" or args.acc != "f64"):
             ctx.profile_enable(2)                           # compute-only, no events: re-heat in this mode
@@ -319,7 +329,7 @@ def main(args):
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32",
-        "data": "synthetic",
+        "data": "synthetic (%s)" % ("deterministic C++ generator tools/uwt_gen.h, shared with tools/uwt_bench" if args.generator == "cpp" else "uw-slam_amd/synth.py"),
         "config": {
             "workload": ("synthetic %dx%d pairs, %s, "
                          "dense points%s, %d pairs in total, %d resident on rank 0 (%d distinct), image pyramids of both frames + depth pyramid and gradients of the reference frame + alignment per step"
@@ -364,6 +374,12 @@ def main(args):
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "frac_of_measured_copy_peak": round(achieved / HBM_COPY_GBS, 4),
+                # the same launches on the bytes the PMC counters see (u16 depth instead of the f32 z the 10 B assume)
+                "frac_counter_bytes": round(achieved * traffic_px / ALG_BYTES_PER_PIXEL_ITER / HBM_PEAK_GBS, 4) if traffic_px else None,
+                "counter_bytes_per_pixel_iteration": traffic_px,
+                "per_level": [{"level": l, "launches": int(n), "avg_launch_ms": round(ms / n, 5),
+                               "algorithmic_GBs": round(ALG_BYTES_PER_PIXEL_ITER * P * (w >> l) * (h >> l) / (ms / n * 1e-3) / 1e9, 1)}
+                              for l, (ms, n) in enumerate(res_levels) if n],
                 "traffic": int(traffic_px * res_pixels / res_launches) if traffic_px else None,
                 "traffic_source": facts.get("hbm_bytes_source") if traffic_px else None,
                 "launches": int(res_launches), "avg_launch_ms": round(res_ms / res_launches, 5),
@@ -394,21 +410,10 @@ def main(args):
             po = O.default_params(w, h, *intr, **{k: v for k, v in over.items() if k != "accumulate_f64"})
             n_cpu = args.cpu_pairs                  # cycles over the U distinct pairs
             t0 = time.perf_counter()
-            cpu_poses = []
             for k in range(n_cpu):
                 u = k % U
-                st, pose, _ = O.align_pair(po, refs[u], tgts[u], deps[u] if has_depth else None)
-                if k < U:
-                    cpu_poses.append(pose)
+                O.align_pair(po, refs[u], tgts[u], deps[u] if has_depth else None)
             t_cpu = time.perf_counter() - t0
-            dr, dtr, bit = [], [], 0
-            for u in range(len(cpu_poses)):
-                a, b = gpu_poses[u].astype(np.float64), cpu_poses[u].astype(np.float64)
-                wv = abs(float(np.dot(a[:4], b[:4])))
-                v = b[3] * a[:3] - a[3] * b[:3] - np.cross(a[:3], b[:3])
-                dr.append(2.0 * np.arctan2(np.linalg.norm(v), wv))
-                dtr.append(float(np.linalg.norm(a[4:] - b[4:])))
-                bit += int(np.array_equal(gpu_poses[u].view(np.uint32), cpu_poses[u].view(np.uint32)))
             out["cpu_baseline"] = {
                 "value": round(n_cpu / t_cpu, 4), "unit": "alignments/s", "cores": 1, "kind": "port",
                 "sample": "%d alignments over the batch's %d distinct pairs through oracle/uwt_oracle.c "
@@ -420,12 +425,21 @@ def main(args):
             cores = max(1, min(cores, 64))                  # a thread pool of ctypes calls stops scaling well before that
             def _one(k):
                 u = k % U
-                return O.align_pair(po, refs[u], tgts[u], deps[u] if has_depth else None)[0]
-            n_mt = cores * 8
+                return O.align_pair(po, refs[u], tgts[u], deps[u] if has_depth else None)[1]
+            n_mt = max(cores * 8, U)                        # covers every distinct pair: the parity leg below checks them all
             t0 = time.perf_counter()
             with ThreadPoolExecutor(cores) as ex:
-                list(ex.map(_one, range(n_mt)))
+                mt_poses = list(ex.map(_one, range(n_mt)))
             t_mt = time.perf_counter() - t0
+            cpu_poses = [mt_poses[u] for u in range(U)]
+            dr, dtr, bit = [], [], 0
+            for u in range(U):
+                a, b = gpu_poses[u].astype(np.float64), cpu_poses[u].astype(np.float64)
+                wv = abs(float(np.dot(a[:4], b[:4])))
+                v = b[3] * a[:3] - a[3] * b[:3] - np.cross(a[:3], b[:3])
+                dr.append(2.0 * np.arctan2(np.linalg.norm(v), wv))
+                dtr.append(float(np.linalg.norm(a[4:] - b[4:])))
+                bit += int(np.array_equal(gpu_poses[u].view(np.uint32), cpu_poses[u].view(np.uint32)))
             out["cpu_baseline_all_cores"] = {"value": round(n_mt / t_mt, 4), "unit": "alignments/s", "cores": cores,
                                              "kind": "port", "sample": "%d alignments, thread pool, %.1f s" % (n_mt, t_mt)}
             # every resident pair repeats one of the U distinct inputs: all P poses are covered by comparing each with its original
@@ -439,6 +453,29 @@ def main(args):
     ctx.close()
     if use_dist:
         dist.destroy_process_group()
+
+
+def _cpp_generator():
+    """tools/libuwt_gen.so (make -C tools; __graft_entry__.build() does it): the benchmarks' deterministic C++ input generator."""
+    import ctypes as C
+    path = os.path.join(ROOT, "tools", "libuwt_gen.so")
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "libuwt_gen.so"])
+    lib = C.CDLL(path)
+    lib.uwt_gen_pair.restype = C.c_int
+    lib.uwt_gen_pair.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.POINTER(C.c_double)]
+
+    def gen(w, h, intr, gid, with_depth):
+        ref = np.empty((h, w), np.uint8); tgt = np.empty((h, w), np.uint8)
+        dep = np.empty((h, w), np.uint16) if with_depth else None
+        z = C.c_double()
+        rc = lib.uwt_gen_pair(w, h, *[float(v) for v in intr], gid, ref.ctypes.data, tgt.ctypes.data,
+                              dep.ctypes.data if dep is not None else None, C.byref(z))
+        if rc:
+            raise RuntimeError("uwt_gen_pair failed")
+        return ref, tgt, dep
+    return gen
 
 
 def _under_profiler():

@@ -192,6 +192,8 @@ int uwt_stream(uwt_ctx* ctx, void** out);
  * roofline.valu).  0 switches both off. */
 int uwt_profile_enable(uwt_ctx* ctx, int32_t on);
 int uwt_profile_read(uwt_ctx* ctx, double* residual_ms_total, int64_t* residual_launches, int64_t* residual_pixels);
+/* the same durations and launch counts by pyramid level (arrays of n_levels entries) */
+int uwt_profile_read_levels(uwt_ctx* ctx, double* ms_by_level, int64_t* launches_by_level, int32_t n_levels);
 /* Shader clock (GHz) the chip held inside the last profiled k_residual launch: blocks of a profiled launch leave their
  * s_memtime (shader cycles) and s_memrealtime (100 MHz) deltas in their records.  Diagnostic; synchronises. */
 int uwt_profile_clock(uwt_ctx* ctx, double* shader_ghz);

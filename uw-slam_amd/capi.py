@@ -46,7 +46,7 @@ SYMBOLS = [
     "uwt_abi_version", "uwt_status_string", "uwt_last_error", "uwt_default_params", "uwt_create", "uwt_destroy",
     "uwt_level_info", "uwt_set_frame", "uwt_upload_frames", "uwt_upload_frames_async", "uwt_host_alloc", "uwt_host_free", "uwt_plane_device_ptr", "uwt_get_plane",
     "uwt_build_pyramids", "uwt_apply_gradient", "uwt_estimate_pose_batch", "uwt_track_batch_async", "uwt_track_batch_host_async", "uwt_wait_ticket", "uwt_sync", "uwt_set_deferred",
-    "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_profile_clock", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
+    "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_profile_read_levels", "uwt_profile_clock", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
     "uwt_warp", "uwt_residual_jacobian", "uwt_ls_accumulate", "uwt_se3_exp", "uwt_se3_mul", "uwt_se3_matrix",
     "uwt_se3_handoff", "uwt_solve_delta", "uwt_accumulate_trajectory", "uwt_accumulate_trajectory_scan",
     "uwt_residual_jacobian_weighted", "uwt_estimate_pose_points", "uwt_gradient_magnitude",
@@ -291,6 +291,14 @@ class Context:
         ms, n, px = C.c_double(), C.c_int64(), C.c_int64()
         self._chk(lib().uwt_profile_read(self._h, C.byref(ms), C.byref(n), C.byref(px)))
         return ms.value, n.value, px.value
+
+    def profile_read_levels(self):
+        """[(ms, launches)] by pyramid level for the residual launches since profiling was enabled."""
+        n = self.params.n_levels
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        self._chk(lib().uwt_profile_read_levels(self._h, ms, cnt, n))
+        return [(ms[l], cnt[l]) for l in range(n)]
 
     def profile_clock(self):
         """Shader clock (GHz) inside the last profiled residual launch."""

@@ -101,6 +101,9 @@ struct uwt_ctx {
   size_t ev_used = 0;
   double prof_ms = 0.0;
   long long prof_launches = 0, prof_pixels = 0;
+  double prof_level_ms[UWT_MAX_LEVELS] = {};        // the same durations by pyramid level (uwt_profile_read_levels)
+  long long prof_level_launches[UWT_MAX_LEVELS] = {};
+  std::vector<int> prof_ev_level;                      // level of the launch each event pair brackets
   int prof_slices = 0, prof_pairs = 0;   // slicing of the last profiled residual launch (uwt_profile_clock)
   std::string last_error;
 };
@@ -293,7 +296,9 @@ ResidualArgs residual_args(uwt_ctx* c, int lvl) {
   return a;
 }
 
-int prof_begin(uwt_ctx* c, size_t* idx) {
+int prof_begin(uwt_ctx* c, size_t* idx, int lvl = 0) {
+  if (c->prof_ev_level.size() < c->ev_used / 2 + 1) c->prof_ev_level.resize(c->ev_used / 2 + 1);
+  c->prof_ev_level[c->ev_used / 2] = lvl;
   if (c->ev_used + 2 > c->ev_pool.size()) {
     for (int i = 0; i < 64; i++) {
       hipEvent_t e;
@@ -312,6 +317,8 @@ int prof_collect(uwt_ctx* c) {  // after a stream sync
     float ms = 0.f;
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i], c->ev_pool[i + 1]));
     c->prof_ms += ms;
+    const int lvl = c->prof_ev_level[i / 2];
+    if (lvl >= 0 && lvl < UWT_MAX_LEVELS) { c->prof_level_ms[lvl] += ms; c->prof_level_launches[lvl] += 1; }
   }
   c->ev_used = 0;
   return UWT_OK;
@@ -551,7 +558,7 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
       if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
       size_t ev = 0;
       if (c->profiling) {
-        int st = prof_begin(c, &ev);
+        int st = prof_begin(c, &ev, lvl);
         if (st) return st;
         ra.probe = 1;
         c->prof_slices = ra.slices;
@@ -660,7 +667,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
       for (int k = 0; k < p.max_iters; k++) {
         size_t ev = 0;
         if (c->profiling) {
-          int st = prof_begin(c, &ev);
+          int st = prof_begin(c, &ev, lvl);
           if (st) return st;
           ra.probe = 1;
           c->prof_slices = ra.slices;
@@ -1443,6 +1450,13 @@ int uwt_profile_enable(uwt_ctx* c, int32_t on) {
   c->prof_ms = 0.0;
   c->prof_launches = 0;
   c->prof_pixels = 0;
+  for (int l = 0; l < UWT_MAX_LEVELS; l++) { c->prof_level_ms[l] = 0.0; c->prof_level_launches[l] = 0; }
+  return UWT_OK;
+}
+
+int uwt_profile_read_levels(uwt_ctx* c, double* ms_by_level, int64_t* launches_by_level, int32_t n_levels) {
+  if (!c || !ms_by_level || !launches_by_level || n_levels < 1 || n_levels > UWT_MAX_LEVELS) return UWT_ERR_INVALID_ARG;
+  for (int l = 0; l < n_levels; l++) { ms_by_level[l] = c->prof_level_ms[l]; launches_by_level[l] = c->prof_level_launches[l]; }
   return UWT_OK;
 }
 
