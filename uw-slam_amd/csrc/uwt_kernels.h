@@ -537,7 +537,7 @@ __device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf_, float
 
 // Accumulator type: double reproduces the reference's double-accumulating gemm (src/Tracker.cpp:560-561) to the
 // last bit of the f32 result in practice (products of two f32 are exact in f64); float is the cheaper variant.
-__device__ __forceinline__ void accumulate(float acc[kAccFloats], const float J[6], int ri) {
+__device__ __forceinline__ void accumulate(float acc[kAccFloats], const float J[6], int ri, double* = nullptr) {
   const float r = (float)ri;
   int s = 0;
 #pragma unroll
@@ -548,11 +548,14 @@ __device__ __forceinline__ void accumulate(float acc[kAccFloats], const float J[
   for (int i = 0; i < 6; i++) acc[21 + i] = __builtin_fmaf(J[i], r, acc[21 + i]);
 }
 
-__device__ __forceinline__ void accumulate(double acc[kAccFloats], const float J[6], int ri) {
+// r2 (optional): the sum of r^2 kept as a 28th f64 sum — integers below 2^53 add exactly, and the residual is in f64 anyway:
+// one fma in place of an integer multiply and add
+__device__ __forceinline__ void accumulate(double acc[kAccFloats], const float J[6], int ri, double* r2 = nullptr) {
   double Jd[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) Jd[i] = (double)J[i];
   const double rd = (double)ri;  // the residual is an integer: one conversion instead of two
+  if (r2) *r2 = __builtin_fma(rd, rd, *r2);
   int s = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++)
@@ -625,9 +628,9 @@ constexpr int reduce_lds_bytes(int pass) { return pass * kBlock * 8 + 2 * kBlock
 constexpr int kReduceLdsBytes = reduce_lds_bytes(14);   // 34688
 constexpr int kIteratePass = kAccFloats;                // k_iterate, up to 3 pairs (blocks alone on their CUs): one pass, 61312 B
 
-template <typename AccT, bool HAS_EXTRA = false, int PASS = 14>
+template <typename AccT, bool HAS_EXTRA = false, int PASS = 14, typename R2T = uint32_t>
 __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict__ lds, const AccT acc[kAccFloats],
-                                                      uint32_t sum_r2, uint32_t n_valid, uint32_t* __restrict__ rec,
+                                                      R2T sum_r2, uint32_t n_valid, uint32_t* __restrict__ rec,
                                                       AccT extra = (AccT)0) {
   constexpr int kPass = PASS;  // accumulators per LDS pass
   constexpr int kRows = kAccFloats + (HAS_EXTRA ? 1 : 0);   // the extra sum rides in the last pass
@@ -691,11 +694,11 @@ __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict_
   }
 }
 
-template <typename AccT, bool HAS_EXTRA = false>
-__device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], uint32_t sum_r2, uint32_t n_valid,
+template <typename AccT, bool HAS_EXTRA = false, typename R2T = uint32_t>
+__device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], R2T sum_r2, uint32_t n_valid,
                                                    uint32_t* __restrict__ rec, AccT extra = (AccT)0) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kReduceLdsBytes];
-  block_reduce_store_at<AccT, HAS_EXTRA>(lds, acc, sum_r2, n_valid, rec, extra);
+  block_reduce_store_at<AccT, HAS_EXTRA, 14, R2T>(lds, acc, sum_r2, n_valid, rec, extra);
 }
 
 // robust weights / bilinear sampler shared by the dense kernels and the general (dump-capable) kernel
@@ -839,6 +842,7 @@ struct ResidualArgs {
   float* dumpR;
   uint8_t* dumpV;
   float* dumpW;             // per-pixel robust weights (general path only)
+  int* fix;                 // [pair] flags of the lean kernel: "evaluate this pair's slices the exact way" (k_gn_update_fix)
   int probe;                // 1: thread 0 of every block leaves its shader-clock / 100 MHz real-time deltas in words 60, 61
                             // of the block's record (uwt_profile_clock: the clock the chip holds under this kernel)
 };
@@ -880,8 +884,9 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
 // by register arithmetic — results are meaningless, its duration is the kernel's own instruction-issue floor.
 // residual_core evaluates one slice of one pair at `pose`; `lds` (optional) is the caller's buffer for the block reduction.
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, int EXT_LDS = 0>   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's
-__device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
+          bool COMPUTE_ONLY = false, int EXT_LDS = 0,   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's
+          bool LEAN = false>                            // LEAN: see residual_block
+__device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first = nullptr, int ref_slot = -1,
                                               int tgt_slot = -1);
 
@@ -896,7 +901,7 @@ __device__ __forceinline__ void load_first_group(RefGroup<VEC>& rg, const Residu
 }
 
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false>
+          bool COMPUTE_ONLY = false, bool LEAN = false>
 __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int pair, const int slice) {
   Pose pose;
   if constexpr (COMPUTE_ONLY) {
@@ -908,13 +913,30 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   } else {
     pose = a.pose;
   }
+  // LEAN (round 3; a kernel of its own for the batch path, identity weights / nearest sampler / f64 sums): the three
+  // per-pixel selects that sanitise x2, y2, iz of an invalid pixel are dropped — its gradients and residual are still
+  // zeroed, so its Jacobian row is (+-0) * (finite Jw) = +-0 and the sums are untouched, bit for bit.  What the selects
+  // guard against is a NON-FINITE Jw of an invalid pixel (z2 = 0 over a depth hole at the identity start, an overflowing
+  // 1 / z2): then 0 * inf = NaN enters the sums, and NaN is sticky — so the block looks at its diagonal sums once, after
+  // the loop, and when any thread saw NaN it stores nothing and raises the pair's flag: the pair's update block
+  // (k_gn_update_fix) then evaluates the pair's slices the exact way before it folds them.  The host launches the exact
+  // kernel for the first evaluation of an alignment with a depth plane (pose = identity puts z2 = t_z = 0 over every
+  // hole); after that the flag is practically never raised.  Either way the records are those of the exact evaluation.
+  if constexpr (LEAN) {
+    static_assert(VEC == 4 && !DUMP && SAMPLER == 0 && WEIGHTS == 0 && std::is_same<AccT, double>::value, "lean form");
+    const bool stored = residual_core<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, 0, true>(a, pair, slice, pose, nullptr);
+    if (!stored && !COMPUTE_ONLY && threadIdx.x == 0) atomicOr(a.fix + pair, 1);
+    return;
+  }
   residual_core<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, slice, pose, nullptr);
 }
 
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
-          int EXT_LDS>
-__device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
+          int EXT_LDS, bool LEAN>
+__device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot) {
+  static_assert(!LEAN || (!DUMP && SAMPLER == 0 && WEIGHTS == 0 && std::is_same<AccT, double>::value),
+                "the lean form exists for the batch kernel of the identity / nearest path");
   WarpK K;
   pose_to_T12(pose, K.T);
 #pragma unroll
@@ -941,6 +963,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 #pragma unroll
   for (int i = 0; i < kAccFloats; i++) acc[i] = (AccT)0;
   uint32_t sum_r2 = 0, n_valid_wave = 0;  // the valid count is kept per wave in a scalar register
+  double r2d = 0.0;                       // LEAN: the sum of r^2 as an f64 sum (see accumulate)
   constexpr bool GENERAL = SAMPLER != 0 || WEIGHTS != 0;  // float residuals and/or robust weights
   AccT err = (AccT)0;                                      // Σ r·(r·w), the error numerator on the general path
   float inv_mad = 1.f;
@@ -1010,7 +1033,22 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
       }
       if constexpr (DEPTH) z = z * bc<F>(L.zscale);
       xf = bc<F>(xf0) + xf;
-      pixel_warp<F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N], &gidx[u * N]);
+      if constexpr (LEAN) {
+        pixel_warp_raw<F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N]);
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+          float r = get(iz[u], c);
+          asm("v_max_f32 %0, 0, %0" : "+v"(r));   // "if (inv_z2 < 0) inv_z2 = 0" (:452-453) for a valid pixel; a NaN of an invalid one becomes 0
+          put(iz[u], c, r);
+          int ix2 = round_pos(get(x2[u], c)), iy2 = round_pos(get(y2[u], c));
+          // x2, y2 are not sanitised here: clamp both ways, in one instruction (the compiler keeps min and max apart)
+          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(ix2) : "s"(L.w - 1));
+          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy2) : "s"(L.h - 1));
+          gidx[u * N + c] = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;
+        }
+      } else {
+        pixel_warp<F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N], &gidx[u * N]);
+      }
     }
     // phase 2: the samples of the target level
     int i2[VEC];
@@ -1080,7 +1118,8 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
       int ri = 0;
       if constexpr (!GENERAL) {
         ri = keep_i(i2[j] - (int)i1[j], okm[j]);
-        accumulate(acc, Jp, ri);
+        if constexpr (LEAN) accumulate(acc, Jp, ri, &r2d);
+        else accumulate(acc, Jp, ri);
       } else {
         float rf;
         if constexpr (SAMPLER == 0) rf = (float)keep_i(i2[j] - (int)i1[j], okm[j]);
@@ -1089,7 +1128,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
         accumulate_weighted(acc, err, Jp, rf, w, a.gain);
         ri = (int)rintf(rf);
       }
-      sum_r2 += (uint32_t)__mul24(ri, ri);  // |ri| <= 255
+      if constexpr (!LEAN) sum_r2 += (uint32_t)__mul24(ri, ri);  // |ri| <= 255
       n_valid_wave += (uint32_t)__builtin_popcountll(okm[j]);  // scalar
       if constexpr (DUMP) {
         if (active) {
@@ -1108,12 +1147,18 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     xf0 -= wrap ? wf : 0.f;
     yf += wrap ? 1.f : 0.f;
   }
+  if constexpr (LEAN) {
+    // diagonal sums are sums of squares: NaN in any Jacobian entry of any pixel of this thread shows in one of them
+    const double d = ((double)acc[0] + (double)acc[6]) + ((double)acc[11] + (double)acc[15]) + ((double)acc[18] + (double)acc[20]);
+    if (__syncthreads_or(!(d == d))) return false;   // block-uniform: the caller evaluates the slice the exact way
+  }
   const uint32_t n_valid = (threadIdx.x & 63) == 0 ? n_valid_wave : 0u;
   uint32_t* out_rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
 #ifdef UWT_EXP_STAMPS
   if (threadIdx.x == 0) out_rec[62] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
-  if constexpr (EXT_LDS != 0) block_reduce_store_at<AccT, GENERAL, EXT_LDS>(lds, acc, sum_r2, n_valid, out_rec, err);   // the caller's bytes: k_iterate
+  if constexpr (LEAN) block_reduce_store<AccT, false, double>(acc, r2d, n_valid, out_rec, err);
+  else if constexpr (EXT_LDS != 0) block_reduce_store_at<AccT, GENERAL, EXT_LDS>(lds, acc, sum_r2, n_valid, out_rec, err);   // the caller's bytes: k_iterate
   else if constexpr (TABLE) {
     __syncthreads();   // every wave has read its last table entry: the bytes become the reduction's image
     block_reduce_store_at<AccT, true>(tlds, acc, sum_r2, n_valid, out_rec, err);
@@ -1123,6 +1168,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     rec[60] = (uint32_t)(__builtin_amdgcn_s_memtime() - clk0);
     rec[61] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt0);
   }
+  return true;
 }
 
 #ifndef UWT_EXP_WAVES
@@ -1131,9 +1177,9 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 #define UWT_RESIDUAL_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(UWT_EXP_WAVES, UWT_EXP_WAVES)))
 #endif
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false>
+          bool COMPUTE_ONLY = false, bool LEAN = false>
 __global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
-  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
+  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, LEAN>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1687,6 +1733,29 @@ __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const u
 __global__ __launch_bounds__(kUpdateBlock) void k_gn_update(const UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kUpdateLdsBytes];
   const int pair = (int)blockIdx.x + a.pair_base;
+  const PairState st = update_compute(a, a.partials + (size_t)pair * a.slices * kRecWords, &a.state[pair], lds, true);
+  if (threadIdx.x == 0) a.state[pair] = st;
+}
+
+// The update behind a LEAN residual launch: a pair whose flag the lean kernel raised (NaN from an unsanitised invalid
+// pixel, see residual_block) first has its slices evaluated the exact way by this block — rare, and its cost is that of
+// the evaluation it replaces — then the update runs as always on the records now in place.
+template <bool DEPTH, bool UNIT_FACTORS, bool SQUARE>
+__global__ __launch_bounds__(kUpdateBlock) void k_gn_update_fix(const UpdateArgs a, const ResidualArgs ra) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kUpdateLdsBytes];
+  __shared__ __attribute__((aligned(16))) unsigned char rlds[kReduceLdsBytes];
+  const int pair = (int)blockIdx.x + a.pair_base;
+  if (ra.fix[pair]) {   // block-uniform
+    const PairState cur = a.state[pair];
+    if (!(cur.level_done || cur.status))
+      for (int slice = 0; slice < ra.slices; slice++) {
+        residual_core<4, DEPTH, UNIT_FACTORS, false, double, SQUARE, 0, 0, false, 14, false>(ra, pair, slice, cur.pose, rlds);
+        __syncthreads();
+      }
+    if (threadIdx.x == 0) ra.fix[pair] = 0;
+    __threadfence();   // the records this block has just written are read back below, by other lanes, through a cold L1
+    __syncthreads();
+  }
   const PairState st = update_compute(a, a.partials + (size_t)pair * a.slices * kRecWords, &a.state[pair], lds, true);
   if (threadIdx.x == 0) a.state[pair] = st;
 }
