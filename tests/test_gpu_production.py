@@ -435,32 +435,3 @@ print("ok")
     r = _run([sys.executable, "-c", code])
     assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]
 
-
-def test_lean_kernel_flagged_pairs_are_reevaluated_exactly(O, synth):
-    """The batch path's lean residual kernel drops the selects that sanitise an invalid pixel's x2, y2, 1/z2; a block that
-    then meets NaN raises its pair's flag and the update block evaluates the pair the exact way.  UWT_LEAN_FIRST=1 sends
-    the first evaluation (identity pose: z2 = 0 over every depth hole, NaN for certain) through the lean kernel too, so
-    every pair takes that path — and UWT_NO_LEAN=1 never uses the lean kernel.  Both in a child process each (the switches
-    are read when a context is created); all poses bit-identical to the oracle's either way."""
-    code = r'''
-import importlib, sys, numpy as np
-sys.path.insert(0, %r)
-capi = importlib.import_module("uw-slam_amd.capi"); synth = importlib.import_module("uw-slam_amd.synth")
-from oracle import oracle as O
-w, h, intr = 320, 240, (262.5, 262.5, 159.5, 119.5)
-over = dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0, has_depth=1)
-n = 20                                   # past the chained flow's few pairs: the batch path
-pairs = [synth.render_pair(w, h, *intr, seed=300 + i, z=0.8 + 0.04 * i, with_depth=True) for i in range(n)]
-ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
-frames = np.stack([f for p in pairs for f in (p[0], p[1])]); depth = np.stack([p[2] for p in pairs for _ in (0, 1)])
-ctx.upload_frames(0, frames, depth); ctx.build_pyramids(0, 2 * n); ctx.apply_gradient(0, 2 * n)
-poses, stats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1, raise_on_pair_failure=True)
-po = O.default_params(w, h, *intr, **over)
-for i, p in enumerate(pairs):
-    st, pose_cpu, _ = O.align_pair(po, p[0], p[1], p[2])
-    assert st == 0 and np.array_equal(poses[i].view(np.uint32), pose_cpu.view(np.uint32)), (i, poses[i], pose_cpu)
-ctx.close(); print("ok")
-''' % ROOT
-    for env in ({"UWT_LEAN_FIRST": "1"}, {"UWT_NO_LEAN": "1"}, {}):
-        r = _run([sys.executable, "-c", code], extra_env=env)
-        assert r.returncode == 0 and b"ok" in r.stdout, (env, r.stderr.decode()[-2000:])

@@ -31,10 +31,6 @@ struct uwt_ctx {
   // iterations of the alignment (VALU-bound), which only read the coarsest iterated level.  UWT_OVERLAP_GRAD=0: off.
   hipStream_t side = nullptr;
   static constexpr int kMaxParts = 4;
-  int* d_fix = nullptr;                 // [max_pairs] flags of the lean residual kernel (residual_block / k_gn_update_fix)
-  bool lean = true;                     // UWT_NO_LEAN=1: always the exact kernel
-  bool lean_first = false;              // UWT_LEAN_FIRST=1 (tests): the lean kernel for the first evaluation too, so that every
-                                        // block over a depth hole raises its pair's flag and the update block re-evaluates
   int dep_first = 0, dep_n = 0;         // slot range the running tracker call depends on (track_batch_enqueue)
   hipStream_t part_stream[kMaxParts] = {};   // compute streams of parts 1.. of a split batch (part 0: `stream`)
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {};
@@ -235,23 +231,7 @@ int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int 
 }
 
 template <int VEC, bool DEPTH, bool UNIT, bool DUMP>
-void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64, bool compute_only, bool lean) {
-  if constexpr (VEC == 4 && !DUMP) {
-    if (lean && acc64) {   // the lean kernel (residual_block): identity weights, nearest sampler, f64 sums
-      const dim3 grid(a.slices, n_pairs), blk(kBlock);
-      if constexpr (UNIT) {
-        if (a.L.fx == a.L.fy) {
-          if (compute_only) hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, true, 0, 0, true, true>), grid, blk, 0, s, a);
-          else hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, true, 0, 0, false, true>), grid, blk, 0, s, a);
-          return;
-        }
-      }
-      if (!compute_only) {
-        hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, false, 0, 0, false, true>), grid, blk, 0, s, a);
-        return;
-      }
-    }
-  }
+void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64, bool compute_only) {
   if constexpr (VEC == 4 && UNIT && !DUMP) {
     if (compute_only && acc64 && a.L.fx == a.L.fy) {  // diagnostic twin of the production instantiation
       hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
@@ -266,7 +246,7 @@ void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool a
     hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, float>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
 }
 
-int launch_residual(uwt_ctx* c, const ResidualArgs& a, int n_pairs, bool dump, bool lean = false) {
+int launch_residual(uwt_ctx* c, const ResidualArgs& a, int n_pairs, bool dump) {
   const bool depth = c->p.has_depth != 0;
   const bool unit = (a.zf == 1.0f && a.af == 1.0f);
   const int key = (c->vec == 4 ? 8 : 0) | (depth ? 4 : 0) | (unit ? 2 : 0) | (dump ? 1 : 0);
@@ -274,43 +254,22 @@ int launch_residual(uwt_ctx* c, const ResidualArgs& a, int n_pairs, bool dump, b
   const bool acc64 = c->p.accumulate_f64 != 0;
   const bool co = c->compute_only && !dump;
   switch (key) {
-    case 0: launch_residual_t<1, false, false, false>(s, a, n_pairs, acc64, co, lean); break;
-    case 1: launch_residual_t<1, false, false, true>(s, a, n_pairs, acc64, co, lean); break;
-    case 2: launch_residual_t<1, false, true, false>(s, a, n_pairs, acc64, co, lean); break;
-    case 3: launch_residual_t<1, false, true, true>(s, a, n_pairs, acc64, co, lean); break;
-    case 4: launch_residual_t<1, true, false, false>(s, a, n_pairs, acc64, co, lean); break;
-    case 5: launch_residual_t<1, true, false, true>(s, a, n_pairs, acc64, co, lean); break;
-    case 6: launch_residual_t<1, true, true, false>(s, a, n_pairs, acc64, co, lean); break;
-    case 7: launch_residual_t<1, true, true, true>(s, a, n_pairs, acc64, co, lean); break;
-    case 8: launch_residual_t<4, false, false, false>(s, a, n_pairs, acc64, co, lean); break;
-    case 9: launch_residual_t<4, false, false, true>(s, a, n_pairs, acc64, co, lean); break;
-    case 10: launch_residual_t<4, false, true, false>(s, a, n_pairs, acc64, co, lean); break;
-    case 11: launch_residual_t<4, false, true, true>(s, a, n_pairs, acc64, co, lean); break;
-    case 12: launch_residual_t<4, true, false, false>(s, a, n_pairs, acc64, co, lean); break;
-    case 13: launch_residual_t<4, true, false, true>(s, a, n_pairs, acc64, co, lean); break;
-    case 14: launch_residual_t<4, true, true, false>(s, a, n_pairs, acc64, co, lean); break;
-    default: launch_residual_t<4, true, true, true>(s, a, n_pairs, acc64, co, lean); break;
-  }
-  HIPCHK(c, hipGetLastError());
-  return UWT_OK;
-}
-
-// the update behind a residual launch; `fix`: the launch may have been a lean one (k_gn_update_fix looks at the pair's flag)
-int launch_update(uwt_ctx* c, const UpdateArgs& ua, const ResidualArgs& ra, int n_pairs, hipStream_t s, bool fix) {
-  const dim3 grid(n_pairs), blk(kUpdateBlock);
-  if (!fix) {
-    hipLaunchKernelGGL(k_gn_update, grid, blk, 0, s, ua);
-  } else {
-    const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f), sq = unit && ra.L.fx == ra.L.fy;
-    const int key = (depth ? 4 : 0) | (unit ? 2 : 0) | (sq ? 1 : 0);
-    switch (key) {
-      case 0: hipLaunchKernelGGL((k_gn_update_fix<false, false, false>), grid, blk, 0, s, ua, ra); break;
-      case 2: hipLaunchKernelGGL((k_gn_update_fix<false, true, false>), grid, blk, 0, s, ua, ra); break;
-      case 3: hipLaunchKernelGGL((k_gn_update_fix<false, true, true>), grid, blk, 0, s, ua, ra); break;
-      case 4: hipLaunchKernelGGL((k_gn_update_fix<true, false, false>), grid, blk, 0, s, ua, ra); break;
-      case 6: hipLaunchKernelGGL((k_gn_update_fix<true, true, false>), grid, blk, 0, s, ua, ra); break;
-      default: hipLaunchKernelGGL((k_gn_update_fix<true, true, true>), grid, blk, 0, s, ua, ra); break;
-    }
+    case 0: launch_residual_t<1, false, false, false>(s, a, n_pairs, acc64, co); break;
+    case 1: launch_residual_t<1, false, false, true>(s, a, n_pairs, acc64, co); break;
+    case 2: launch_residual_t<1, false, true, false>(s, a, n_pairs, acc64, co); break;
+    case 3: launch_residual_t<1, false, true, true>(s, a, n_pairs, acc64, co); break;
+    case 4: launch_residual_t<1, true, false, false>(s, a, n_pairs, acc64, co); break;
+    case 5: launch_residual_t<1, true, false, true>(s, a, n_pairs, acc64, co); break;
+    case 6: launch_residual_t<1, true, true, false>(s, a, n_pairs, acc64, co); break;
+    case 7: launch_residual_t<1, true, true, true>(s, a, n_pairs, acc64, co); break;
+    case 8: launch_residual_t<4, false, false, false>(s, a, n_pairs, acc64, co); break;
+    case 9: launch_residual_t<4, false, false, true>(s, a, n_pairs, acc64, co); break;
+    case 10: launch_residual_t<4, false, true, false>(s, a, n_pairs, acc64, co); break;
+    case 11: launch_residual_t<4, false, true, true>(s, a, n_pairs, acc64, co); break;
+    case 12: launch_residual_t<4, true, false, false>(s, a, n_pairs, acc64, co); break;
+    case 13: launch_residual_t<4, true, false, true>(s, a, n_pairs, acc64, co); break;
+    case 14: launch_residual_t<4, true, true, false>(s, a, n_pairs, acc64, co); break;
+    default: launch_residual_t<4, true, true, true>(s, a, n_pairs, acc64, co); break;
   }
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
@@ -334,7 +293,6 @@ ResidualArgs residual_args(uwt_ctx* c, int lvl) {
   a.partials = c->partials;
   a.scale = c->scale;
   a.gain = c->p.gain;
-  a.fix = c->d_fix;
   return a;
 }
 
@@ -680,12 +638,6 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
     slicing(lvl, gpb, sl);
     smax = std::max(smax, sl);
   }
-  // The lean residual kernel (residual_block) runs every evaluation but the alignment's first where there is a depth plane:
-  // the start pose is the identity, which puts z2 = t_z = 0 over every depth hole — NaN for certain, so that one evaluation
-  // takes the exact kernel straight away.
-  const bool lean_ok = !general && c->lean && c->vec == 4 && p.accumulate_f64 != 0;
-  auto first_exact = [&](int lvl, int k) { return p.has_depth != 0 && lvl == p.first_level && k == 0 && !c->lean_first; };
-  if (lean_ok) HIPCHK(c, hipMemsetAsync(c->d_fix, 0, sizeof(int) * n_pairs, c->stream));
   // robust weights: the per-pair residual histograms (and the ticket word of each) start an alignment all-zero; every scale
   // pass leaves them so (k_resid_hist_v)
   if (general && p.weights)
@@ -722,7 +674,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
           c->prof_pairs = cnt;
           c->prof_records = c->partials;
         }
-        int st = general ? launch_general(c, ra, cnt) : launch_residual(c, ra, cnt, false, lean_ok && !first_exact(lvl, k));
+        int st = general ? launch_general(c, ra, cnt) : launch_residual(c, ra, cnt, false);
         if (st) return st;
         if (c->profiling) {
           HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
@@ -734,8 +686,8 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
         ua.active = poll ? c->d_active : nullptr;
         if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
-        st = launch_update(c, ua, ra, cnt, c->stream, lean_ok);
-        if (st) return st;
+        hipLaunchKernelGGL(k_gn_update, dim3(cnt), dim3(kUpdateBlock), 0, c->stream, ua);
+        HIPCHK(c, hipGetLastError());
         if (poll) {  // reference-mode early exit: stop launching once every pair has left this level
           HIPCHK(c, hipMemcpyAsync(c->h_active, c->d_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
           HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -805,13 +757,12 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
       for (int i = 0; i < parts && st == UWT_OK; i++) {
         Part& q = pt[i];
         c->stream = q.s;      // every launch helper enqueues on c->stream
-        st = general ? launch_general(c, q.ra, q.cnt) : launch_residual(c, q.ra, q.cnt, false, lean_ok && !first_exact(lvl, k));
+        st = general ? launch_general(c, q.ra, q.cnt) : launch_residual(c, q.ra, q.cnt, false);
         c->stream = main_stream;
         if (st) break;
         q.ua.k = k;
         q.ua.active = nullptr;
-        st = launch_update(c, q.ua, q.ra, q.cnt, q.s, lean_ok);
-        if (st) break;
+        hipLaunchKernelGGL(k_gn_update, dim3(q.cnt), dim3(kUpdateBlock), 0, q.s, q.ua);
       }
     if (st) return st;
     for (int i = 0; i < parts; i++)
@@ -1036,10 +987,6 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_poses, sizeof(float) * 7 * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_stats, sizeof(StatsOut) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_active, sizeof(int)));
-  CREATE_CHK(hipMalloc((void**)&c->d_fix, sizeof(int) * p->max_pairs));
-  CREATE_CHK(hipMemset(c->d_fix, 0, sizeof(int) * p->max_pairs));
-  if (std::getenv("UWT_NO_LEAN")) c->lean = false;
-  if (std::getenv("UWT_LEAN_FIRST")) c->lean_first = true;
   CREATE_CHK(hipHostMalloc((void**)&c->h_small, sizeof(uwt_ctx::SmallResults)));
   CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_small, c->h_small, 0));
   if (const char* e = std::getenv("UWT_TARGET_BLOCKS")) c->target_blocks = std::max(1, std::atoi(e));  // tuning experiments only
@@ -1079,7 +1026,6 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stats) (void)hipFree(c->d_stats);
   if (c->d_active) (void)hipFree(c->d_active);
-  if (c->d_fix) (void)hipFree(c->d_fix);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->hist) (void)hipFree(c->hist);
   if (c->scale) (void)hipFree(c->scale);

@@ -537,7 +537,7 @@ __device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf_, float
 
 // Accumulator type: double reproduces the reference's double-accumulating gemm (src/Tracker.cpp:560-561) to the
 // last bit of the f32 result in practice (products of two f32 are exact in f64); float is the cheaper variant.
-__device__ __forceinline__ void accumulate(float acc[kAccFloats], const float J[6], int ri, double* = nullptr) {
+__device__ __forceinline__ void accumulate(float acc[kAccFloats], const float J[6], int ri) {
   const float r = (float)ri;
   int s = 0;
 #pragma unroll
@@ -548,14 +548,12 @@ __device__ __forceinline__ void accumulate(float acc[kAccFloats], const float J[
   for (int i = 0; i < 6; i++) acc[21 + i] = __builtin_fmaf(J[i], r, acc[21 + i]);
 }
 
-// r2 (optional): the sum of r^2 kept as a 28th f64 sum — integers below 2^53 add exactly, and the residual is in f64 anyway:
-// one fma in place of an integer multiply and add
-__device__ __forceinline__ void accumulate(double acc[kAccFloats], const float J[6], int ri, double* r2 = nullptr) {
+__device__ __forceinline__ void accumulate(double acc[kAccFloats], const float J[6], int ri) {
   double Jd[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) Jd[i] = (double)J[i];
   const double rd = (double)ri;  // the residual is an integer: one conversion instead of two
-  if (r2) *r2 = __builtin_fma(rd, rd, *r2);
+
   int s = 0;
 #pragma unroll
   for (int i = 0; i < 6; i++)
@@ -607,6 +605,87 @@ __device__ __forceinline__ void accumulate_preweighted(float acc[kAccFloats], co
     for (int j = i; j < 6; j++, s++) acc[s] = (float)__builtin_fma((double)wJ[i], (double)wJ[j], (double)acc[s]);
 #pragma unroll
   for (int i = 0; i < 6; i++) acc[21 + i] = (float)__builtin_fma((double)wJ[i], (double)rw, (double)acc[21 + i]);
+}
+
+// Masked accumulation (round 3).  The sums of one pixel are added under an EXEC mask that holds the lanes whose pixel is
+// valid — two scalar instructions (s_and_saveexec_b64, s_mov_b64 exec) around the 28 f64 operations — instead of zeroing
+// every invalid pixel's gradients and residual with vector selects so that its row adds exact zeros: an invalid pixel's
+// lane simply does not take part.  Its x2, y2, 1 / z2 therefore need no sanitising either (a NaN there never reaches a
+// sum): 6 selects and a compare per pixel less, 376 -> 347 vector instructions per 4 pixels on the identity path.  The
+// sums are the same bit for bit: a masked-out lane keeps its accumulators, exactly what adding +-0 did.
+// One asm statement cannot take all 35 operands (the limit is 30), hence two statements of 14 sums each.
+__device__ __forceinline__ void masked_sums_lo(double acc[kAccFloats], const double Jd[6], unsigned long long mask) {
+  unsigned long long saved;
+  asm volatile("s_and_saveexec_b64 %14, %21\n\t"
+               "v_fmac_f64 %0, %15, %15\n\t"
+               "v_fmac_f64 %1, %15, %16\n\t"
+               "v_fmac_f64 %2, %15, %17\n\t"
+               "v_fmac_f64 %3, %15, %18\n\t"
+               "v_fmac_f64 %4, %15, %19\n\t"
+               "v_fmac_f64 %5, %15, %20\n\t"
+               "v_fmac_f64 %6, %16, %16\n\t"
+               "v_fmac_f64 %7, %16, %17\n\t"
+               "v_fmac_f64 %8, %16, %18\n\t"
+               "v_fmac_f64 %9, %16, %19\n\t"
+               "v_fmac_f64 %10, %16, %20\n\t"
+               "v_fmac_f64 %11, %17, %17\n\t"
+               "v_fmac_f64 %12, %17, %18\n\t"
+               "v_fmac_f64 %13, %17, %19\n\t"
+               "s_mov_b64 exec, %14"
+               : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]),
+                 "+v"(acc[8]), "+v"(acc[9]), "+v"(acc[10]), "+v"(acc[11]), "+v"(acc[12]), "+v"(acc[13]), "=&s"(saved)
+               : "v"(Jd[0]), "v"(Jd[1]), "v"(Jd[2]), "v"(Jd[3]), "v"(Jd[4]), "v"(Jd[5]), "s"(mask)
+               : "scc");
+}
+// sums 14..26 and a 28th: TAIL 0: x += rd * rd (the sum of r^2, integers below 2^53: exact); TAIL 1: x += e (the error term of
+// the weighted path, see WeightEntry)
+template <int TAIL>
+__device__ __forceinline__ void masked_sums_hi(double acc[kAccFloats], double& x, const double Jd[6], double rd, double e,
+                                               unsigned long long mask) {
+  unsigned long long saved;
+  if constexpr (TAIL == 0) {
+    asm volatile("s_and_saveexec_b64 %14, %22\n\t"
+                 "v_fmac_f64 %0, %17, %20\n\t"
+                 "v_fmac_f64 %1, %18, %18\n\t"
+                 "v_fmac_f64 %2, %18, %19\n\t"
+                 "v_fmac_f64 %3, %18, %20\n\t"
+                 "v_fmac_f64 %4, %19, %19\n\t"
+                 "v_fmac_f64 %5, %19, %20\n\t"
+                 "v_fmac_f64 %6, %20, %20\n\t"
+                 "v_fmac_f64 %7, %15, %21\n\t"
+                 "v_fmac_f64 %8, %16, %21\n\t"
+                 "v_fmac_f64 %9, %17, %21\n\t"
+                 "v_fmac_f64 %10, %18, %21\n\t"
+                 "v_fmac_f64 %11, %19, %21\n\t"
+                 "v_fmac_f64 %12, %20, %21\n\t"
+                 "v_fmac_f64 %13, %21, %21\n\t"
+                 "s_mov_b64 exec, %14"
+                 : "+v"(acc[14]), "+v"(acc[15]), "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]),
+                   "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23]), "+v"(acc[24]), "+v"(acc[25]), "+v"(acc[26]), "+v"(x), "=&s"(saved)
+                 : "v"(Jd[0]), "v"(Jd[1]), "v"(Jd[2]), "v"(Jd[3]), "v"(Jd[4]), "v"(Jd[5]), "v"(rd), "s"(mask)
+                 : "scc");
+  } else {
+    asm volatile("s_and_saveexec_b64 %14, %22\n\t"
+                 "v_fmac_f64 %0, %17, %20\n\t"
+                 "v_fmac_f64 %1, %18, %18\n\t"
+                 "v_fmac_f64 %2, %18, %19\n\t"
+                 "v_fmac_f64 %3, %18, %20\n\t"
+                 "v_fmac_f64 %4, %19, %19\n\t"
+                 "v_fmac_f64 %5, %19, %20\n\t"
+                 "v_fmac_f64 %6, %20, %20\n\t"
+                 "v_fmac_f64 %7, %15, %21\n\t"
+                 "v_fmac_f64 %8, %16, %21\n\t"
+                 "v_fmac_f64 %9, %17, %21\n\t"
+                 "v_fmac_f64 %10, %18, %21\n\t"
+                 "v_fmac_f64 %11, %19, %21\n\t"
+                 "v_fmac_f64 %12, %20, %21\n\t"
+                 "v_add_f64 %13, %13, %23\n\t"
+                 "s_mov_b64 exec, %14"
+                 : "+v"(acc[14]), "+v"(acc[15]), "+v"(acc[16]), "+v"(acc[17]), "+v"(acc[18]), "+v"(acc[19]), "+v"(acc[20]),
+                   "+v"(acc[21]), "+v"(acc[22]), "+v"(acc[23]), "+v"(acc[24]), "+v"(acc[25]), "+v"(acc[26]), "+v"(x), "=&s"(saved)
+                 : "v"(Jd[0]), "v"(Jd[1]), "v"(Jd[2]), "v"(Jd[3]), "v"(Jd[4]), "v"(Jd[5]), "v"(rd), "s"(mask), "v"(e)
+                 : "scc");
+  }
 }
 
 #ifdef UWT_EXP_STAMPS
@@ -842,7 +921,6 @@ struct ResidualArgs {
   float* dumpR;
   uint8_t* dumpV;
   float* dumpW;             // per-pixel robust weights (general path only)
-  int* fix;                 // [pair] flags of the lean kernel: "evaluate this pair's slices the exact way" (k_gn_update_fix)
   int probe;                // 1: thread 0 of every block leaves its shader-clock / 100 MHz real-time deltas in words 60, 61
                             // of the block's record (uwt_profile_clock: the clock the chip holds under this kernel)
 };
@@ -884,9 +962,8 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
 // by register arithmetic — results are meaningless, its duration is the kernel's own instruction-issue floor.
 // residual_core evaluates one slice of one pair at `pose`; `lds` (optional) is the caller's buffer for the block reduction.
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, int EXT_LDS = 0,   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's
-          bool LEAN = false>                            // LEAN: see residual_block
-__device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
+          bool COMPUTE_ONLY = false, int EXT_LDS = 0>   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's
+__device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first = nullptr, int ref_slot = -1,
                                               int tgt_slot = -1);
 
@@ -901,7 +978,7 @@ __device__ __forceinline__ void load_first_group(RefGroup<VEC>& rg, const Residu
 }
 
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, bool LEAN = false>
+          bool COMPUTE_ONLY = false>
 __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int pair, const int slice) {
   Pose pose;
   if constexpr (COMPUTE_ONLY) {
@@ -913,30 +990,15 @@ __device__ __forceinline__ void residual_block(const ResidualArgs& a, const int 
   } else {
     pose = a.pose;
   }
-  // LEAN (round 3; a kernel of its own for the batch path, identity weights / nearest sampler / f64 sums): the three
-  // per-pixel selects that sanitise x2, y2, iz of an invalid pixel are dropped — its gradients and residual are still
-  // zeroed, so its Jacobian row is (+-0) * (finite Jw) = +-0 and the sums are untouched, bit for bit.  What the selects
-  // guard against is a NON-FINITE Jw of an invalid pixel (z2 = 0 over a depth hole at the identity start, an overflowing
-  // 1 / z2): then 0 * inf = NaN enters the sums, and NaN is sticky — so the block looks at its diagonal sums once, after
-  // the loop, and when any thread saw NaN it stores nothing and raises the pair's flag: the pair's update block
-  // (k_gn_update_fix) then evaluates the pair's slices the exact way before it folds them.  The host launches the exact
-  // kernel for the first evaluation of an alignment with a depth plane (pose = identity puts z2 = t_z = 0 over every
-  // hole); after that the flag is practically never raised.  Either way the records are those of the exact evaluation.
-  if constexpr (LEAN) {
-    static_assert(VEC == 4 && !DUMP && SAMPLER == 0 && WEIGHTS == 0 && std::is_same<AccT, double>::value, "lean form");
-    const bool stored = residual_core<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, 0, true>(a, pair, slice, pose, nullptr);
-    if (!stored && !COMPUTE_ONLY && threadIdx.x == 0) atomicOr(a.fix + pair, 1);
-    return;
-  }
   residual_core<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, slice, pose, nullptr);
 }
 
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
-          int EXT_LDS, bool LEAN>
-__device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
+          int EXT_LDS>
+__device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot) {
-  static_assert(!LEAN || (!DUMP && SAMPLER == 0 && WEIGHTS == 0 && std::is_same<AccT, double>::value),
-                "the lean form exists for the batch kernel of the identity / nearest path");
+  // MASKED: f64 sums added under an EXEC mask of the valid lanes (masked_sums_*), nothing of an invalid pixel sanitised
+  constexpr bool MASKED = std::is_same<AccT, double>::value && !DUMP && SAMPLER == 0;
   WarpK K;
   pose_to_T12(pose, K.T);
 #pragma unroll
@@ -963,7 +1025,7 @@ __device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int p
 #pragma unroll
   for (int i = 0; i < kAccFloats; i++) acc[i] = (AccT)0;
   uint32_t sum_r2 = 0, n_valid_wave = 0;  // the valid count is kept per wave in a scalar register
-  double r2d = 0.0;                       // LEAN: the sum of r^2 as an f64 sum (see accumulate)
+  double r2d = 0.0;                       // MASKED: the sum of r^2 as a 28th f64 sum (masked_sums_hi)
   constexpr bool GENERAL = SAMPLER != 0 || WEIGHTS != 0;  // float residuals and/or robust weights
   AccT err = (AccT)0;                                      // Σ r·(r·w), the error numerator on the general path
   float inv_mad = 1.f;
@@ -1033,12 +1095,12 @@ __device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int p
       }
       if constexpr (DEPTH) z = z * bc<F>(L.zscale);
       xf = bc<F>(xf0) + xf;
-      if constexpr (LEAN) {
+      if constexpr (MASKED) {
         pixel_warp_raw<F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N]);
 #pragma unroll
         for (int c = 0; c < N; c++) {
           float r = get(iz[u], c);
-          asm("v_max_f32 %0, 0, %0" : "+v"(r));   // "if (inv_z2 < 0) inv_z2 = 0" (:452-453) for a valid pixel; a NaN of an invalid one becomes 0
+          asm("v_max_f32 %0, 0, %0" : "+v"(r));   // "if (inv_z2 < 0) inv_z2 = 0" (:452-453); what an invalid pixel gets does not matter
           put(iz[u], c, r);
           int ix2 = round_pos(get(x2[u], c)), iy2 = round_pos(get(y2[u], c));
           // x2, y2 are not sanitised here: clamp both ways, in one instruction (the compiler keeps min and max apart)
@@ -1063,8 +1125,13 @@ __device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int p
     F g0[NU], g1[NU];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      put(g0[j / N], j % N, keep_f((float)rg.gx[j], okm[j]));
-      put(g1[j / N], j % N, keep_f((float)rg.gy[j], okm[j]));
+      if constexpr (MASKED) {
+        put(g0[j / N], j % N, (float)rg.gx[j]);
+        put(g1[j / N], j % N, (float)rg.gy[j]);
+      } else {
+        put(g0[j / N], j % N, keep_f((float)rg.gx[j], okm[j]));
+        put(g1[j / N], j % N, keep_f((float)rg.gy[j], okm[j]));
+      }
     }
     // The scheduling fences keep the requests where they are written: left alone the scheduler sinks them to the end of
     // the body (shorter live ranges), and the residual subtractions — the first use of the gathered bytes — rise to just
@@ -1090,8 +1157,7 @@ __device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int p
 #pragma unroll
         for (int c = 0; c < N; c++) {
           const int j = u * N + c;
-          const int ri = keep_i(i2[j] - (int)i1[j], okm[j]);
-          sum_r2 += (uint32_t)__mul24(ri, ri);
+          const int ri = i2[j] - (int)i1[j];   // in [-255, 255] whatever the pixel's validity: a table index either way
           n_valid_wave += (uint32_t)__builtin_popcountll(okm[j]);
           off[c] = (uint32_t)(ri + 255) * (uint32_t)sizeof(WeightEntry);
           put(wv, c, *reinterpret_cast<const float*>(tlds + off[c] + 16));
@@ -1100,12 +1166,24 @@ __device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int p
         for (int k = 0; k < 6; k++) J[u][k] = wv * J[u][k];
 #pragma unroll
         for (int c = 0; c < N; c++) {
-          float Jp[6];
-#pragma unroll
-          for (int k = 0; k < 6; k++) Jp[k] = get(J[u][k], c);
+          const int j = u * N + c;
           const double2 re = *reinterpret_cast<const double2*>(tlds + off[c]);   // rwd, e
-          err += (AccT)re.y;
-          accumulate_preweighted(acc, Jp, re.x);
+          if constexpr (MASKED) {
+            double Jd[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) Jd[k] = (double)get(J[u][k], c);
+            masked_sums_lo(acc, Jd, okm[j]);
+            masked_sums_hi<1>(acc, err, Jd, re.x, re.y, okm[j]);
+          } else {
+            float Jp[6];
+#pragma unroll
+            for (int k = 0; k < 6; k++) Jp[k] = get(J[u][k], c);
+            const unsigned long long m = okm[j];
+            if (lane_bit(m)) {
+              err += (AccT)re.y;
+              accumulate_preweighted(acc, Jp, re.x);
+            }
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1116,10 +1194,16 @@ __device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int p
 #pragma unroll
       for (int k = 0; k < 6; k++) Jp[k] = get(J[j / N][k], j % N);
       int ri = 0;
-      if constexpr (!GENERAL) {
+      if constexpr (!GENERAL && MASKED) {
+        ri = i2[j] - (int)i1[j];
+        double Jd[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) Jd[k] = (double)Jp[k];
+        masked_sums_lo(acc, Jd, okm[j]);
+        masked_sums_hi<0>(acc, r2d, Jd, (double)ri, 0.0, okm[j]);
+      } else if constexpr (!GENERAL) {
         ri = keep_i(i2[j] - (int)i1[j], okm[j]);
-        if constexpr (LEAN) accumulate(acc, Jp, ri, &r2d);
-        else accumulate(acc, Jp, ri);
+        accumulate(acc, Jp, ri);
       } else {
         float rf;
         if constexpr (SAMPLER == 0) rf = (float)keep_i(i2[j] - (int)i1[j], okm[j]);
@@ -1128,7 +1212,7 @@ __device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int p
         accumulate_weighted(acc, err, Jp, rf, w, a.gain);
         ri = (int)rintf(rf);
       }
-      if constexpr (!LEAN) sum_r2 += (uint32_t)__mul24(ri, ri);  // |ri| <= 255
+      if constexpr (GENERAL || !MASKED) sum_r2 += (uint32_t)__mul24(ri, ri);  // |ri| <= 255 (masked path: r2d)
       n_valid_wave += (uint32_t)__builtin_popcountll(okm[j]);  // scalar
       if constexpr (DUMP) {
         if (active) {
@@ -1147,28 +1231,24 @@ __device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int p
     xf0 -= wrap ? wf : 0.f;
     yf += wrap ? 1.f : 0.f;
   }
-  if constexpr (LEAN) {
-    // diagonal sums are sums of squares: NaN in any Jacobian entry of any pixel of this thread shows in one of them
-    const double d = ((double)acc[0] + (double)acc[6]) + ((double)acc[11] + (double)acc[15]) + ((double)acc[18] + (double)acc[20]);
-    if (__syncthreads_or(!(d == d))) return false;   // block-uniform: the caller evaluates the slice the exact way
-  }
   const uint32_t n_valid = (threadIdx.x & 63) == 0 ? n_valid_wave : 0u;
   uint32_t* out_rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
 #ifdef UWT_EXP_STAMPS
   if (threadIdx.x == 0) out_rec[62] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
-  if constexpr (LEAN) block_reduce_store<AccT, false, double>(acc, r2d, n_valid, out_rec, err);
-  else if constexpr (EXT_LDS != 0) block_reduce_store_at<AccT, GENERAL, EXT_LDS>(lds, acc, sum_r2, n_valid, out_rec, err);   // the caller's bytes: k_iterate
+  constexpr bool R2D = MASKED && !GENERAL;   // the identity path's sum of r^2 is the f64 one
+  if constexpr (EXT_LDS != 0 && R2D) block_reduce_store_at<AccT, false, EXT_LDS, double>(lds, acc, r2d, n_valid, out_rec, err);   // the caller's bytes: k_iterate
+  else if constexpr (EXT_LDS != 0) block_reduce_store_at<AccT, GENERAL, EXT_LDS>(lds, acc, sum_r2, n_valid, out_rec, err);
   else if constexpr (TABLE) {
     __syncthreads();   // every wave has read its last table entry: the bytes become the reduction's image
     block_reduce_store_at<AccT, true>(tlds, acc, sum_r2, n_valid, out_rec, err);
-  } else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err);
+  } else if constexpr (R2D) block_reduce_store<AccT, false, double>(acc, r2d, n_valid, out_rec, err);
+  else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err);
   if (a.probe && threadIdx.x == 0) {
     uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
     rec[60] = (uint32_t)(__builtin_amdgcn_s_memtime() - clk0);
     rec[61] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt0);
   }
-  return true;
 }
 
 #ifndef UWT_EXP_WAVES
@@ -1177,9 +1257,9 @@ __device__ __forceinline__ bool residual_core(const ResidualArgs& a, const int p
 #define UWT_RESIDUAL_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(UWT_EXP_WAVES, UWT_EXP_WAVES)))
 #endif
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, bool LEAN = false>
+          bool COMPUTE_ONLY = false>
 __global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
-  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, LEAN>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
+  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1733,29 +1813,6 @@ __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const u
 __global__ __launch_bounds__(kUpdateBlock) void k_gn_update(const UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kUpdateLdsBytes];
   const int pair = (int)blockIdx.x + a.pair_base;
-  const PairState st = update_compute(a, a.partials + (size_t)pair * a.slices * kRecWords, &a.state[pair], lds, true);
-  if (threadIdx.x == 0) a.state[pair] = st;
-}
-
-// The update behind a LEAN residual launch: a pair whose flag the lean kernel raised (NaN from an unsanitised invalid
-// pixel, see residual_block) first has its slices evaluated the exact way by this block — rare, and its cost is that of
-// the evaluation it replaces — then the update runs as always on the records now in place.
-template <bool DEPTH, bool UNIT_FACTORS, bool SQUARE>
-__global__ __launch_bounds__(kUpdateBlock) void k_gn_update_fix(const UpdateArgs a, const ResidualArgs ra) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kUpdateLdsBytes];
-  __shared__ __attribute__((aligned(16))) unsigned char rlds[kReduceLdsBytes];
-  const int pair = (int)blockIdx.x + a.pair_base;
-  if (ra.fix[pair]) {   // block-uniform
-    const PairState cur = a.state[pair];
-    if (!(cur.level_done || cur.status))
-      for (int slice = 0; slice < ra.slices; slice++) {
-        residual_core<4, DEPTH, UNIT_FACTORS, false, double, SQUARE, 0, 0, false, 14, false>(ra, pair, slice, cur.pose, rlds);
-        __syncthreads();
-      }
-    if (threadIdx.x == 0) ra.fix[pair] = 0;
-    __threadfence();   // the records this block has just written are read back below, by other lanes, through a cold L1
-    __syncthreads();
-  }
   const PairState st = update_compute(a, a.partials + (size_t)pair * a.slices * kRecWords, &a.state[pair], lds, true);
   if (threadIdx.x == 0) a.state[pair] = st;
 }
