@@ -377,7 +377,7 @@ def main(args):
                 # the same launches on the bytes the PMC counters see (u16 depth instead of the f32 z the 10 B assume)
                 "frac_counter_bytes": round(achieved * traffic_px / ALG_BYTES_PER_PIXEL_ITER / HBM_PEAK_GBS, 4) if traffic_px else None,
                 "counter_bytes_per_pixel_iteration": traffic_px,
-                "per_level": [{"level": l, "launches": int(n), "avg_launch_ms": round(ms / n, 5),
+                "per_level": [{"level": l, "evaluations": int(n), "avg_ms_per_evaluation": round(ms / n, 5),
                                "algorithmic_GBs": round(ALG_BYTES_PER_PIXEL_ITER * P * (w >> l) * (h >> l) / (ms / n * 1e-3) / 1e9, 1)}
                               for l, (ms, n) in enumerate(res_levels) if n],
                 "traffic": int(traffic_px * res_pixels / res_launches) if traffic_px else None,

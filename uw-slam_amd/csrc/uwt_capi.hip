@@ -92,6 +92,7 @@ struct uwt_ctx {
   bool inline_pairs = false;
   bool deferred = false;                // uwt_set_deferred: stage calls return once enqueued
   bool coarse = true;                   // k_coarse for the coarsest levels of the chained flow (UWT_NO_COARSE=1: off)
+  int coarse_batch_px = 0;              // batches: levels of up to this many pixels run in one k_coarse launch (UWT_COARSE_BATCH_PX)
   int pair_slots[4] = {0, 0, 0, 0};
   int first_poll = 3;                   // evaluations of a level before the first early-exit read-back
   int chained = -1;                     // -1: chained flow for a few pairs (takes_chained_flow); UWT_CHAINED=1 / 0: always / never (A/B runs)
@@ -103,7 +104,7 @@ struct uwt_ctx {
   long long prof_launches = 0, prof_pixels = 0;
   double prof_level_ms[UWT_MAX_LEVELS] = {};        // the same durations by pyramid level (uwt_profile_read_levels)
   long long prof_level_launches[UWT_MAX_LEVELS] = {};
-  std::vector<int> prof_ev_level;                      // level of the launch each event pair brackets
+  std::vector<int> prof_ev_level, prof_ev_evals;                      // level of the launch each event pair brackets
   int prof_slices = 0, prof_pairs = 0;   // slicing of the last profiled residual launch (uwt_profile_clock)
   std::string last_error;
 };
@@ -296,9 +297,10 @@ ResidualArgs residual_args(uwt_ctx* c, int lvl) {
   return a;
 }
 
-int prof_begin(uwt_ctx* c, size_t* idx, int lvl = 0) {
-  if (c->prof_ev_level.size() < c->ev_used / 2 + 1) c->prof_ev_level.resize(c->ev_used / 2 + 1);
+int prof_begin(uwt_ctx* c, size_t* idx, int lvl = 0, int evaluations = 1) {
+  if (c->prof_ev_level.size() < c->ev_used / 2 + 1) { c->prof_ev_level.resize(c->ev_used / 2 + 1); c->prof_ev_evals.resize(c->ev_used / 2 + 1); }
   c->prof_ev_level[c->ev_used / 2] = lvl;
+  c->prof_ev_evals[c->ev_used / 2] = evaluations;   // evaluations the bracketed launch stands for (k_coarse: a whole level)
   if (c->ev_used + 2 > c->ev_pool.size()) {
     for (int i = 0; i < 64; i++) {
       hipEvent_t e;
@@ -318,7 +320,7 @@ int prof_collect(uwt_ctx* c) {  // after a stream sync
     HIPCHK(c, hipEventElapsedTime(&ms, c->ev_pool[i], c->ev_pool[i + 1]));
     c->prof_ms += ms;
     const int lvl = c->prof_ev_level[i / 2];
-    if (lvl >= 0 && lvl < UWT_MAX_LEVELS) { c->prof_level_ms[lvl] += ms; c->prof_level_launches[lvl] += 1; }
+    if (lvl >= 0 && lvl < UWT_MAX_LEVELS) { c->prof_level_ms[lvl] += ms; c->prof_level_launches[lvl] += c->prof_ev_evals[i / 2]; }
   }
   c->ev_used = 0;
   return UWT_OK;
@@ -642,11 +644,61 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   // pass leaves them so (k_resid_hist_v)
   if (general && p.weights)
     HIPCHK(c, hipMemsetAsync(c->hist, 0, sizeof(unsigned int) * kHistBins * n_pairs, c->stream));
+  // The coarsest levels of a batch in ONE launch (round 3): one block per pair runs each of them to its end — evaluation,
+  // update, exit test and hand-off on the device, the record in LDS (k_coarse, four blocks per CU) — instead of a residual
+  // and an update launch per evaluation whose blocks, a few pixel groups long, run 25-50 % below the level-0 rate.  Dense
+  // path with the default constants (f64 sums, unit factors, square pixels); levels of up to coarse_batch_px pixels.
+  int n_coarse = 0;
+  {
+    const LevelK& L0 = c->lv[p.first_level];
+    const bool plain = !general && c->vec == 4 && p.accumulate_f64 != 0 && p.z_factor == 1.0f && p.angle_factor == 1.0f && L0.fx == L0.fy;
+    if (plain && c->coarse_batch_px > 0 && !c->compute_only && !(c->profiling && p.early_exit))
+      while (n_coarse < kCoarseMaxLevels && p.first_level - n_coarse >= p.last_level &&
+             c->lv[p.first_level - n_coarse].n <= c->coarse_batch_px) n_coarse++;
+  }
+  auto run_coarse = [&](int base, int cnt, hipStream_t s) -> int {
+    for (int i = 0; i < n_coarse; i++) {   // a launch per level (one level per launch: 4 waves / SIMD), each to the level's end
+      const int lvl = p.first_level - i;
+      if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(s, level_ready[lvl], 0));  // its gradients
+      CoarseArgs ca;
+      std::memset(&ca, 0, sizeof(ca));
+      ca.lv[0] = residual_args(c, lvl);
+      ca.lv[0].state = nullptr;
+      ca.level_id[0] = lvl;
+      ca.n_levels = 1;
+      UpdateArgs u = update_args(c, lvl);
+      u.pair_base = base;
+      ca.u = u;
+      ca.state_out = c->state;
+      ca.scale_t = p.handoff_scale_t;
+      ca.initial_error = p.initial_error;
+      ca.resume = i > 0;
+      size_t ev = 0;
+      if (c->profiling) {
+        int st = prof_begin(c, &ev, lvl, p.max_iters);
+        if (st) return st;
+      }
+      if (p.has_depth) hipLaunchKernelGGL((k_coarse<true, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
+      else hipLaunchKernelGGL((k_coarse<false, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
+      HIPCHK(c, hipGetLastError());
+      if (c->profiling) {   // (fixed schedules only: the level runs max_iters evaluations; the launch stands for that many)
+        HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], s));
+        c->prof_launches += p.max_iters;
+        c->prof_pixels += (long long)cnt * c->lv[lvl].n * p.max_iters;
+      }
+    }
+    return UWT_OK;
+  };
   // the schedule for pairs [base, base + cnt) of a batch of n_pairs, on c->stream
   auto run = [&](int base, int cnt) -> int {
-    hipLaunchKernelGGL(k_init_state, dim3((cnt + tb - 1) / tb), dim3(tb), 0, c->stream, c->state + base, cnt, p.initial_error);
-    HIPCHK(c, hipGetLastError());
-    for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
+    if (n_coarse > 0) {
+      int st = run_coarse(base, cnt, c->stream);
+      if (st) return st;
+    } else {
+      hipLaunchKernelGGL(k_init_state, dim3((cnt + tb - 1) / tb), dim3(tb), 0, c->stream, c->state + base, cnt, p.initial_error);
+      HIPCHK(c, hipGetLastError());
+    }
+    for (int lvl = p.first_level - n_coarse; lvl >= p.last_level; lvl--) {
       if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(c->stream, level_ready[lvl], 0));  // its gradients
       ResidualArgs ra = residual_args(c, lvl);
       UpdateArgs ua = update_args(c, lvl);
@@ -732,11 +784,16 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
     q.cnt = (int)((long long)n_pairs * (i + 1) / parts) - q.base;
     q.s = i ? c->part_stream[i] : main_stream;
     if (i) HIPCHK(c, hipStreamWaitEvent(q.s, c->ev_fork, 0));
-    hipLaunchKernelGGL(k_init_state, dim3((q.cnt + tb - 1) / tb), dim3(tb), 0, q.s, c->state + q.base, q.cnt, p.initial_error);
+    if (n_coarse > 0) {
+      int stc = run_coarse(q.base, q.cnt, q.s);
+      if (stc) return stc;
+    } else {
+      hipLaunchKernelGGL(k_init_state, dim3((q.cnt + tb - 1) / tb), dim3(tb), 0, q.s, c->state + q.base, q.cnt, p.initial_error);
+    }
   }
   HIPCHK(c, hipGetLastError());
   int st = UWT_OK;
-  for (int lvl = p.first_level; lvl >= p.last_level && st == UWT_OK; lvl--) {
+  for (int lvl = p.first_level - n_coarse; lvl >= p.last_level && st == UWT_OK; lvl--) {
     for (int i = 0; i < parts; i++) {
       Part& q = pt[i];
       if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(q.s, level_ready[lvl], 0));  // its gradients
@@ -957,6 +1014,8 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   if (const char* e = std::getenv("UWT_SPLIT")) c->split = std::max(1, std::min(uwt_ctx::kMaxParts, std::atoi(e)));
   if (std::getenv("UWT_NO_COARSE")) c->coarse = false;
+  c->coarse_batch_px = kCoarseMaxPixels;   // e.g. level 3 of 640x480: +0.8 % on the default batch; larger levels lose (2 waves / SIMD)
+  if (const char* e = std::getenv("UWT_COARSE_BATCH_PX")) c->coarse_batch_px = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("UWT_SPLIT_MIN")) c->split_min = std::max(1, std::atoi(e));
   if (const char* e = std::getenv("UWT_SPLIT_MIN_PX")) c->split_min_px = std::max(1LL, std::atoll(e));
   CREATE_CHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));

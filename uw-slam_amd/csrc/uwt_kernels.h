@@ -1931,11 +1931,24 @@ struct CoarseArgs {
   float initial_error;
   int inline_pairs;                    // see IterArgs
   int pair_slots[4];
+  int resume;                          // 1: continue from state_out[pair] instead of starting the alignment
 };
 
-template <bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE>
+// PASS: rows per LDS pass of the block reduction: kIteratePass (61 KB, the block alone on its CU: a lone pair) or 14 (35 KB,
+// four blocks per CU: the batch form, one block per pair of a whole batch — round 3)
+// NLEV: levels the launch can run (the loop over them is unrolled).  The batch form (one block per pair of a whole batch, one
+// level per launch, PASS 14) stays at ~210 registers, two waves per SIMD: forced to 128 it spills and loses (measured), so it
+// pays only on the smallest levels, where the per-evaluation launches run furthest below the level-0 rate.
+template <bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS, int NLEV>
+__device__ __forceinline__ void coarse_body(const CoarseArgs& ca);
+
+template <bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS = kIteratePass, int NLEV = kCoarseMaxLevels>
 __global__ UWT_RESIDUAL_BOUNDS void k_coarse(const CoarseArgs ca) {
-  constexpr int kLds = iterate_lds_bytes(kIteratePass);
+  coarse_body<DEPTH, UNIT_FACTORS, AccT, SQUARE, PASS, NLEV>(ca);
+}
+template <bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS, int NLEV>
+__device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
+  constexpr int kLds = iterate_lds_bytes(PASS);
   __shared__ __attribute__((aligned(16))) unsigned char lds[kLds + kRecWords * 4 + 64];
   uint32_t* rec = reinterpret_cast<uint32_t*>(lds + kLds);                     // the evaluation's record
   PairState* cur = reinterpret_cast<PairState*>(lds + kLds + kRecWords * 4);   // the state update_compute reads
@@ -1943,15 +1956,19 @@ __global__ UWT_RESIDUAL_BOUNDS void k_coarse(const CoarseArgs ca) {
   const int ref_slot = ca.inline_pairs ? (lp == 0 ? ca.pair_slots[0] : ca.pair_slots[2]) : ca.lv[0].ref_slots[pair];
   const int tgt_slot = ca.inline_pairs ? (lp == 0 ? ca.pair_slots[1] : ca.pair_slots[3]) : ca.lv[0].tgt_slots[pair];
   PairState st;
-  pose_identity(st.pose);  // src/Tracker.cpp:385
-  st.last_error = ca.initial_error;
-  st.error = 0.f;
-  st.level_done = 0;
-  st.status = 0;
-  st.iters = 0;
-  st.n_valid = 0;
+  if (ca.resume) {
+    st = ca.state_out[pair];   // a level of a batch behind the coarser one's launch: re-armed by that launch's tail
+  } else {
+    pose_identity(st.pose);  // src/Tracker.cpp:385
+    st.last_error = ca.initial_error;
+    st.error = 0.f;
+    st.level_done = 0;
+    st.status = 0;
+    st.iters = 0;
+    st.n_valid = 0;
+  }
 #pragma unroll
-  for (int li = 0; li < kCoarseMaxLevels; li++) {
+  for (int li = 0; li < NLEV; li++) {
     if (li >= ca.n_levels) break;   // block-uniform
     ResidualArgs a = ca.lv[li];
     a.slices = 1;
@@ -1965,7 +1982,7 @@ __global__ UWT_RESIDUAL_BOUNDS void k_coarse(const CoarseArgs ca) {
       for (int k = 0; k < u.max_iters; k++) {
         __syncthreads();   // every thread has taken the state out of the update's LDS bytes: they become the reduction's
         if (threadIdx.x == 0) *cur = st;
-        residual_core<4, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, false, kIteratePass>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot);
+        residual_core<4, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot);
         __syncthreads();   // the record and the state are in LDS; the reduction's image is free
         u.k = k;
         st = update_compute(u, rec, cur, lds, false);   // ends with a barrier: every thread has the new state
