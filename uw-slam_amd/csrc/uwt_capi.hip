@@ -95,6 +95,8 @@ struct uwt_ctx {
   int coarse_batch_px = 0;              // batches: levels of up to this many pixels run in one k_coarse launch (UWT_COARSE_BATCH_PX)
   int pair_slots[4] = {0, 0, 0, 0};
   int first_poll = 3;                   // evaluations of a level before the first early-exit read-back
+  unsigned poll_seq = 0;                // batch path: read-backs alternate between two counters / events (taken one evaluation late)
+  hipEvent_t ev_poll[2] = {};
   int chained = -1;                     // -1: chained flow for a few pairs (takes_chained_flow); UWT_CHAINED=1 / 0: always / never (A/B runs)
   const uint32_t* prof_records = nullptr;
   bool compute_only = false;            // uwt_profile_enable(ctx, 2): residual launches run their no-memory diagnostic twin
@@ -715,7 +717,12 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
       // Early exit: the host reads back how many pairs are still iterating after the update of evaluation first_poll - 1,
       // then after twice as many, ...  With the reference's constants a level ends at its third evaluation as a rule
       // (error rises or stalls, src/Tracker.cpp:508), so the first look comes after three (UWT_FIRST_POLL).
+      // The read-back is taken one evaluation late (round 3): the count of evaluation k is copied to page-locked memory
+      // behind its update, evaluation k + 1 is enqueued, and only then does the host wait for the copy — the GPU works on
+      // k + 1 meanwhile instead of idling for the host's round trip (~25 us per look).  When the count says "nobody left",
+      // evaluation k + 1 has been enqueued for nothing: its blocks see level_done and return at once (a few us).
       int next_poll = c->first_poll;
+      int pending = -1;   // slot of the look not yet taken
       for (int k = 0; k < p.max_iters; k++) {
         size_t ev = 0;
         if (c->profiling) {
@@ -736,14 +743,22 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         if (general) ua.general = 1;
         ua.k = k;
         const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
-        ua.active = poll ? c->d_active : nullptr;
-        if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
+        const int slot = c->poll_seq & 1;
+        ua.active = poll ? c->d_active + slot : nullptr;
+        if (poll) HIPCHK(c, hipMemsetAsync(c->d_active + slot, 0, sizeof(int), c->stream));
         hipLaunchKernelGGL(k_gn_update, dim3(cnt), dim3(kUpdateBlock), 0, c->stream, ua);
         HIPCHK(c, hipGetLastError());
-        if (poll) {  // reference-mode early exit: stop launching once every pair has left this level
-          HIPCHK(c, hipMemcpyAsync(c->h_active, c->d_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-          HIPCHK(c, hipStreamSynchronize(c->stream));
-          if (*c->h_active == 0) break;
+        if (pending >= 0) {   // the look at the evaluation before this one, taken while this one runs
+          HIPCHK(c, hipEventSynchronize(c->ev_poll[pending]));
+          const bool nobody_left = c->h_active[pending] == 0;
+          pending = -1;
+          if (nobody_left) break;   // reference-mode early exit: every pair has left this level
+        }
+        if (poll) {
+          HIPCHK(c, hipMemcpyAsync(c->h_active + slot, c->d_active + slot, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+          HIPCHK(c, hipEventRecord(c->ev_poll[slot], c->stream));
+          pending = slot;
+          c->poll_seq++;
           next_poll *= 2;
         }
       }
@@ -1045,7 +1060,8 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->state2, sizeof(PairState) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_poses, sizeof(float) * 7 * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_stats, sizeof(StatsOut) * p->max_pairs));
-  CREATE_CHK(hipMalloc((void**)&c->d_active, sizeof(int)));
+  CREATE_CHK(hipMalloc((void**)&c->d_active, 2 * sizeof(int)));
+  for (int i = 0; i < 2; i++) CREATE_CHK(hipEventCreateWithFlags(&c->ev_poll[i], hipEventDisableTiming));
   CREATE_CHK(hipHostMalloc((void**)&c->h_small, sizeof(uwt_ctx::SmallResults)));
   CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_small, c->h_small, 0));
   if (const char* e = std::getenv("UWT_TARGET_BLOCKS")) c->target_blocks = std::max(1, std::atoi(e));  // tuning experiments only
@@ -1054,7 +1070,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->scale, sizeof(PairScale) * p->max_pairs));
     CREATE_CHK(hipMemset(c->scale, 0, sizeof(PairScale) * p->max_pairs));
   }
-  CREATE_CHK(hipHostMalloc((void**)&c->h_active, sizeof(int)));
+  CREATE_CHK(hipHostMalloc((void**)&c->h_active, 2 * sizeof(int)));
   CREATE_CHK(hipHostMalloc((void**)&c->h_pairs, sizeof(int) * 2 * p->max_pairs * uwt_ctx::kPairStages));
   std::memset(c->h_pairs, 0xff, sizeof(int) * 2 * p->max_pairs * uwt_ctx::kPairStages);
 #undef CREATE_CHK
@@ -1085,6 +1101,8 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stats) (void)hipFree(c->d_stats);
   if (c->d_active) (void)hipFree(c->d_active);
+  for (int i = 0; i < 2; i++)
+    if (c->ev_poll[i]) (void)hipEventDestroy(c->ev_poll[i]);
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->hist) (void)hipFree(c->hist);
   if (c->scale) (void)hipFree(c->scale);
