@@ -36,7 +36,7 @@ ALG_BYTES_PER_PIXEL_ITER = 10          # I_ref 1 + gx 2 + gy 2
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0                  # MI355X_MICROARCH.md §Chip-level parameters: measured copy ceiling
 # Static facts about the dominant kernel that cannot be measured from inside this process; each names its source file.
-PROFILE_FACTS = os.path.join(ROOT, "profiles", "r02", "k_residual_facts.json")
+PROFILE_FACTS = os.path.join(ROOT, "profiles", "r03", "k_residual_facts.json")
 
 
 def parse_args(argv=None):
@@ -404,6 +404,14 @@ def main(args):
                 if k in facts:
                     valu[k] = facts[k]
             roof["valu"] = valu
+            if args.reference_schedule:
+                # early exit: a launch is counted (and its level's pixels with it) whether or not its pairs have already left
+                # the level, so bytes / time overstates what the kernel moved; the durations stay, the fractions go
+                for k in ("achieved", "frac", "frac_of_measured_copy_peak", "frac_counter_bytes"):
+                    roof[k] = None
+                for e in roof["per_level"]:
+                    e["algorithmic_GBs"] = None
+                roof["note"] = "early-exit schedule: launches whose pairs have left the level fall through; no meaningful bytes per launch"
             out["roofline"] = roof
         if world == 1 and args.cpu_pairs > 0:
             from oracle import oracle as O          # test infrastructure, used here only as the timed CPU baseline/checker

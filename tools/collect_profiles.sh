@@ -1,11 +1,12 @@
 #!/bin/bash
 # Collect the round's profiles on the GPU box (run from the repo root through gpurun):
 #   tools/collect_profiles.sh <out dir under gpurun_out>
+# (round 3: + bilinear+huber, SQ counters of the robust-weight kernels)
 # kernel-trace statistics and the bench line of the default workload and of the other quoted configurations, HBM
 # traffic counters (separate --pmc passes, never together with other trace domains), SQ counters of the residual kernel.
 set -u
 R=$(pwd)
-out=$R/gpurun_out/${1:-prof_r02}
+out=$R/gpurun_out/${1:-prof_r03}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 stats() {  # name, bench args...
@@ -19,6 +20,7 @@ stats tukey_p256 --weights tukey --pairs 256 --cpu-pairs 8 --unique 8
 stats huber_p256 --weights huber --pairs 256 --cpu-pairs 8 --unique 8
 stats bilinear_p256 --bilinear --pairs 256 --cpu-pairs 8 --unique 8
 stats nodepth_p1024 --no-depth --cpu-pairs 16
+stats bilinear_huber_p256 --bilinear --weights huber --pairs 256 --cpu-pairs 8 --unique 8
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd $R && rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c --output-format csv -- python3 bench.py --cpu-pairs 0 --steps 2 --warmup 1 --no-profile > $out/pmc_$c.log 2>&1)
 done
@@ -31,6 +33,10 @@ cd $R
 python3 tools/pmc_summary.py $out/pmc_FETCH_SIZE $out/pmc_fetch.csv
 python3 tools/pmc_summary.py $out/pmc_WRITE_SIZE $out/pmc_write.csv
 python3 tools/sq_summary.py $out/sq k_residual $((1024*640*480)) $out/sq_counters_k_residual_level0_p1024.csv
+# the robust-weight path: level-0 launches of the scale pass and of the weighted accumulation at 256 pairs
+bash tools/exp/r3_sq.sh ${1:-prof_r03}/sq_huber k_resid_hist_v --pairs 256 --unique 8 --weights huber > /dev/null 2>&1
+python3 tools/sq_summary.py $out/sq_huber k_resid_hist_v $((256*640*480)) $out/sq_counters_k_resid_hist_v_level0_p256_huber.csv
+python3 tools/sq_summary.py $out/sq_huber "k_residual<" $((256*640*480)) $out/sq_counters_k_residual_weighted_level0_p256_huber.csv
 # keep what travels back small: the statistics tables, not the raw traces
 find $out -name "*kernel_trace.csv" -size +20M -delete
 find $out -name "*counter_collection.csv" -size +20M -delete

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r02/k_residual_facts.json from the round's counter summaries: the static facts about the dominant kernel that
+"""profiles/<round>/k_residual_facts.json from the round's counter summaries: the static facts about the dominant kernel that
 bench.py quotes with their source (HBM bytes per pixel-iteration from the FETCH_SIZE / WRITE_SIZE passes, instruction
 mix from the SQ passes).
 
@@ -22,11 +22,15 @@ def main(d):
     # KiB per dispatch, weighted by dispatch count = bytes of all residual launches of the run
     kib = sum(2.0 * m * n for _, m, n in fetch) + sum(m * n for _, m, n in write)   # x2: gfx950 FETCH_SIZE correction
     launches = sum(n for _, _, n in fetch)
-    px_per_4_levels = 1024 * (640 * 480 + 320 * 240 + 160 * 120 + 80 * 60)
-    pixels = px_per_4_levels * launches / 4.0
+    # levels the k_residual launches cover: 0..3 in rounds 1-2 (level 3 shows as a smaller grid); from round 3 the coarsest
+    # level of a batch runs in k_coarse, and k_residual launches cover levels 0..2, all at one grid size
+    grids = sorted({g for g, _, _ in fetch})
+    n_lv = 4 if len(grids) > 1 else 3
+    px_levels = 1024 * sum((640 >> l) * (480 >> l) for l in range(n_lv))
+    pixels = px_levels * launches / float(n_lv)
     facts = {
         "hbm_bytes_per_pixel_iteration": round(kib * 1024.0 / pixels, 3),
-        "hbm_bytes_source": "profiles/r02/pmc_fetch_bench_default_p1024.csv + pmc_write_bench_default_p1024.csv "
+        "hbm_bytes_source": d.rstrip("/") + "/pmc_fetch_bench_default_p1024.csv + pmc_write_bench_default_p1024.csv "
                             "(2 x FETCH_SIZE + WRITE_SIZE, KiB, separate --pmc passes of bench.py at its defaults)",
     }
     sq = os.path.join(d, "sq_counters_k_residual_level0_p1024.csv")
@@ -39,7 +43,7 @@ def main(d):
             vals[name] = float(per_px)
         facts["valu_instructions_per_pixel"] = round(vals["SQ_INSTS_VALU"], 2)
         facts["f64_fma_per_pixel"] = round(vals["SQ_INSTS_VALU_FMA_F64"], 2)
-        facts["instruction_mix_source"] = "profiles/r02/sq_counters_k_residual_level0_p1024.csv (SQ_INSTS_VALU, SQ_INSTS_VALU_FMA_F64 per lane-pixel, level-0 launches)"
+        facts["instruction_mix_source"] = d.rstrip("/") + "/sq_counters_k_residual_level0_p1024.csv (SQ_INSTS_VALU, SQ_INSTS_VALU_FMA_F64 per lane-pixel, level-0 launches)"
     json.dump(facts, open(os.path.join(d, "k_residual_facts.json"), "w"), indent=1)
     print(json.dumps(facts, indent=1))
 

@@ -1495,9 +1495,6 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
     }
   };
   load_planes(g_begin + (int)threadIdx.x);
-#ifdef UWT_EXP_HIST_NOATOMIC
-  unsigned exp_sink = 0;
-#endif
   for (int g = g_begin + (int)threadIdx.x; g < g_end; g += kBlock) {
     const uint32_t idx = (uint32_t)g * VEC;
     const uint32_t y = __umulhi(idx, L.magic), x = idx - y * L.w;
@@ -1529,12 +1526,24 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
       if constexpr (DEPTH) z = z * bc<F>(L.zscale);
       // the reciprocal's clamp and its select are of no use here: only x2, y2 (the sample position) are read
       pixel_warp_raw<F>(L, K, xf, bc<F>((float)y), z, okin_m, x2u, y2u, izu, okm);
+      if constexpr (SAMPLER == 0) {
+        // nothing of an invalid pixel is sanitised: its sample index is clamped both ways (any in-range byte will do) and
+        // its count is added under an EXEC mask of the valid lanes, like the sums of the accumulation kernel
 #pragma unroll
-      for (int c = 0; c < N; c++) {
-        put(x2u, c, keep_f(get(x2u, c), okm[c]));
-        put(y2u, c, keep_f(get(y2u, c), okm[c]));
+        for (int c = 0; c < N; c++) {
+          int ix2 = round_pos(get(x2u, c)), iy2 = round_pos(get(y2u, c));
+          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(ix2) : "s"(L.w - 1));
+          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy2) : "s"(L.h - 1));
+          gidx[u * N + c] = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+          put(x2u, c, keep_f(get(x2u, c), okm[c]));
+          put(y2u, c, keep_f(get(y2u, c), okm[c]));
+        }
+        pixel_gather_index<F>(L, x2u, y2u, &gidx[u * N]);
       }
-      pixel_gather_index<F>(L, x2u, y2u, &gidx[u * N]);
 #pragma unroll
       for (int c = 0; c < N; c++) {
         x2[u * N + c] = get(x2u, c);
@@ -1545,23 +1554,19 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
     if constexpr (SAMPLER == 0) {
       int q[VEC];
 #pragma unroll
-#ifdef UWT_EXP_HIST_NOGATHER
-      for (int j = 0; j < VEC; j++) q[j] = (int)(gidx[j] & 255u);
-#else
       for (int j = 0; j < VEC; j++) q[j] = (int)I2[gidx[j]];
-#endif
       __builtin_amdgcn_sched_barrier(0);
       load_planes(g + kBlock);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
-        int b = q[j] - (int)i1[j];
-        asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(b) : "v"(kTrash), "s"(okv[j]));   // valid ? r : the spare bin
-#ifdef UWT_EXP_HIST_NOATOMIC
-        exp_sink += (unsigned)b;
-#else
-        atomicAdd(&myh[b * kHistRep], 1u);
-#endif
+        const int b = q[j] - (int)i1[j];   // in [-255, 255] for any two bytes: a bin of this thread's replica whatever the validity
+        const unsigned addr = (unsigned)(uintptr_t)(myh + b * kHistRep);   // LDS byte address (the low 32 bits of the pointer)
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %0, %1\n\t"
+                     "ds_add_u32 %2, %3\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(saved) : "s"(okv[j]), "v"(addr), "v"(1u) : "scc", "memory");
       }
     } else {
       float rf[VEC];
@@ -1578,9 +1583,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
       }
     }
   }
-#ifdef UWT_EXP_HIST_NOATOMIC
-  atomicAdd(&h[(exp_sink & 255u) * kHistRep], 1u);
-#endif
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the masked ds_add_u32 above are the asm's own: the compiler does not count them
   __syncthreads();
   unsigned int* gh = hist + (size_t)pair * kHistBins;
   // This block's counts must be performed (at the device's coherence point, where atomics execute) before its ticket is
