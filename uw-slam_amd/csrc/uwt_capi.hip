@@ -92,6 +92,13 @@ struct uwt_ctx {
   bool inline_pairs = false;
   bool deferred = false;                // uwt_set_deferred: stage calls return once enqueued
   bool coarse = true;                   // k_coarse for the coarsest levels of the chained flow (UWT_NO_COARSE=1: off)
+  bool fused = false;                   // UWT_FUSED=1: robust weights through k_residual_fused (scale pass + weighted accumulation in one
+                                        // launch); built in round 3, bit-identical, and slower than the two launches (37 k against 47 k
+                                        // alignments/s at 256 pairs): off unless asked for
+  unsigned long long* d_ready = nullptr;   // [max_pairs] {epoch, 1 / MAD} words of k_residual_fused
+  int* d_fused_err = nullptr;           // raised by a block whose poll ran out
+  unsigned fused_epoch = 0;
+  bool fused_used = false;              // a fused launch has been enqueued since the flag was last looked at
   int coarse_batch_px = 0;              // batches: levels of up to this many pixels run in one k_coarse launch (UWT_COARSE_BATCH_PX)
   int pair_slots[4] = {0, 0, 0, 0};
   int first_poll = 3;                   // evaluations of a level before the first early-exit read-back
@@ -365,11 +372,53 @@ void launch_general_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sam
   }
 }
 
+// Robust weights over integer residuals take the fused launch (k_residual_fused: scale pass and weighted accumulation in one,
+// a pair's blocks waiting for the pair's scale) on the levels where a pair's blocks — kFusedG groups per thread each — are
+// few enough to be resident together many times over, and where the records the context holds per pair suffice.
+constexpr int kFusedMaxSlices = 256;
+int fused_slices(const uwt_ctx* c, int lvl) {
+  const int n_groups = c->lv[lvl].n / 4;
+  return (n_groups + kFusedG * kBlock - 1) / (kFusedG * kBlock);
+}
+bool takes_fused(const uwt_ctx* c, int lvl) {
+  if (!c->fused || c->vec != 4 || !c->p.weights || c->p.sampler || !c->p.accumulate_f64 || c->compute_only) return false;
+  const int sl = fused_slices(c, lvl);
+  return sl <= kFusedMaxSlices && sl <= c->slices[lvl];
+}
+
+template <bool DEPTH, bool UNIT>
+void launch_fused_t(hipStream_t s, const ResidualArgs& a, const FusedArgs& fa, int n_pairs) {
+  const dim3 grid(a.slices, n_pairs), blk(kBlock);
+  const bool sq = UNIT && a.L.fx == a.L.fy;
+  if (fa.weights == kWeightsTukeyRef) {
+    if (sq) hipLaunchKernelGGL((k_residual_fused<DEPTH, UNIT, true, kWeightsTukeyRef>), grid, blk, 0, s, a, fa);
+    else hipLaunchKernelGGL((k_residual_fused<DEPTH, UNIT, false, kWeightsTukeyRef>), grid, blk, 0, s, a, fa);
+  } else {
+    if (sq) hipLaunchKernelGGL((k_residual_fused<DEPTH, UNIT, true, kWeightsHuber>), grid, blk, 0, s, a, fa);
+    else hipLaunchKernelGGL((k_residual_fused<DEPTH, UNIT, false, kWeightsHuber>), grid, blk, 0, s, a, fa);
+  }
+}
+
 // The alignment loop's launch on the general path: the scale pass (weights only), then the dense kernel specialised for
 // the sampler / weights.  Same slicing as the fast path.
-int launch_general(uwt_ctx* c, const ResidualArgs& ra, int n_pairs) {
+int launch_general(uwt_ctx* c, const ResidualArgs& ra, int n_pairs, bool fused = false) {
   const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f);
   GeneralArgs ga = general_args(c);
+  if (fused) {   // (the caller sliced the level for it: kFusedG groups per thread)
+    FusedArgs fa;
+    fa.hist = c->hist;
+    fa.ready = c->d_ready;
+    fa.scale_out = c->scale;
+    fa.error = c->d_fused_err;
+    if (++c->fused_epoch == 0) ++c->fused_epoch;
+    fa.epoch = c->fused_epoch;
+    fa.weights = ga.weights;
+    c->fused_used = true;
+    if (depth) { if (unit) launch_fused_t<true, true>(c->stream, ra, fa, n_pairs); else launch_fused_t<true, false>(c->stream, ra, fa, n_pairs); }
+    else { if (unit) launch_fused_t<false, true>(c->stream, ra, fa, n_pairs); else launch_fused_t<false, false>(c->stream, ra, fa, n_pairs); }
+    HIPCHK(c, hipGetLastError());
+    return UWT_OK;
+  }
   if (ga.weights) {
     // the scale pass: residual histograms per pair, the scale derived in the tail of the pair's last block; the histograms
     // are all-zero before and after (cleared once per alignment call, enqueue_estimate)
@@ -629,6 +678,11 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
                         ? 1 : std::min(c->split, n_pairs / std::max(1, c->split_min));
   const int target_blocks = c->target_blocks ? c->target_blocks : (parts >= 2 ? 1024 : 4096);
   auto slicing = [&](int lvl, int& groups_per_block, int& slices) {
+    if (general && takes_fused(c, lvl)) {   // the fused robust launch: what a block can keep on chip between its two phases
+      groups_per_block = kFusedG * kBlock;
+      slices = fused_slices(c, lvl);
+      return;
+    }
     const int n_groups = c->lv[lvl].n / c->vec;
     int want = (target_blocks + n_pairs - 1) / n_pairs;
     want = std::max(1, std::min(want, c->slices[lvl]));
@@ -733,7 +787,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
           c->prof_pairs = cnt;
           c->prof_records = c->partials;
         }
-        int st = general ? launch_general(c, ra, cnt) : launch_residual(c, ra, cnt, false);
+        int st = general ? launch_general(c, ra, cnt, takes_fused(c, lvl)) : launch_residual(c, ra, cnt, false);
         if (st) return st;
         if (c->profiling) {
           HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
@@ -829,7 +883,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
       for (int i = 0; i < parts && st == UWT_OK; i++) {
         Part& q = pt[i];
         c->stream = q.s;      // every launch helper enqueues on c->stream
-        st = general ? launch_general(c, q.ra, q.cnt) : launch_residual(c, q.ra, q.cnt, false);
+        st = general ? launch_general(c, q.ra, q.cnt, takes_fused(c, lvl)) : launch_residual(c, q.ra, q.cnt, false);
         c->stream = main_stream;
         if (st) break;
         q.ua.k = k;
@@ -1029,6 +1083,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   if (const char* e = std::getenv("UWT_SPLIT")) c->split = std::max(1, std::min(uwt_ctx::kMaxParts, std::atoi(e)));
   if (std::getenv("UWT_NO_COARSE")) c->coarse = false;
+  if (std::getenv("UWT_FUSED")) c->fused = true;
   c->coarse_batch_px = kCoarseMaxPixels;   // e.g. level 3 of 640x480: +0.8 % on the default batch; larger levels lose (2 waves / SIMD)
   if (const char* e = std::getenv("UWT_COARSE_BATCH_PX")) c->coarse_batch_px = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("UWT_SPLIT_MIN")) c->split_min = std::max(1, std::atoi(e));
@@ -1069,6 +1124,10 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->hist, sizeof(unsigned int) * kHistBins * p->max_pairs));
     CREATE_CHK(hipMalloc((void**)&c->scale, sizeof(PairScale) * p->max_pairs));
     CREATE_CHK(hipMemset(c->scale, 0, sizeof(PairScale) * p->max_pairs));
+    CREATE_CHK(hipMalloc((void**)&c->d_ready, sizeof(unsigned long long) * p->max_pairs));
+    CREATE_CHK(hipMemset(c->d_ready, 0, sizeof(unsigned long long) * p->max_pairs));
+    CREATE_CHK(hipMalloc((void**)&c->d_fused_err, sizeof(int)));
+    CREATE_CHK(hipMemset(c->d_fused_err, 0, sizeof(int)));
   }
   CREATE_CHK(hipHostMalloc((void**)&c->h_active, 2 * sizeof(int)));
   CREATE_CHK(hipHostMalloc((void**)&c->h_pairs, sizeof(int) * 2 * p->max_pairs * uwt_ctx::kPairStages));
@@ -1106,6 +1165,8 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->hist) (void)hipFree(c->hist);
   if (c->scale) (void)hipFree(c->scale);
+  if (c->d_ready) (void)hipFree(c->d_ready);
+  if (c->d_fused_err) (void)hipFree(c->d_fused_err);
   if (c->h_active) (void)hipHostFree(c->h_active);
   if (c->h_pairs) (void)hipHostFree(c->h_pairs);
   if (c->scratch) (void)hipFree(c->scratch);
@@ -1154,6 +1215,10 @@ int uwt_update_params(uwt_ctx* c, const uwt_params* p) {
     HIPCHK(c, hipMalloc((void**)&c->hist, sizeof(unsigned int) * kHistBins * o.max_pairs));
     HIPCHK(c, hipMalloc((void**)&c->scale, sizeof(PairScale) * o.max_pairs));
     HIPCHK(c, hipMemset(c->scale, 0, sizeof(PairScale) * o.max_pairs));
+    HIPCHK(c, hipMalloc((void**)&c->d_ready, sizeof(unsigned long long) * o.max_pairs));
+    HIPCHK(c, hipMemset(c->d_ready, 0, sizeof(unsigned long long) * o.max_pairs));
+    HIPCHK(c, hipMalloc((void**)&c->d_fused_err, sizeof(int)));
+    HIPCHK(c, hipMemset(c->d_fused_err, 0, sizeof(int)));
   }
   c->p = *p;
   return UWT_OK;
@@ -1340,6 +1405,17 @@ int uwt_apply_gradient(uwt_ctx* c, int32_t first_slot, int32_t n) {
   return UWT_OK;
 }
 
+// after a wait for the context's stream: has a block of a fused robust launch given up waiting for its pair's scale?
+static int check_fused(uwt_ctx* c) {
+  if (!c->fused_used) return UWT_OK;
+  c->fused_used = false;
+  int e = 0;
+  HIPCHK(c, hipMemcpy(&e, c->d_fused_err, sizeof(int), hipMemcpyDeviceToHost));
+  if (!e) return UWT_OK;
+  HIPCHK(c, hipMemset(c->d_fused_err, 0, sizeof(int)));
+  return fail(c, UWT_ERR_HIP, "k_residual_fused: a pair's scale never arrived (blocks of a pair not resident together?); unset UWT_FUSED");
+}
+
 int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
                             float* poses_out, uwt_stats* stats_out) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
@@ -1391,6 +1467,8 @@ int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slot
     st = prof_collect(c);
     if (st) return st;
   }
+  st = check_fused(c);
+  if (st) return st;
   int worst = UWT_OK;
   for (int i = 0; i < n_pairs; i++) {
     if (stats_out) stats_out[i] = tmp[i];
@@ -1507,8 +1585,11 @@ int uwt_sync(uwt_ctx* c) {
   (void)hipSetDevice(c->p.device);
   HIPCHK(c, hipStreamSynchronize(c->copy));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  if (c->profiling) return prof_collect(c);
-  return UWT_OK;
+  if (c->profiling) {
+    int st = prof_collect(c);
+    if (st) return st;
+  }
+  return check_fused(c);
 }
 
 int uwt_stream(uwt_ctx* c, void** out) {

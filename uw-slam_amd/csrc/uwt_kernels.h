@@ -1613,6 +1613,257 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
   if (lane == 0) scale_out[pair] = sc;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// k_residual_fused (round 3): the scale pass and the weighted accumulation of one evaluation in ONE launch, the warp
+// computed once.  Both passes are bound by vector-instruction issue (SQ counters: 37 + 90 instructions per pixel, the
+// VALU 75-90 % busy), and 30 of the scale pass's 37 are the warp, the validity tests and the sample index all over
+// again.  Handing (x2, y2, 1 / z2, r) from one pass to the other through HBM costs more than it saves (14 B per pixel each
+// way against 8 B of compulsory traffic), so they stay on chip: a block takes kFusedG groups of 4 pixels per thread —
+// what fits — through phase 1 (warp, validity, sample, residual -> the pair's histogram), keeps x2, y2 in LDS and 1 / z2,
+// r, the validity masks in registers, waits for the pair's scale, and runs phase 2 (Jacobian, weight from the
+// per-residual-value table, masked sums) on what it kept.
+//
+// The wait: the pair's blocks add their counts to the pair's global bins and draw tickets (as k_resid_hist_v); the one
+// that draws the last derives the scale and publishes {epoch, 1 / MAD} as one 64-bit word; the others poll that word
+// (one lane, sc1 loads, s_sleep between).  This needs every block of a pair resident before any of them can finish:
+// blocks are dispatched in the order of their index, pair-major (x = slice runs fastest), per XCD in order — the
+// earliest unfinished pair therefore has all its blocks dispatched, finishes, and frees its slots; a level-0 pair of
+// 640x480 is 100 blocks, the chip holds 1024.  (The same forward-progress assumption decoupled look-back scans make.)
+// The poll is bounded: when it runs out the block gives up with NaN sums and raises `fused_error`, which fails the call —
+// a hang is not an outcome.
+//
+// MEASURED AND NOT THE DEFAULT (UWT_FUSED=1 selects it; tests/test_robust_bilinear.py keeps it bit-identical): 37.3 k against
+// 47.0 k alignments/s for Huber at 256 pairs of 640x480, 160 us against 85 + 43 us per evaluation.  What a block can keep on
+// chip is 12 pixels per thread, about 3 us of arithmetic of its own, and the chain it waits through — its counts to the
+// global bins (returning atomics), the ticket, the last block's scale, the poll that sees it — is 6-10 us during which the
+// blocks that share its CU, which belong to the same or the neighbouring pair and so sit at the same point of the same
+// chain, have nothing to issue either.  The two launches repeat 30 instructions per pixel and never wait.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int kFusedG = 3;                                   // groups of 4 pixels per thread (12 pixels: 24 KB of x2, y2 per block)
+constexpr int kFusedRep = 4;                                 // histogram replicas (8 KB: the bytes the weight table takes afterwards)
+constexpr int kFusedHistBytes = kHistBins * kFusedRep * 4;   // 8192
+constexpr int kFusedStashBytes = kFusedG * 4 * kBlock * 8;   // 24576
+constexpr int kFusedLdsBytes = (kFusedHistBytes + kFusedStashBytes) > kReduceLdsBytes ? (kFusedHistBytes + kFusedStashBytes) : kReduceLdsBytes;
+constexpr unsigned kFusedMaxPolls = 1u << 22;
+
+struct FusedArgs {
+  unsigned int* hist;              // [pair][kHistBins] (word 511: the pair's ticket counter), all-zero between evaluations
+  unsigned long long* ready;       // [pair] {epoch << 32 | bits(1 / MAD)} published by the pair's last block
+  PairScale* scale_out;            // [pair] (for the record; phase 2 takes the scale from `ready`)
+  int* error;                      // raised when a poll runs out
+  unsigned int epoch;              // this launch's number (never 0; the same value is not reused while a stale word could match)
+  int weights;
+};
+
+template <bool DEPTH, bool UNIT_FACTORS, bool SQUARE, int WEIGHTS>
+__global__ __launch_bounds__(kBlock) void k_residual_fused(const ResidualArgs a, const FusedArgs fa) {
+  static_assert(WEIGHTS == kWeightsTukeyRef || WEIGHTS == kWeightsHuber, "robust weights over integer residuals");
+  constexpr int VEC = 4, N = 2, NU = 2;
+  using F = v2f;
+  const int pair = (int)blockIdx.y + a.pair_base, slice = (int)blockIdx.x;
+  const PairState st = a.state[pair];
+  if (st.level_done || st.status) return;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kFusedLdsBytes];
+  __shared__ int s_last;
+  __shared__ float s_inv_mad;
+  unsigned int* h = reinterpret_cast<unsigned int*>(lds);                       // phase 1: histogram; phase 2: weight table
+  float2* stash = reinterpret_cast<float2*>(lds + kFusedHistBytes);             // x2, y2 of pixel (j, p) of thread t at [(j * 4 + p) * 256 + t]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < kHistBins * kFusedRep; i += kBlock) h[i] = 0;
+  WarpK K;
+  pose_to_T12(st.pose, K.T);
+#pragma unroll
+  for (int i = 0; i < 12; i++) K.T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(K.T[i])));
+  const LevelK L = a.L;
+  const int ref_slot = a.ref_slots[pair], tgt_slot = a.tgt_slots[pair];
+  const size_t ref_off = (size_t)ref_slot * L.n, tgt_off = (size_t)tgt_slot * L.n;
+  const uint8_t* __restrict__ I1 = a.img + ref_off;
+  const uint8_t* __restrict__ I2 = a.img + tgt_off;
+  const int16_t* __restrict__ GX = a.gx + ref_off;
+  const int16_t* __restrict__ GY = a.gy + ref_off;
+  const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
+  const int n_groups = L.n / VEC;
+  const int g_begin = slice * (kFusedG * kBlock), g_end = min(g_begin + kFusedG * kBlock, n_groups);
+  __syncthreads();
+
+  // ---- phase 1: warp, validity, sample, residual; counts into the block's histogram; x2, y2 -> LDS, 1 / z2, r, masks kept
+  float izs[kFusedG][VEC];
+  uint32_t rpk[kFusedG][2];              // (r + 255) of the four pixels, 16 bits each
+  unsigned long long okm[kFusedG][VEC];  // validity as wave masks (scalar registers)
+  uint32_t n_valid_wave = 0;
+  unsigned int* myh = h + 255 * kFusedRep + (tid & (kFusedRep - 1));
+#pragma unroll
+  for (int j = 0; j < kFusedG; j++) {
+    const int g = g_begin + j * kBlock + tid;
+    const unsigned long long active_mask = __builtin_amdgcn_sicmp(g, g_end, kIcmpSLT);
+    const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
+    const uint32_t y = __umulhi(idx, L.magic), x = idx - y * (uint32_t)L.w;
+    uint8_t i1[VEC];
+    uint16_t dp[VEC];
+    *reinterpret_cast<uint32_t*>(i1) = *reinterpret_cast<const uint32_t*>(I1 + idx);
+    if constexpr (DEPTH) *reinterpret_cast<uint2*>(dp) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(DP) + idx * 2u);
+    uint32_t gidx[VEC];
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      F z = bc<F>(1.0f), xf, x2u, y2u, izu;
+      unsigned long long okin[N];
+#pragma unroll
+      for (int c = 0; c < N; c++) {
+        const int p = u * N + c;
+        okin[c] = active_mask;
+        if constexpr (DEPTH) {
+          const int d = (int)(int16_t)dp[p];
+          okin[c] &= __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
+          put(z, c, (float)d);
+        }
+        put(xf, c, (float)x + (float)p);
+      }
+      if constexpr (DEPTH) z = z * bc<F>(L.zscale);
+      pixel_warp_raw<F>(L, K, xf, bc<F>((float)y), z, okin, x2u, y2u, izu, &okm[j][u * N]);
+#pragma unroll
+      for (int c = 0; c < N; c++) {
+        const int p = u * N + c;
+        float r = get(izu, c);
+        asm("v_max_f32 %0, 0, %0" : "+v"(r));   // "if (inv_z2 < 0) inv_z2 = 0" (:452-453)
+        izs[j][p] = r;
+        int ix2 = round_pos(get(x2u, c)), iy2 = round_pos(get(y2u, c));
+        asm("v_med3_i32 %0, %0, 0, %1" : "+v"(ix2) : "s"(L.w - 1));
+        asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy2) : "s"(L.h - 1));
+        gidx[p] = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;
+        stash[(j * VEC + p) * kBlock + tid] = make_float2(get(x2u, c), get(y2u, c));
+      }
+    }
+    int q[VEC];
+#pragma unroll
+    for (int p = 0; p < VEC; p++) q[p] = (int)I2[gidx[p]] - (int)i1[p];
+#pragma unroll
+    for (int p = 0; p < VEC; p++) {
+      const unsigned addr = (unsigned)(uintptr_t)(myh + q[p] * kFusedRep);
+      unsigned long long saved;
+      asm volatile("s_and_saveexec_b64 %0, %1\n\t"
+                   "ds_add_u32 %2, %3\n\t"
+                   "s_mov_b64 exec, %0"
+                   : "=&s"(saved) : "s"(okm[j][p]), "v"(addr), "v"(1u) : "scc", "memory");
+      n_valid_wave += (uint32_t)__builtin_popcountll(okm[j][p]);
+    }
+    rpk[j][0] = (uint32_t)(q[0] + 255) | ((uint32_t)(q[1] + 255) << 16);
+    rpk[j][1] = (uint32_t)(q[2] + 255) | ((uint32_t)(q[3] + 255) << 16);
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm's own ds_add_u32
+  __syncthreads();
+
+  // ---- the pair's histogram, the ticket, the scale (see k_resid_hist_v)
+  unsigned int* gh = fa.hist + (size_t)pair * kHistBins;
+  {
+    unsigned int seen = 0;
+    for (int i = tid; i < kHistBins - 1; i += kBlock) {
+      const uint4 v = *reinterpret_cast<const uint4*>(&h[i * kFusedRep]);
+      const unsigned int t = v.x + v.y + v.z + v.w;
+      if (t) seen |= atomicAdd(&gh[i], t);
+    }
+    if (seen == 0xffffffffu) s_last = 0;   // (never true: keeps the returns, i.e. the adds performed before the ticket)
+  }
+  __syncthreads();
+  if (tid == 0) s_last = atomicAdd(&gh[kHistTicketWord], 1u) == gridDim.x - 1 ? 1 : 0;
+  __syncthreads();
+  if (s_last) {
+    if (tid < 64) {
+      unsigned int mine[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int b = tid * 8 + k;
+        mine[k] = b < 511 ? atomicExch(&gh[b], 0u) : 0u;
+      }
+      if (tid == 0) atomicExch(&gh[kHistTicketWord], 0u);
+      const PairScale sc = wave_scale(mine, h, WEIGHTS == kWeightsTukeyRef, tid);   // (h: every wave is past its flush)
+      if (tid == 0) {
+        fa.scale_out[pair] = sc;
+        s_inv_mad = sc.inv_mad;
+        __hip_atomic_store(fa.ready + pair, ((unsigned long long)fa.epoch << 32) | (unsigned long long)__float_as_uint(sc.inv_mad),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else if (tid == 0) {
+    unsigned long long v = 0;
+    unsigned polls = 0;
+    for (;;) {
+      v = __hip_atomic_load(fa.ready + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned int)(v >> 32) == fa.epoch) break;
+      if (++polls > kFusedMaxPolls) {   // never seen; a lost forward-progress assumption must not hang the GPU
+        atomicOr(fa.error, 1);
+        v = 0x7fc00000ull;              // NaN scale: the sums come out NaN, the call fails
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    s_inv_mad = __uint_as_float((unsigned int)v);
+  }
+  __syncthreads();
+  const float inv_mad = s_inv_mad;
+
+  // ---- the weight table in the histogram's bytes: w, (r * gain) * w as f32, r * (r * w) as f64, one entry per residual value
+  float* tw = reinterpret_cast<float*>(lds);                 // [511]
+  float* trw = tw + 512;                                     // [511]
+  double* te = reinterpret_cast<double*>(lds + 4096);        // [511]
+  for (int i = tid; i < 511; i += kBlock) {
+    const float rf = (float)(i - 255);
+    const float w = robust_weight(WEIGHTS, rf, inv_mad);
+    tw[i] = w;
+    trw[i] = (rf * a.gain) * w;
+    te[i] = (double)rf * (double)(rf * w);
+  }
+  __syncthreads();
+
+  // ---- phase 2: Jacobian, weight, masked sums
+  double acc[kAccFloats];
+#pragma unroll
+  for (int i = 0; i < kAccFloats; i++) acc[i] = 0.0;
+  double err = 0.0;
+#pragma unroll
+  for (int j = 0; j < kFusedG; j++) {
+    const int g = g_begin + j * kBlock + tid;
+    const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
+    int16_t gxv[VEC], gyv[VEC];
+    *reinterpret_cast<uint2*>(gxv) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(GX) + idx * 2u);
+    *reinterpret_cast<uint2*>(gyv) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(GY) + idx * 2u);
+    F J[NU][6];
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      F x2u, y2u, izu, g0, g1, wv;
+#pragma unroll
+      for (int c = 0; c < N; c++) {
+        const int p = u * N + c;
+        const float2 xy = stash[(j * VEC + p) * kBlock + tid];
+        put(x2u, c, xy.x);
+        put(y2u, c, xy.y);
+        put(izu, c, izs[j][p]);
+        put(g0, c, (float)gxv[p]);
+        put(g1, c, (float)gyv[p]);
+        const uint32_t rb = (rpk[j][p >> 1] >> ((p & 1) * 16)) & 0xffffu;
+        put(wv, c, tw[rb]);
+      }
+      pixel_jacobian<UNIT_FACTORS, SQUARE, false, F>(L, a.zf, a.af, x2u, y2u, izu, g0, g1, J[u]);
+#pragma unroll
+      for (int k = 0; k < 6; k++) J[u][k] = wv * J[u][k];   // J <- w * J (src/Tracker.cpp:554-557)
+#pragma unroll
+      for (int c = 0; c < N; c++) {
+        const int p = u * N + c;
+        const uint32_t rb = (rpk[j][p >> 1] >> ((p & 1) * 16)) & 0xffffu;
+        double Jd[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) Jd[k] = (double)get(J[u][k], c);
+        masked_sums_lo(acc, Jd, okm[j][p]);
+        masked_sums_hi<1>(acc, err, Jd, (double)trw[rb], te[rb], okm[j][p]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  __syncthreads();   // the table and the stash become the reduction's image
+  const uint32_t n_valid = (tid & 63) == 0 ? n_valid_wave : 0u;
+  uint32_t* out_rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
+  block_reduce_store_at<double, true>(lds, acc, 0u, n_valid, out_rec, err);
+}
+
 // weighted / bilinear accumulation: J <- w·J, r <- gain·r, A = Σ(wJ)(wJ)ᵀ, jtr = Σ(wJ)·((gain r)·w) (src/Tracker.cpp:554-561),
 // error numerator Σ r·(r·w) (:499-502).  With identity weights this is the plain sum with float residuals.
 template <bool DEPTH, bool UNIT_FACTORS>
