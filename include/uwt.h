@@ -159,8 +159,9 @@ int uwt_estimate_pose_batch(uwt_ctx* ctx, int32_t n_pairs, const int32_t* ref_sl
  * System::AddFrame / System::Tracking do for each new frame.
  * Asynchronous with early_exit = 0 (fixed iteration counts: nothing in the call waits for the device).  With
  * early_exit = 1 — the reference's schedule, uwt_default_params' setting — the call itself waits for the device a few
- * times per level (after iterations 2, 4, 8, ... it reads back how many pairs are still iterating and stops launching for
- * a level every pair has left), so it returns only once the last level's first iterations are queued.
+ * times per level above 6144 pixels (after evaluations 3, 6, 12, ... it reads back how many pairs are still iterating — each
+ * look taken while the next evaluation already runs — and stops launching for a level every pair has left; smaller levels
+ * decide on the device), so it returns only once the last level's first iterations are queued.
  * Ordering against uwt_upload_frames_async covers every slot the call touches: the prepared range AND every slot the pair
  * lists name (they may lie outside the range). */
 int uwt_track_batch_async(uwt_ctx* ctx, int32_t first_slot, int32_t n_frames, int32_t grad_refs_only,

@@ -12,6 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 stats() {  # name, bench args...
   name=$1; shift
   (cd $R && rocprofv3 --kernel-trace --stats -d $out/stats_$name --output-format csv -- python3 bench.py "$@" > $out/bench_$name.json 2> $out/bench_$name.err)
+  (cd $R && python3 bench.py "$@" > $out/bench_${name}_no_profiler.json 2> $out/bench_${name}_no_profiler.err)   # the same line without the profiler
 }
 stats default_p1024
 stats cfg3_1280x960_l5_p256 --width 1280 --height 960 --levels 5 --pairs 256 --cpu-pairs 8 --unique 8
@@ -21,6 +22,7 @@ stats huber_p256 --weights huber --pairs 256 --cpu-pairs 8 --unique 8
 stats bilinear_p256 --bilinear --pairs 256 --cpu-pairs 8 --unique 8
 stats nodepth_p1024 --no-depth --cpu-pairs 16
 stats bilinear_huber_p256 --bilinear --weights huber --pairs 256 --cpu-pairs 8 --unique 8
+stats huber_p1024 --weights huber --cpu-pairs 8 --unique 8
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd $R && rocprofv3 --kernel-trace --pmc $c -d $out/pmc_$c --output-format csv -- python3 bench.py --cpu-pairs 0 --steps 2 --warmup 1 --no-profile > $out/pmc_$c.log 2>&1)
 done

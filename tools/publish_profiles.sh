@@ -9,6 +9,7 @@ for d in $src/stats_*; do
   f=$(find $d -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && cp $f $dst/kernel_stats_bench_$n.csv
   [ -f $src/bench_$n.json ] && cp $src/bench_$n.json $dst/bench_$n.json
+  [ -f $src/bench_${n}_no_profiler.json ] && cp $src/bench_${n}_no_profiler.json $dst/bench_${n}_no_profiler.json
 done
 cp $src/pmc_fetch.csv $dst/pmc_fetch_bench_default_p1024.csv
 cp $src/pmc_write.csv $dst/pmc_write_bench_default_p1024.csv
