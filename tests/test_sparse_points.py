@@ -176,3 +176,41 @@ def test_gpu_candidate_points_batch_of_frames_matches_oracle_per_frame(capi, O, 
     full, cnt2 = ctx.obtain_candidate_points_batch(2, 3, 0, 20.0)
     assert np.array_equal(cnt, cnt2) and all(np.array_equal(capped[f], full[f][:50]) for f in range(3))
     ctx.close()
+
+
+def test_oracle_add_patch_points_semantics(O):
+    w, h = 40, 30
+    pts = np.array([[3.4, 2.6, 0.7, 1.0], [0.2, 0.4, 1.5, 1.0], [39.2, 29.4, 0.9, 1.0], [20.5, 10.5, 1.1, 1.0]], np.float32)
+    got, n = O.add_patch_points(pts, w, h)
+    exp = [list(p) for p in pts]
+    for x, y, z, _ in pts:
+        x, y = np.float32(np.floor(x + 0.5)) if x >= 0 else x, np.float32(np.floor(y + 0.5)) if y >= 0 else y   # C round(), x, y >= 0
+        for i in range(int(x) - 2, int(x) + 3):
+            for j in range(int(y) - 2, int(y) + 3):
+                if 0 < i < w and 0 < j < h and not (i == x and j == y):
+                    exp.append([i, j, z, 1.0])
+    assert n == len(exp) and np.array_equal(got, np.array(exp, np.float32))
+    assert n == 4 + 24 + 4 + 8 + 24            # interior points: 24 cells; at (0, 0): the 2x2 cells with i, j > 0; at (39, 29): 3x3 - 1
+
+
+@pytest.mark.gpu
+def test_add_patch_points_matches_oracle_over_levels_sizes_and_caps(capi, O):
+    """uwt_add_patch_points = Tracker::AddPatchPointsFeatures (src/Tracker.cpp:599-629): the table, then per point the patch
+    cells inside the level except the centre, in the reference's push_back order; empty tables, borders, a cap smaller than
+    the full count, more points than one chunk of the kernel, other patch sizes."""
+    w, h = 160, 96
+    ctx = capi.Context(capi.default_params(w, h, 131.25, 131.25, 79.5, 47.5, max_frames=2, max_pairs=1))
+    rng = np.random.default_rng(77)
+    for lvl in (0, 1, 3):
+        L = ctx.level_info(lvl)
+        for n in (0, 1, 7, 300, 1000):
+            pts = np.column_stack([rng.uniform(-1, L.w + 1, n), rng.uniform(-1, L.h + 1, n), rng.uniform(0.5, 2.0, n), np.ones(n)]).astype(np.float32)
+            for ps in (5, 3, 1):
+                got, cnt = ctx.add_patch_points(lvl, pts, patch_size=ps)
+                want, n_want = O.add_patch_points(pts, L.w, L.h, patch_size=ps)
+                assert cnt == n_want and np.array_equal(got.view(np.uint32), want.view(np.uint32)), (lvl, n, ps)
+        pts = np.array([[10.4, 10.6, 1.0, 1.0], [0.0, 0.0, 2.0, 1.0]], np.float32)
+        got, cnt = ctx.add_patch_points(lvl, pts, cap=9)                 # full count reported, nine rows written
+        want, n_want = O.add_patch_points(pts, L.w, L.h, cap=9)
+        assert cnt == n_want > 9 and got.shape == (9, 4) and np.array_equal(got, want)
+    ctx.close()
