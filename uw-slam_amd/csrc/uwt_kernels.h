@@ -773,11 +773,14 @@ __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict_
   }
 }
 
+#ifndef UWT_EXP_PASS
+#define UWT_EXP_PASS 14
+#endif
 template <typename AccT, bool HAS_EXTRA = false, typename R2T = uint32_t>
 __device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], R2T sum_r2, uint32_t n_valid,
                                                    uint32_t* __restrict__ rec, AccT extra = (AccT)0) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kReduceLdsBytes];
-  block_reduce_store_at<AccT, HAS_EXTRA, 14, R2T>(lds, acc, sum_r2, n_valid, rec, extra);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[reduce_lds_bytes(UWT_EXP_PASS)];
+  block_reduce_store_at<AccT, HAS_EXTRA, UWT_EXP_PASS, R2T>(lds, acc, sum_r2, n_valid, rec, extra);
 }
 
 // robust weights / bilinear sampler shared by the dense kernels and the general (dump-capable) kernel
@@ -791,14 +794,21 @@ struct PairScale {
   int pad;
 };
 
-// EXTENSION: bilinear sample; same f32 operation order as the oracle's uwo_bilinear_u8
+// EXTENSION: bilinear sample; same f32 operation order as the oracle's uwo_bilinear_u8.  The four sample addresses are
+// 32-bit offsets from the level's base (no 64-bit address arithmetic per sample) and clamped both ways, so that a position
+// that has not been sanitised (an invalid pixel of the masked path: anything, NaN included) still reads inside the level.
 __device__ __forceinline__ float sample_bilinear(const uint8_t* __restrict__ I2, const LevelK& L, float x, float y) {
   const float x0 = floorf(x), y0 = floorf(y);
   const float ax = x - x0, ay = y - y0;
-  const int ix0 = min((int)x0, L.w - 1), iy0 = min((int)y0, L.h - 1);
+  int ix0, iy0;   // (the instruction saturates and maps NaN to 0; a C++ conversion of such a value would be undefined)
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(ix0) : "v"(x0));
+  asm("v_cvt_i32_f32 %0, %1" : "=v"(iy0) : "v"(y0));
+  asm("v_med3_i32 %0, %0, 0, %1" : "+v"(ix0) : "s"(L.w - 1));
+  asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy0) : "s"(L.h - 1));
   const int ix1 = min(ix0 + 1, L.w - 1), iy1 = min(iy0 + 1, L.h - 1);
-  const float a = (float)I2[iy0 * L.w + ix0], b = (float)I2[iy0 * L.w + ix1];
-  const float c = (float)I2[iy1 * L.w + ix0], d = (float)I2[iy1 * L.w + ix1];
+  const uint32_t r0 = __umul24((unsigned)iy0, (unsigned)L.w), r1 = __umul24((unsigned)iy1, (unsigned)L.w);
+  const float a = (float)I2[r0 + (unsigned)ix0], b = (float)I2[r0 + (unsigned)ix1];
+  const float c = (float)I2[r1 + (unsigned)ix0], d = (float)I2[r1 + (unsigned)ix1];
   const float top = __builtin_fmaf(ax, b - a, a);
   const float bot = __builtin_fmaf(ax, d - c, c);
   return __builtin_fmaf(ay, bot - top, top);
@@ -998,7 +1008,7 @@ template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot) {
   // MASKED: f64 sums added under an EXEC mask of the valid lanes (masked_sums_*), nothing of an invalid pixel sanitised
-  constexpr bool MASKED = std::is_same<AccT, double>::value && !DUMP && SAMPLER == 0;
+  constexpr bool MASKED = std::is_same<AccT, double>::value && !DUMP;
   WarpK K;
   pose_to_T12(pose, K.T);
 #pragma unroll
@@ -1067,7 +1077,8 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   constexpr int N = (VEC % 2 == 0) ? 2 : 1;
   using F = typename std::conditional<N == 2, v2f, float>::type;
   constexpr int NU = VEC / N;
-  for (int it = 0; it < iters; it++, g += kBlock) {
+  // one step of the loop on the planes in `rg`, which are re-requested in place for the group `ahead` steps on
+  auto body = [&](RefGroup<VEC>& rg, const int ahead) __attribute__((always_inline)) {
     const bool active = g < g_end;
     const unsigned long long active_mask = __builtin_amdgcn_sicmp(g, g_end, kIcmpSLT);
     const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
@@ -1138,7 +1149,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     // behind the gathers.  The request is unconditional (the index is clamped): inside a branch, the compiler's wait for
     // the gathers would have to assume the branch not taken and count the plane loads in.
     __builtin_amdgcn_sched_barrier(0);
-    load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, I1, GX, GY, DP, (uint32_t)min(g + kBlock, n_groups - 1) * VEC);
+    load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, I1, GX, GY, DP, (uint32_t)min(g + ahead * kBlock, n_groups - 1) * VEC);
     __builtin_amdgcn_sched_barrier(0);
     // phase 3: Jacobians (cover the gather latency)
     F J[NU][6];
@@ -1204,6 +1215,19 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
       } else if constexpr (!GENERAL) {
         ri = keep_i(i2[j] - (int)i1[j], okm[j]);
         accumulate(acc, Jp, ri);
+      } else if constexpr (MASKED) {
+        // float residuals (bilinear sampler) and / or weights evaluated per pixel: the same masked sums, fed with w * J,
+        // (r * gain) * w and the error term r * (r * w) (accumulate_weighted's operations, src/Tracker.cpp:499-502, 554-561)
+        float rf;
+        if constexpr (SAMPLER == 0) rf = (float)(i2[j] - (int)i1[j]);
+        else rf = s2[j] - (float)i1[j];
+        const float w = robust_weight(WEIGHTS, rf, inv_mad);
+        double Jd[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) Jd[k] = (double)(w * Jp[k]);
+        const double e = (double)rf * (double)(rf * w);
+        masked_sums_lo(acc, Jd, okm[j]);
+        masked_sums_hi<1>(acc, err, Jd, (double)((rf * a.gain) * w), e, okm[j]);
       } else {
         float rf;
         if constexpr (SAMPLER == 0) rf = (float)keep_i(i2[j] - (int)i1[j], okm[j]);
@@ -1230,7 +1254,22 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     const bool wrap = xf0 >= wf;
     xf0 -= wrap ? wf : 0.f;
     yf += wrap ? 1.f : 0.f;
+  };
+#ifdef UWT_EXP_PF2
+  // experiment: the planes two steps ahead (two register sets that take turns)
+  RefGroup<VEC> rgB;
+  load_group<VEC, DEPTH, COMPUTE_ONLY>(rgB, I1, GX, GY, DP, (uint32_t)min(g + kBlock, n_groups - 1) * VEC);
+  for (int it = 0; it < iters; it += 2) {
+    body(rg, 2);
+    g += kBlock;
+    if (it + 1 < iters) {
+      body(rgB, 2);
+      g += kBlock;
+    }
   }
+#else
+  for (int it = 0; it < iters; it++, g += kBlock) body(rg, 1);
+#endif
   const uint32_t n_valid = (threadIdx.x & 63) == 0 ? n_valid_wave : 0u;
   uint32_t* out_rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
 #ifdef UWT_EXP_STAMPS
@@ -1476,9 +1515,8 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
   const uint8_t* __restrict__ I1 = a.img + ref_off;
   const uint8_t* __restrict__ I2 = a.img + tgt_off;
   const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
-  // bin q of this thread's replica: myh[q * kHistRep]; an invalid pixel counts into the unused 512th bin (no branch)
+  // bin q of this thread's replica: myh[q * kHistRep]
   unsigned int* myh = h + 255 * kHistRep + (threadIdx.x & (kHistRep - 1));
-  constexpr int kTrash = (kHistBins - 1) - 255;
   const int n_groups = L.n / VEC;
   const int g_begin = blockIdx.x * a.groups_per_block, g_end = min(g_begin + a.groups_per_block, n_groups);
   // the planes of a thread's next group are requested behind this group's gathers, as in residual_core
@@ -1536,14 +1574,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
           asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy2) : "s"(L.h - 1));
           gidx[u * N + c] = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;
         }
-      } else {
-#pragma unroll
-        for (int c = 0; c < N; c++) {
-          put(x2u, c, keep_f(get(x2u, c), okm[c]));
-          put(y2u, c, keep_f(get(y2u, c), okm[c]));
-        }
-        pixel_gather_index<F>(L, x2u, y2u, &gidx[u * N]);
-      }
+      }   // (bilinear: sample_bilinear clamps its four addresses both ways; nothing to prepare)
 #pragma unroll
       for (int c = 0; c < N; c++) {
         x2[u * N + c] = get(x2u, c);
@@ -1577,9 +1608,14 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int j = 0; j < VEC; j++) {
-        int b = (int)rintf(rf[j]);
-        asm("v_cndmask_b32_e64 %0, %1, %0, %2" : "+v"(b) : "v"(kTrash), "s"(okv[j]));
-        atomicAdd(&myh[b * kHistRep], 1u);
+        int b;   // |rf| <= 255 on a valid lane; an invalid lane's may be NaN (its position was): the instruction maps that to 0, the count is masked out
+        asm("v_cvt_i32_f32 %0, %1" : "=v"(b) : "v"(rintf(rf[j])));
+        const unsigned addr = (unsigned)(uintptr_t)(myh + b * kHistRep);
+        unsigned long long saved;
+        asm volatile("s_and_saveexec_b64 %0, %1\n\t"
+                     "ds_add_u32 %2, %3\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(saved) : "s"(okv[j]), "v"(addr), "v"(1u) : "scc", "memory");
       }
     }
   }
