@@ -16,6 +16,8 @@ ap.add_argument("--mode", default="fixed")
 ap.add_argument("--depth", type=int, default=0)
 ap.add_argument("--seed0", type=int, default=1000)
 ap.add_argument("--single", type=int, default=0, help="1: one pair per synchronous call (the chained k_iterate flow)")
+ap.add_argument("--weights", type=int, default=0, help="0 identity, 1 Tukey (reference medians), 2 Huber")
+ap.add_argument("--sampler", type=int, default=0, help="0 nearest, 1 bilinear")
 a = ap.parse_args()
 w, h = a.w, a.h
 f = 525.0 * w / 640.0
@@ -26,18 +28,27 @@ else:
     over = dict()
 if a.depth:
     over["has_depth"] = 1
+if a.weights:
+    over["weights"] = a.weights
+if a.sampler:
+    over["sampler"] = a.sampler
 n = a.n
 ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
 po = O.default_params(w, h, *intr, **over)
 frames, depths, cpu = [], [], []
 t0 = time.time()
-for s in range(n):
-    ref, tgt, dep, _, _ = synth.render_pair(w, h, *intr, seed=a.seed0 + s, z=1.0 + 0.2 * ((s % 5) - 2) / 2, with_depth=bool(a.depth))
+pairs = [synth.render_pair(w, h, *intr, seed=a.seed0 + s, z=1.0 + 0.2 * ((s % 5) - 2) / 2, with_depth=bool(a.depth)) for s in range(n)]
+for ref, tgt, dep, _, _ in pairs:
     frames += [ref, tgt]
     if a.depth:
         depths += [dep, dep]
+def _cpu(i):                                    # the C oracle releases the GIL: every host core
+    ref, tgt, dep, _, _ = pairs[i]
     st, pose, tr = O.align_pair(po, ref, tgt, dep if a.depth else None, want_trace=True)
-    cpu.append((st, pose, len(tr)))
+    return st, pose, len(tr)
+from concurrent.futures import ThreadPoolExecutor
+with ThreadPoolExecutor(min(32, os.cpu_count() or 4)) as ex:
+    cpu = list(ex.map(_cpu, range(n)))
 t_cpu = time.time() - t0
 ctx.upload_frames(0, np.stack(frames), np.stack(depths) if a.depth else None)
 ctx.build_pyramids(0, 2 * n); ctx.apply_gradient(0, 2 * n)
@@ -58,7 +69,7 @@ dr = np.array([rot_angle(poses[i][:4], cpu[i][1][:4]) for i in range(n)])
 dt = np.array([np.linalg.norm(poses[i][4:].astype(np.float64) - cpu[i][1][4:]) for i in range(n)])
 bit = sum(np.array_equal(poses[i].view(np.uint32), cpu[i][1].view(np.uint32)) for i in range(n))
 it_eq = sum(stats[i]["iterations"] == cpu[i][2] for i in range(n))
-print("mode %s%s %dx%d depth=%d n=%d: bit-identical %d, iterations equal %d, status!=0 %d" % (a.mode, " (one pair per call)" if a.single else " (one batch)", w, h, a.depth, n, bit, it_eq, sum(s["status"] != 0 for s in stats)))
+print("mode %s%s weights=%d sampler=%d %dx%d depth=%d n=%d: bit-identical %d, iterations equal %d, status!=0 %d" % (a.mode, " (one pair per call)" if a.single else " (one batch)", a.weights, a.sampler, w, h, a.depth, n, bit, it_eq, sum(s["status"] != 0 for s in stats)))
 print("  rot  diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dr), np.percentile(dr, 90), dr.max(), (dr > 1e-4).sum()))
 print("  trans diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dt), np.percentile(dt, 90), dt.max(), (dt > 1e-4).sum()))
 print("  |t| median %.2e ; cpu time/pair %.3fs" % (np.median([np.linalg.norm(c[1][4:]) for c in cpu]), t_cpu / n))
