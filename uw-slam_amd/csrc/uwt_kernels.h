@@ -9,9 +9,14 @@
 //   k_gn_update    error / exit test / normal equations / solve / pose update (src/Tracker.cpp:495-574)
 //   k_level_end    level hand-off                           (src/Tracker.cpp:580-590)
 //   k_iterate, k_finish   the same loop chained: update + hand-off at the head of the next evaluation (a few pairs per call)
-//   k_coarse       the coarsest levels of such a call run to their end in one launch, one block per pair
-//   k_residual_points, k_residual_general, k_resid_hist*, k_scale_stage   explicit point tables; robust weights / bilinear
-//   k_grad_mag*, k_candidates_batch, k_scan_counts, k_patch_points, k_remap_crop, k_trajectory*   the rows next to the path
+//   k_coarse       the coarsest levels of such a call — and the coarsest level of a batch — run to their end in one launch,
+//                  one block per pair
+//   k_resid_hist_v (scale pass with the scale stage in its tail) + k_residual<.., WEIGHTS>   robust weights in the alignment loop;
+//                  k_residual_fused: both in one launch (opt-in); k_residual<.., SAMPLER = 1>: bilinear sampler
+//   k_residual_points, k_residual_general, k_resid_hist, k_scale_stage   explicit point tables; per-stage (dump) forms
+//   k_grad_mag*, k_candidates_batch, k_scan_counts, k_patch_points, k_add_patch_points, k_remap_crop, k_trajectory*   the rows
+//                  next to the path
+//   masked_sums_*  a pixel's 28 f64 sums under an EXEC mask of the valid lanes (no select anywhere in the loop)
 //
 // Stencil + gather + reduction work with a 6-wide contraction: no MFMA.  Wave = 64 lanes, blocks of 256.
 // Build with -ffp-contract=off: the per-pixel float sequence is part of the contract (every FMA is explicit).
