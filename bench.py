@@ -32,6 +32,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The HIP runtime deals a process's streams onto a few hardware queues in turn (4 by default).  A batch runs as two halves
+# on two streams whose launches fill each other's gaps; in a process that holds more streams — an RCCL communicator's, in
+# every multi-GPU rank — the two can be dealt the same queue, where they simply run one after the other: 12.57 -> 12.93 ms per
+# step with a communicator present, 13.04 with 2 queues, 12.62 with a communicator and 8 queues.  Set before anything
+# initialises the runtime (read once, at its start-up).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ALG_BYTES_PER_PIXEL_ITER = 10          # I_ref 1 + gx 2 + gy 2 + z 4 + I_tgt 1
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0                  # MI355X_MICROARCH.md §Chip-level parameters: measured copy ceiling
@@ -240,19 +247,39 @@ def main(args):
     ref_slots = np.arange(P, dtype=np.int32) * 2
     tgt_slots = ref_slots + 1
 
-    poses = torch.empty((P, 7), dtype=torch.float32, device=dev)
-    # torch sees the context's HIP stream as an external stream: the RCCL gather and the un-shuffle into global pair
-    # order are enqueued behind the alignment on that stream (no host synchronisation per step), and the next step's
-    # kernels queue behind them.
+    # torch sees the context's HIP stream as an external stream.  The RCCL gather and the un-shuffle into global pair order
+    # run on a stream of their own behind an event recorded after the alignment (no host synchronisation per step), so the
+    # next step's kernels do not queue behind the collective: pose and gather buffers alternate between two sets, and a
+    # step waits (on the device) for the gather that last read the set it is about to overwrite.  (Measured with a world of one:
+    # the gather itself costs a step 0.07-0.1 ms; what cost 0.3 ms more was the communicator's streams crowding the hardware
+    # queues, see GPU_MAX_HW_QUEUES at the top.)
+    n_buf = 2 if use_dist else 1
+    poses_buf = [torch.empty((P, 7), dtype=torch.float32, device=dev) for _ in range(n_buf)]
     ctx_stream = torch.cuda.ExternalStream(ctx.stream(), device=dev) if use_dist else None
-    gatherer = distm.PoseGatherer(total, dev) if use_dist else None
+    gather_stream = torch.cuda.Stream(device=dev) if use_dist else None
+    gatherers = [distm.PoseGatherer(total, dev) for _ in range(n_buf)] if use_dist else None
+    gatherer = gatherers[0] if use_dist else None
+    align_done = [torch.cuda.Event() for _ in range(n_buf)] if use_dist else None
+    gather_done = [torch.cuda.Event() for _ in range(n_buf)] if use_dist else None
+    gather_pending = [False] * n_buf
     gathered = [None]
+    step_no = [0]
+    last_buf = [0]
 
     def step():
-        ctx.track_batch_async(0, 2 * P, ref_slots, tgt_slots, poses.data_ptr())
+        b = step_no[0] % n_buf
+        step_no[0] += 1
+        last_buf[0] = b
+        if use_dist and gather_pending[b]:
+            ctx_stream.wait_event(gather_done[b])          # the gather of two steps ago has read poses_buf[b]
+        ctx.track_batch_async(0, 2 * P, ref_slots, tgt_slots, poses_buf[b].data_ptr())
         if use_dist:
-            with torch.cuda.stream(ctx_stream):
-                gathered[0] = gatherer.gather(poses)       # RCCL all_gather over xGMI + permutation to global order
+            align_done[b].record(ctx_stream)
+            with torch.cuda.stream(gather_stream):
+                gather_stream.wait_event(align_done[b])
+                gathered[0] = gatherers[b].gather(poses_buf[b])   # RCCL all_gather over xGMI + permutation to global order
+                gather_done[b].record(gather_stream)
+            gather_pending[b] = True
 
     def fence():
         ctx.sync()
@@ -273,7 +300,7 @@ def main(args):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    gpu_poses = poses.cpu().numpy()
+    gpu_poses = poses_buf[last_buf[0]].cpu().numpy()
     all_poses = gathered[0].cpu().numpy() if use_dist else gpu_poses
 
     # ---- after the timed region: one step with HIP events around every residual launch (each event pair drains the

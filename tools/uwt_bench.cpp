@@ -162,6 +162,9 @@ int run_device(Shared& S, int dev) {
 }  // namespace
 
 int main(int argc, char** argv) {
+  // more hardware queues than the runtime's default of 4: with RCCL's streams in the process the two halves of a batch can
+  // otherwise be dealt one queue and run one after the other (bench.py has the measurements); read once, at start-up
+  setenv("GPU_MAX_HW_QUEUES", "8", 0);
   Shared S;
   S.P = arg_int(argc, argv, "--pairs", 1024);
   const int U0 = arg_int(argc, argv, "--unique", 32);
