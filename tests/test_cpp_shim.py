@@ -27,6 +27,16 @@ def test_shim_compiles_and_links():
     assert os.path.exists(build_exe())
 
 
+def test_optional_opencv_and_eigen_branches_pass_a_syntax_check():
+    """UW_WITH_OPENCV / UW_WITH_EIGEN of include/uw_tracker.hpp cannot be compiled against the real libraries here (the image
+    has neither); tests/cpp/stubs/ declares just the members the header touches, so that the cv::Mat overloads, the Eigen
+    typedefs and the reference's DSO-way block at least go through the compiler's parser and overload resolution."""
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                        "-I", os.path.join(ROOT, "tests", "cpp", "stubs"), os.path.join(ROOT, "tests", "cpp", "shim_optional_branches.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 @pytest.mark.gpu
 def test_shim_sequence_matches_oracle(O, synth, tmp_path):
     exe = EXE if os.path.exists(EXE) else build_exe()
