@@ -56,7 +56,7 @@ class Tracker:
         over.update(self._over)
         p = capi.default_params(int(_width), int(_height), float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), **over)
         self._ctx = capi.Context(p)
-        if LS._default_ctx is None:
+        if LS._default_ctx is None or not LS._default_ctx._h:
             LS.bind(self._ctx)                  # `LS ls;` inside the tracking loop folds on the tracker's context
         self._ctx.set_deferred(True)   # one wait per frame, in EstimatePose (pyramids and gradients are enqueued only)
         lv = [self._ctx.level_info(l) for l in range(p.n_levels)]
@@ -221,6 +221,8 @@ class LS:
     def _ctx(self):
         if self._ctx_arg is not None:
             return self._ctx_arg
+        if LS._default_ctx is not None and not LS._default_ctx._h:
+            LS._default_ctx = None              # the context it was bound to has been closed
         if LS._default_ctx is None:             # nothing bound: a minimal context just for the reductions
             LS._default_ctx = capi.Context(capi.default_params(64, 48, 64.0, 64.0, 31.5, 23.5, n_levels=1, first_level=0,
                                                                last_level=0, max_frames=2, max_pairs=1))
