@@ -137,6 +137,17 @@ def test_instrumentation_finds_every_insertion_point():
     assert "\n".join(l for l in out.split("\n") if "tools/ref_dump" not in l) == text
 
 
+def test_driver_passes_a_syntax_check_against_interface_stubs():
+    """tools/ref_dump/ref_dump.cpp is built by a maintainer against the real reference (OpenCV, Eigen, Sophus, the reference's
+    headers) — none of which exist here.  tests/cpp/stubs/ref/ declares only the members the driver and its hooks touch, so that
+    at least the parser and overload resolution have seen the file."""
+    import subprocess
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tests", "cpp", "stubs", "ref"),
+                        "-I", os.path.join(ROOT, "tools", "ref_dump"), os.path.join(ROOT, "tools", "ref_dump", "ref_dump.cpp")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
 def test_input_export_round_trips(tmp_path):
     from PIL import Image
     exp = _tool("export_inputs")

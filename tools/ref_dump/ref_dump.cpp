@@ -1,6 +1,7 @@
 // ref_dump.cpp — driver a maintainer compiles AGAINST THE REAL REFERENCE (MecatronicaUSB/uw-slam with its OpenCV 3.2 + Eigen +
 // Sophus build) to produce golden vectors for this repository's parity tests.  It is not built by this repository: the
-// image this framework is developed in has neither OpenCV nor Eigen, so this file has never been compiled here (README.md).
+// image this framework is developed in has neither OpenCV nor Eigen; here the file only passes a syntax check against interface
+// stubs (tests/cpp/stubs/ref/).
 //
 // For every case directory written by export_inputs.py it reproduces what System does for two frames and dumps what the
 // tracker computes, through the reference's own classes only:
