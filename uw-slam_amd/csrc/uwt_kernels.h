@@ -259,32 +259,46 @@ __device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, 
   const int ly = threadIdx.x / (kGradVW / 4), c = threadIdx.x - ly * (kGradVW / 4);
   const int x = x0 + 4 * c, yb = y0 + ly * RPT;
   if (4 * c >= tw || yb >= h) return;
-  int p[3][6];  // p[row][0..5] = pixels x-1 .. x+4 of the window rows
-  auto load_row = [&](int dst, int r) {
+  // Separable form over packed 16-bit pairs (round 3; the scalar form spent ~30 integer instructions per pixel and was bound
+  // by them, not by its 5 bytes per pixel).  Per source row and pixel j: the horizontal difference d = p[j+2] - p[j] and the
+  // horizontal smoothing s = 3 p[j] + 10 p[j+1] + 3 p[j+2]; then gx = 3 (3 d_top + 10 d_mid + 3 d_bot) = 9 (d_top + d_bot) +
+  // 30 d_mid and gy = 3 (s_bot - s_top) — the same integers (|gx|, |gy| <= 12240, s <= 4080: everything fits 16 bits).  A
+  // row's six pixels x-1 .. x+4 are spread into five overlapping pairs by v_perm_b32, and every sum runs on two pixels at
+  // once (v_pk_add/sub/mul/mad on i16); the results are the stored i16 pairs as they stand.
+  typedef short s2v __attribute__((ext_vector_type(2)));
+  struct RowTerms { s2v d01, d23, s01, s23; };
+  auto row_terms = [&](int r) {
     const uint32_t wl = tile[r][c], wc = tile[r][c + 1], wr = tile[r][c + 2];
-    p[dst][0] = wl >> 24;
-    p[dst][1] = wc & 0xff; p[dst][2] = (wc >> 8) & 0xff; p[dst][3] = (wc >> 16) & 0xff; p[dst][4] = wc >> 24;
-    p[dst][5] = wr & 0xff;
+    auto pair = [](uint32_t hi_src, uint32_t lo_src, uint32_t sel) {   // two bytes of {hi_src, lo_src} zero-extended to u16 x 2
+      const uint32_t v = __builtin_amdgcn_perm(hi_src, lo_src, sel);
+      return __builtin_bit_cast(s2v, v);
+    };
+    const s2v p01 = pair(wc, wl, 0x0c040c03u);   // (x-1, x)
+    const s2v p12 = pair(0u, wc, 0x0c010c00u);   // (x, x+1)
+    const s2v p23 = pair(0u, wc, 0x0c020c01u);
+    const s2v p34 = pair(0u, wc, 0x0c030c02u);
+    const s2v p45 = pair(wr, wc, 0x0c040c03u);   // (x+3, x+4)
+    RowTerms t;
+    t.d01 = p23 - p01;
+    t.d23 = p45 - p23;
+    t.s01 = (p01 + p23) * (short)3 + p12 * (short)10;
+    t.s23 = (p23 + p45) * (short)3 + p34 * (short)10;
+    return t;
   };
-  load_row(0, ly * RPT);
-  load_row(1, ly * RPT + 1);
+  RowTerms r0 = row_terms(ly * RPT), r1 = row_terms(ly * RPT + 1);
 #pragma unroll
   for (int k = 0; k < RPT; k++) {
     if (yb + k < h) {
-      load_row(2, ly * RPT + k + 2);
-      int16_t ox[4], oy[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const int sx = 3 * (3 * (p[0][j + 2] - p[0][j]) + 10 * (p[1][j + 2] - p[1][j]) + 3 * (p[2][j + 2] - p[2][j]));
-        const int sy = 3 * (3 * (p[2][j] - p[0][j]) + 10 * (p[2][j + 1] - p[0][j + 1]) + 3 * (p[2][j + 2] - p[0][j + 2]));
-        ox[j] = (int16_t)sx;
-        oy[j] = (int16_t)sy;
-      }
+      const RowTerms r2 = row_terms(ly * RPT + k + 2);
+      const s2v gx01 = (r0.d01 + r2.d01) * (short)9 + r1.d01 * (short)30;
+      const s2v gx23 = (r0.d23 + r2.d23) * (short)9 + r1.d23 * (short)30;
+      const s2v gy01 = (r2.s01 - r0.s01) * (short)3;
+      const s2v gy23 = (r2.s23 - r0.s23) * (short)3;
       const size_t o = (size_t)slot * frame_stride + (size_t)(yb + k) * w + x;
-      *reinterpret_cast<uint2*>(gx + o) = *reinterpret_cast<uint2*>(ox);
-      *reinterpret_cast<uint2*>(gy + o) = *reinterpret_cast<uint2*>(oy);
-#pragma unroll
-      for (int j = 0; j < 6; j++) { p[0][j] = p[1][j]; p[1][j] = p[2][j]; }
+      *reinterpret_cast<uint2*>(gx + o) = make_uint2(__builtin_bit_cast(uint32_t, gx01), __builtin_bit_cast(uint32_t, gx23));
+      *reinterpret_cast<uint2*>(gy + o) = make_uint2(__builtin_bit_cast(uint32_t, gy01), __builtin_bit_cast(uint32_t, gy23));
+      r0 = r1;
+      r1 = r2;
     }
   }
 }
