@@ -224,39 +224,51 @@ __global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ 
 // `slots` (optional) lists the frame slots to process.
 constexpr int kGradVW = 128, kGradVRows = 8;  // columns per tile; thread rows per tile (x RPT output rows each)
 
-// one 128 x (8·RPT) output tile; lds: (8·RPT + 2) x (kGradVW / 4 + 2) words
+// one 128 x (8·RPT) output tile; lds: scharr_v4_lds_rows(RPT) x (kGradVW / 4 + 2) words (the patch's 8·RPT + 2 rows rounded up
+// to whole staging rounds of 8)
+constexpr int scharr_v4_lds_rows(int rpt) { return (kGradVRows * rpt + 2 + kGradVRows - 1) / kGradVRows * kGradVRows; }
 template <int RPT>
 __device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, const uint8_t* __restrict__ src,
                                                int16_t* __restrict__ gx, int16_t* __restrict__ gy, int w, int h,
                                                size_t frame_stride, int slot, int tile_id) {
-  constexpr int TH = kGradVRows * RPT;
-  uint32_t(*tile)[kGradVW / 4 + 2] = reinterpret_cast<uint32_t(*)[kGradVW / 4 + 2]>(lds);  // word 0: left halo in its top byte; word 33: right halo in its low byte
+  constexpr int TH = kGradVRows * RPT, WPR = kGradVW / 4;
+  uint32_t(*tile)[WPR + 2] = reinterpret_cast<uint32_t(*)[WPR + 2]>(lds);  // word 0: left halo in its top byte; word 33: right halo in its low byte
   const int tiles_x = (w + kGradVW - 1) / kGradVW;
   const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
   const int x0 = tx * kGradVW, y0 = ty * TH;
-  const uint8_t* img = src + (size_t)slot * frame_stride;
+  // the frame's planes: uniform bases, 32-bit offsets inside a frame (global_load / global_store with a scalar base)
+  const unsigned char* img = src + (size_t)slot * frame_stride;
+  unsigned char* gxf = reinterpret_cast<unsigned char*>(gx + (size_t)slot * frame_stride);
+  unsigned char* gyf = reinterpret_cast<unsigned char*>(gy + (size_t)slot * frame_stride);
   const int tw = min(kGradVW, w - x0);  // valid width of this tile (multiple of 4)
   const int rows = min(TH, h - y0) + 2; // patch rows this tile needs
+  const int ly = threadIdx.x / WPR, c = threadIdx.x - ly * WPR;
+  // reflect-101 of a row index in [-1, h]: |y|, then folded at the bottom edge
+  auto reflect_row = [&](int y) { const int ay = y < 0 ? -y : y; return min(ay, 2 * h - 2 - ay); };
+  // a thread stages its own column of words: rows ly, ly + 8, ...  All of its loads are issued before the first is waited
+  // for: rows / columns past the tile's patch read a clamped (valid) address and are not written to LDS.
+  constexpr int kStage = (TH + 2 + kGradVRows - 1) / kGradVRows;
+  const uint32_t colb = (uint32_t)(x0 + min(4 * c, tw - 4));
+  uint32_t staged[kStage];
 #pragma unroll
-  for (int i0 = 0; i0 < (TH + 2) * (kGradVW / 4); i0 += kBlock) {
-    const int i = i0 + (int)threadIdx.x;
-    const int r = i / (kGradVW / 4), c = i - r * (kGradVW / 4);
-    if (r < rows && 4 * c < tw) {
-      const int sy = reflect101(y0 + r - 1, h);
-      tile[r][1 + c] = *reinterpret_cast<const uint32_t*>(img + (size_t)sy * w + x0 + 4 * c);
+  for (int i = 0; i < kStage; i++) {
+    const int r = min(ly + kGradVRows * i, rows - 1);
+    staged[i] = *reinterpret_cast<const uint32_t*>(img + (__umul24((unsigned)reflect_row(y0 + r - 1), (unsigned)w) + colb));
+  }
+  // the two halo bytes of a patch row (threads 0 .. 2·rows-1 keep theirs), requested behind the words
+  const int hr = min((int)threadIdx.x >> 1, rows - 1), side = threadIdx.x & 1;
+  const uint32_t halo = img[__umul24((unsigned)reflect_row(y0 + hr - 1), (unsigned)w) + (unsigned)reflect101(side ? x0 + tw : x0 - 1, w)];
+  if (4 * c < tw) {   // (rows past the patch hold a clamped row's words: never read)
+#pragma unroll
+    for (int i = 0; i < kStage; i++) {
+      const int r = ly + kGradVRows * i;
+      tile[r][1 + c] = staged[i];   // (the tile has kStage·8 rows)
     }
   }
-  if (threadIdx.x < 2 * (TH + 2)) {
-    const int r = threadIdx.x >> 1, side = threadIdx.x & 1;
-    if (r < rows) {
-      const int sy = reflect101(y0 + r - 1, h);
-      const int xs = reflect101(side ? x0 + tw : x0 - 1, w);
-      const uint32_t v = img[(size_t)sy * w + xs];
-      if (side) tile[r][1 + tw / 4] = v; else tile[r][0] = v << 24;
-    }
+  if ((int)threadIdx.x < 2 * rows) {
+    if (side) tile[hr][1 + tw / 4] = halo; else tile[hr][0] = halo << 24;
   }
   __syncthreads();
-  const int ly = threadIdx.x / (kGradVW / 4), c = threadIdx.x - ly * (kGradVW / 4);
   const int x = x0 + 4 * c, yb = y0 + ly * RPT;
   if (4 * c >= tw || yb >= h) return;
   // Separable form over packed 16-bit pairs (round 3; the scalar form spent ~30 integer instructions per pixel and was bound
@@ -285,29 +297,34 @@ __device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, 
     t.s23 = (p23 + p45) * (short)3 + p34 * (short)10;
     return t;
   };
-  RowTerms r0 = row_terms(ly * RPT), r1 = row_terms(ly * RPT + 1);
+  auto out_rows = [&](auto whole) {   // whole: every row of the tile is inside the image (no per-row test)
+    RowTerms r0 = row_terms(ly * RPT), r1 = row_terms(ly * RPT + 1);
+    uint32_t o = 2u * (__umul24((unsigned)yb, (unsigned)w) + (unsigned)x);   // byte offset inside the frame's plane
 #pragma unroll
-  for (int k = 0; k < RPT; k++) {
-    if (yb + k < h) {
-      const RowTerms r2 = row_terms(ly * RPT + k + 2);
-      const s2v gx01 = (r0.d01 + r2.d01) * (short)9 + r1.d01 * (short)30;
-      const s2v gx23 = (r0.d23 + r2.d23) * (short)9 + r1.d23 * (short)30;
-      const s2v gy01 = (r2.s01 - r0.s01) * (short)3;
-      const s2v gy23 = (r2.s23 - r0.s23) * (short)3;
-      const size_t o = (size_t)slot * frame_stride + (size_t)(yb + k) * w + x;
-      *reinterpret_cast<uint2*>(gx + o) = make_uint2(__builtin_bit_cast(uint32_t, gx01), __builtin_bit_cast(uint32_t, gx23));
-      *reinterpret_cast<uint2*>(gy + o) = make_uint2(__builtin_bit_cast(uint32_t, gy01), __builtin_bit_cast(uint32_t, gy23));
-      r0 = r1;
-      r1 = r2;
+    for (int k = 0; k < RPT; k++) {
+      if (decltype(whole)::value || yb + k < h) {
+        const RowTerms r2 = row_terms(ly * RPT + k + 2);
+        const s2v gx01 = (r0.d01 + r2.d01) * (short)9 + r1.d01 * (short)30;
+        const s2v gx23 = (r0.d23 + r2.d23) * (short)9 + r1.d23 * (short)30;
+        const s2v gy01 = (r2.s01 - r0.s01) * (short)3;
+        const s2v gy23 = (r2.s23 - r0.s23) * (short)3;
+        *reinterpret_cast<uint2*>(gxf + o) = make_uint2(__builtin_bit_cast(uint32_t, gx01), __builtin_bit_cast(uint32_t, gx23));
+        *reinterpret_cast<uint2*>(gyf + o) = make_uint2(__builtin_bit_cast(uint32_t, gy01), __builtin_bit_cast(uint32_t, gy23));
+        o += 2u * (unsigned)w;
+        r0 = r1;
+        r1 = r2;
+      }
     }
-  }
+  };
+  if (y0 + TH <= h) out_rows(std::true_type{});
+  else out_rows(std::false_type{});
 }
 
 template <int RPT>
 __global__ __launch_bounds__(kBlock) void k_scharr3_v4(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
                                                        int16_t* __restrict__ gy, int w, int h, size_t frame_stride,
                                                        const int* __restrict__ slots, int first_slot) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(kGradVRows * RPT + 2) * (kGradVW / 4 + 2) * 4];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[scharr_v4_lds_rows(RPT) * (kGradVW / 4 + 2) * 4];
   const int slot = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;
   scharr_tile_v4<RPT>(lds, src, gx, gy, w, h, frame_stride, slot, (int)blockIdx.x);
 }
@@ -328,7 +345,7 @@ struct GradLevelsArgs {
 };
 
 __global__ __launch_bounds__(kBlock) void k_scharr3_levels(const GradLevelsArgs a) {
-  constexpr int kV4Bytes = (kGradVRows + 2) * (kGradVW / 4 + 2) * 4, kScBytes = (kGradTH + 2) * (kGradTW + 4);
+  constexpr int kV4Bytes = scharr_v4_lds_rows(1) * (kGradVW / 4 + 2) * 4, kScBytes = (kGradTH + 2) * (kGradTW + 4);
   __shared__ __attribute__((aligned(16))) unsigned char lds[kV4Bytes > kScBytes ? kV4Bytes : kScBytes];
   const int slot = a.slots ? a.slots[blockIdx.y] : a.first_slot + (int)blockIdx.y;
   const int b = (int)blockIdx.x;
