@@ -75,6 +75,8 @@ struct uwt_ctx {
   unsigned int* hist = nullptr;         // general path: [pair][2][kHistBins]
   PairScale* scale = nullptr;           // general path: [pair]
   int* d_active = nullptr;              // early-exit polling counters
+  unsigned int* d_tickets = nullptr;    // tail update: one counter per pair, zero between launches
+  bool tail_update = true;              // the update in the tail of the residual launch (UWT_TAIL_UPDATE=0: k_gn_update launches)
   int target_blocks = 0;                // blocks per residual launch the batch-dependent slicing aims at (UWT_TARGET_BLOCKS);
                                         // 0: 1024 for a batch that runs as two halves (one block per slot of the chip), else 4096
   int* h_active = nullptr;              // pinned
@@ -495,6 +497,20 @@ UpdateArgs update_args(uwt_ctx* c, int lvl) {
   return ua;
 }
 
+// the update of the evaluation `ra` launches, in that launch's tail (tail_update_wave) instead of k_gn_update(ua)
+void arm_tail(uwt_ctx* c, ResidualArgs& ra, const UpdateArgs& ua) {
+  ra.tail.on = 1;
+  ra.tail.tickets = c->d_tickets;
+  ra.tail.state = ua.state;
+  ra.tail.active = ua.active;
+  ra.tail.k = ua.k;
+  ra.tail.max_iters = ua.max_iters;
+  ra.tail.early_exit = ua.early_exit;
+  ra.tail.general = ua.general;
+  ra.tail.epsilon = ua.epsilon;
+  ra.tail.gain = ua.gain;
+}
+
 // k_iterate launch for the dense nearest-neighbour / identity-weights path (VEC = 4)
 template <bool DEPTH, bool UNIT>
 void launch_iterate_t(hipStream_t s, const ResidualArgs& a, const IterArgs& ia, int n_pairs, bool acc64, bool compute_only) {
@@ -787,21 +803,26 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
           c->prof_pairs = cnt;
           c->prof_records = c->partials;
         }
-        int st = general ? launch_general(c, ra, cnt, takes_fused(c, lvl)) : launch_residual(c, ra, cnt, false);
-        if (st) return st;
-        if (c->profiling) {
-          HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
-          c->prof_launches += 1;
-          c->prof_pixels += (long long)cnt * c->lv[lvl].n;
-        }
         if (general) ua.general = 1;
         ua.k = k;
         const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);
         const int slot = c->poll_seq & 1;
         ua.active = poll ? c->d_active + slot : nullptr;
         if (poll) HIPCHK(c, hipMemsetAsync(c->d_active + slot, 0, sizeof(int), c->stream));
-        hipLaunchKernelGGL(k_gn_update, dim3(cnt), dim3(kUpdateBlock), 0, c->stream, ua);
-        HIPCHK(c, hipGetLastError());
+        const bool fused = general && takes_fused(c, lvl);
+        const bool tail = c->tail_update && !fused && !c->compute_only;   // the update in the tail of the evaluation's launch
+        if (tail) arm_tail(c, ra, ua);
+        int st = general ? launch_general(c, ra, cnt, fused) : launch_residual(c, ra, cnt, false);
+        if (st) return st;
+        if (c->profiling) {
+          HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
+          c->prof_launches += 1;
+          c->prof_pixels += (long long)cnt * c->lv[lvl].n;
+        }
+        if (!tail) {
+          hipLaunchKernelGGL(k_gn_update, dim3(cnt), dim3(kUpdateBlock), 0, c->stream, ua);
+          HIPCHK(c, hipGetLastError());
+        }
         if (pending >= 0) {   // the look at the evaluation before this one, taken while this one runs
           HIPCHK(c, hipEventSynchronize(c->ev_poll[pending]));
           const bool nobody_left = c->h_active[pending] == 0;
@@ -882,13 +903,16 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
     for (int k = 0; k < p.max_iters && st == UWT_OK; k++)
       for (int i = 0; i < parts && st == UWT_OK; i++) {
         Part& q = pt[i];
-        c->stream = q.s;      // every launch helper enqueues on c->stream
-        st = general ? launch_general(c, q.ra, q.cnt, takes_fused(c, lvl)) : launch_residual(c, q.ra, q.cnt, false);
-        c->stream = main_stream;
-        if (st) break;
         q.ua.k = k;
         q.ua.active = nullptr;
-        hipLaunchKernelGGL(k_gn_update, dim3(q.cnt), dim3(kUpdateBlock), 0, q.s, q.ua);
+        const bool fused = general && takes_fused(c, lvl);
+        const bool tail = c->tail_update && !fused && !c->compute_only;   // the update in the tail of the evaluation's launch
+        if (tail) arm_tail(c, q.ra, q.ua);
+        c->stream = q.s;      // every launch helper enqueues on c->stream
+        st = general ? launch_general(c, q.ra, q.cnt, fused) : launch_residual(c, q.ra, q.cnt, false);
+        c->stream = main_stream;
+        if (st) break;
+        if (!tail) hipLaunchKernelGGL(k_gn_update, dim3(q.cnt), dim3(kUpdateBlock), 0, q.s, q.ua);
       }
     if (st) return st;
     for (int i = 0; i < parts; i++)
@@ -1116,6 +1140,9 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_poses, sizeof(float) * 7 * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_stats, sizeof(StatsOut) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_active, 2 * sizeof(int)));
+  CREATE_CHK(hipMalloc((void**)&c->d_tickets, sizeof(unsigned int) * (size_t)c->p.max_pairs));
+  CREATE_CHK(hipMemset(c->d_tickets, 0, sizeof(unsigned int) * (size_t)c->p.max_pairs));
+  if (const char* e = std::getenv("UWT_TAIL_UPDATE")) c->tail_update = std::atoi(e) != 0;
   for (int i = 0; i < 2; i++) CREATE_CHK(hipEventCreateWithFlags(&c->ev_poll[i], hipEventDisableTiming));
   CREATE_CHK(hipHostMalloc((void**)&c->h_small, sizeof(uwt_ctx::SmallResults)));
   CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_small, c->h_small, 0));
@@ -1160,6 +1187,7 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->d_poses) (void)hipFree(c->d_poses);
   if (c->d_stats) (void)hipFree(c->d_stats);
   if (c->d_active) (void)hipFree(c->d_active);
+  if (c->d_tickets) (void)hipFree(c->d_tickets);
   for (int i = 0; i < 2; i++)
     if (c->ev_poll[i]) (void)hipEventDestroy(c->ev_poll[i]);
   if (c->h_small) (void)hipHostFree(c->h_small);

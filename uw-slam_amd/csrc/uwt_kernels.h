@@ -746,7 +746,7 @@ constexpr int kIteratePass = kAccFloats;                // k_iterate, up to 3 pa
 template <typename AccT, bool HAS_EXTRA = false, int PASS = 14, typename R2T = uint32_t>
 __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict__ lds, const AccT acc[kAccFloats],
                                                       R2T sum_r2, uint32_t n_valid, uint32_t* __restrict__ rec,
-                                                      AccT extra = (AccT)0) {
+                                                      AccT extra = (AccT)0, bool coherent = false) {
   constexpr int kPass = PASS;  // accumulators per LDS pass
   constexpr int kRows = kAccFloats + (HAS_EXTRA ? 1 : 0);   // the extra sum rides in the last pass
   constexpr int kPasses = (kRows + kPass - 1) / kPass;
@@ -802,7 +802,17 @@ __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict_
     double s = seg_f[tid][0];
 #pragma unroll
     for (int k = 1; k < 8; k++) s += seg_f[tid][k];
-    if (tid == 27) rec[54] = (uint32_t)(unsigned long long)s;                                     // valid pixels
+    if (coherent) {
+      // The record goes to the device's coherence point and this wave learns that it has (tail_update_wave: the pair's last
+      // block reads it in this same launch, from another XCD as a rule): exchanges that RETURN — a value that has come back
+      // was exchanged where atomics execute — instead of stores followed by a release fence (= a write-back of the XCD's
+      // whole L2: what took the scale pass from 41 to 265 us, see k_resid_hist_v).
+      const unsigned long long bits = tid == 27 ? (unsigned long long)(uint32_t)(unsigned long long)s
+                                    : tid == 28 ? (unsigned long long)s : (unsigned long long)__double_as_longlong(s);
+      const unsigned long long old = __hip_atomic_exchange(reinterpret_cast<unsigned long long*>(rec) + tid, bits, __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("" ::"v"(old) : "memory");   // waited for here
+    } else if (tid == 27) rec[54] = (uint32_t)(unsigned long long)s;                              // valid pixels
     else if (tid == 28) reinterpret_cast<unsigned long long*>(rec)[28] = (unsigned long long)s;   // Σ r² (integer residuals)
     else reinterpret_cast<double*>(rec)[tid] = s;   // 29: Σ r·(r·w), the error numerator when residuals are not integers / weighted
     EXP_STAMP(15);
@@ -814,9 +824,9 @@ __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict_
 #endif
 template <typename AccT, bool HAS_EXTRA = false, typename R2T = uint32_t>
 __device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], R2T sum_r2, uint32_t n_valid,
-                                                   uint32_t* __restrict__ rec, AccT extra = (AccT)0) {
+                                                   uint32_t* __restrict__ rec, AccT extra = (AccT)0, bool coherent = false) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[reduce_lds_bytes(UWT_EXP_PASS)];
-  block_reduce_store_at<AccT, HAS_EXTRA, UWT_EXP_PASS, R2T>(lds, acc, sum_r2, n_valid, rec, extra);
+  block_reduce_store_at<AccT, HAS_EXTRA, UWT_EXP_PASS, R2T>(lds, acc, sum_r2, n_valid, rec, extra, coherent);
 }
 
 // robust weights / bilinear sampler shared by the dense kernels and the general (dump-capable) kernel
@@ -946,6 +956,16 @@ __global__ __launch_bounds__(1024) void k_robust_weights(const float* __restrict
 // reference level (implicit dense point table), gathers the target level, accumulates in registers and writes
 // one partial record.  Reference planes are read with one VEC-wide load per plane per group.
 // ------------------------------------------------------------------------------------------------------------
+// The update of an evaluation in the tail of the evaluation's own launch (tail_update_wave) instead of a k_gn_update launch.
+struct TailUpdate {
+  unsigned int* tickets;    // one word per pair (indexed like `state`), zero between launches
+  PairState* state;         // the pairs' states, writable
+  int* active;              // see UpdateArgs
+  int on;                   // 0: the launch leaves its records to k_gn_update
+  int k, max_iters, early_exit, general;
+  float epsilon, gain;
+};
+
 struct ResidualArgs {
   const uint8_t* img;       // level plane of all frame slots: [slot][n]
   const int16_t* gx;
@@ -969,6 +989,7 @@ struct ResidualArgs {
   float* dumpW;             // per-pixel robust weights (general path only)
   int probe;                // 1: thread 0 of every block leaves its shader-clock / 100 MHz real-time deltas in words 60, 61
                             // of the block's record (uwt_profile_clock: the clock the chip holds under this kernel)
+  TailUpdate tail;
 };
 
 // reference planes of one group of VEC pixels, as loaded (one vector load per plane)
@@ -1025,18 +1046,19 @@ __device__ __forceinline__ void load_first_group(RefGroup<VEC>& rg, const Residu
 
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
           bool COMPUTE_ONLY = false>
-__device__ __forceinline__ void residual_block(const ResidualArgs& a, const int pair, const int slice) {
+__device__ __forceinline__ bool residual_block(const ResidualArgs& a, const int pair, const int slice) {   // false: the pair is not iterating
   Pose pose;
   if constexpr (COMPUTE_ONLY) {
     pose_identity(pose);   // never skips a pair, never follows the (meaningless) updates: every launch does the full work
   } else if (a.state) {
     const PairState st = a.state[pair];
-    if (st.level_done || st.status) return;
+    if (st.level_done || st.status) return false;
     pose = st.pose;
   } else {
     pose = a.pose;
   }
   residual_core<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, slice, pose, nullptr);
+  return true;
 }
 
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
@@ -1312,19 +1334,22 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   if (threadIdx.x == 0) out_rec[62] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
   constexpr bool R2D = MASKED && !GENERAL;   // the identity path's sum of r^2 is the f64 one
+  const bool coherent = a.tail.on != 0;   // the record is read in this launch (tail_update_wave)
   if constexpr (EXT_LDS != 0 && R2D) block_reduce_store_at<AccT, false, EXT_LDS, double>(lds, acc, r2d, n_valid, out_rec, err);   // the caller's bytes: k_iterate
   else if constexpr (EXT_LDS != 0) block_reduce_store_at<AccT, GENERAL, EXT_LDS>(lds, acc, sum_r2, n_valid, out_rec, err);
   else if constexpr (TABLE) {
     __syncthreads();   // every wave has read its last table entry: the bytes become the reduction's image
-    block_reduce_store_at<AccT, true>(tlds, acc, sum_r2, n_valid, out_rec, err);
-  } else if constexpr (R2D) block_reduce_store<AccT, false, double>(acc, r2d, n_valid, out_rec, err);
-  else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err);
+    block_reduce_store_at<AccT, true>(tlds, acc, sum_r2, n_valid, out_rec, err, coherent);
+  } else if constexpr (R2D) block_reduce_store<AccT, false, double>(acc, r2d, n_valid, out_rec, err, coherent);
+  else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err, coherent);
   if (a.probe && threadIdx.x == 0) {
     uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
     rec[60] = (uint32_t)(__builtin_amdgcn_s_memtime() - clk0);
     rec[61] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt0);
   }
 }
+
+__device__ __forceinline__ void tail_update_wave(const ResidualArgs& a, int pair);   // (behind update_solve_wave)
 
 #ifndef UWT_EXP_WAVES
 #define UWT_RESIDUAL_BOUNDS __launch_bounds__(kBlock)
@@ -1334,7 +1359,11 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
           bool COMPUTE_ONLY = false>
 __global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
-  residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, (int)blockIdx.y + a.pair_base, (int)blockIdx.x);
+  const int pair = (int)blockIdx.y + a.pair_base;
+  const bool live = residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, (int)blockIdx.x);
+  if constexpr (!COMPUTE_ONLY && !DUMP) {
+    if (a.tail.on && live && threadIdx.x < 64) tail_update_wave(a, pair);   // wave 0 wrote the block's record
+  }
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2027,6 +2056,120 @@ constexpr int kUpdateBlock = 256;   // threads of an updating block: all fold th
 constexpr int kFoldBatch = 16;      // record loads a thread keeps in flight (8 x 16 = 128 records per round trip)
 constexpr int kUpdateLdsBytes = 2 * 8 * 32 * 8 + 512;   // part sums (two readings) + sums, integer sums, the state to broadcast
 
+// One wave, uniform values: from the evaluation's folded sums (sums[0..26]: JtJ upper triangle and Jtr, sums[27]: the
+// weighted error numerator; isums: valid pixels, integer sum of r^2) to the pair's next state.
+__device__ __forceinline__ void update_solve_wave(const UpdateArgs& a, PairState& st, const double* __restrict__ sums,
+                                                  const long long* __restrict__ isums, bool count_active, int lane) {
+  const int n = (int)isums[0];
+  const long long sr2 = isums[1];
+  st.iters += 1;
+  st.n_valid = n;
+  bool update = true;
+  if (n == 0) {
+    st.status = 2;  // UWT_ERR_NO_VALID_POINTS
+    st.level_done = 1;
+    update = false;
+  } else {
+    const float inv_n = (float)(1.0 / (double)n);                 // src/Tracker.cpp:499
+    const float error = a.general ? (float)((double)inv_n * sums[kAccFloats])   // Σ r·(r·w): float / weighted residuals
+                                  : (float)((double)inv_n * (double)sr2);       // :501, scaled-gemm form (exact integer Σr²)
+    st.error = error;
+    if (a.early_exit &&
+        (error >= st.last_error || a.k == a.max_iters - 1 || fabsf(error - st.last_error) < a.epsilon)) {  // :508
+      st.level_done = 1;
+      update = false;
+    } else {
+      st.last_error = error;  // :529
+    }
+  }
+  if (update) {
+    float b[6], delta[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+      b[i] = a.general ? (float)(-sums[21 + i]) : (float)(-((double)a.gain * sums[21 + i]));  // :559-561
+    EXP_STAMP(6);
+    solve_delta_wave(sums, b, delta);                                                // :554-564, A = (float)sums[0..20]
+    EXP_STAMP(7);
+    Pose d, np;
+    se3_exp_wave(delta, d);                                                         // :574
+    EXP_STAMP(8);
+    se3_mul(st.pose, d, np);
+    st.pose = np;
+    EXP_STAMP(9);
+    if (count_active && a.active && lane == 0) atomicAdd(a.active, 1);
+  }
+}
+
+// The update in the tail of the evaluation's own launch (round 3): no k_gn_update launch behind every residual launch.
+// Wave 0 of a block writes the block's record (block_reduce_store_at, `coherent`), then draws a ticket from the pair's
+// counter; the wave that draws the last one (slices - 1) knows every record of the pair is at the coherence point —
+// each was there before its block's ticket was drawn — and folds them (agent-scope loads: past this XCD's L2), solves
+// and writes the pair's next state, which the next launch reads.  The fold adds in update_compute's order (parts 0..7 of
+// records part, part + 8, ..., then the part sums in part order): the same sums bit for bit, by one wave — lane (slot,
+// half) takes parts half, half + 2, half + 4, half + 6 of its slot.  The counter is zero again afterwards.
+// Ordering without fences: see block_reduce_store_at; the ticket is drawn behind the returned exchanges in program order,
+// the loads are issued behind the returned ticket.
+constexpr int kTailRounds = 4;   // rounds of 8 records a lane has in flight per part (4 x 4 loads)
+__device__ __forceinline__ void tail_update_wave(const ResidualArgs& a, int pair) {
+  __shared__ __attribute__((aligned(16))) double t_sums[kAccFloats + 1];
+  __shared__ long long t_isums[2];
+  const int lane = (int)threadIdx.x;   // wave 0
+  unsigned int ticket = 0;
+  if (lane == 0) ticket = __hip_atomic_fetch_add(a.tail.tickets + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ticket = (unsigned int)__builtin_amdgcn_readfirstlane((int)ticket);
+  if (ticket != (unsigned int)a.slices - 1u) return;
+  if (lane == 0) __hip_atomic_store(a.tail.tickets + pair, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int slot = lane & 31, half = lane >> 5;
+  const unsigned long long* g8 = reinterpret_cast<const unsigned long long*>(a.partials + (size_t)pair * a.slices * kRecWords) + slot;
+  double cs[4] = {0.0, 0.0, 0.0, 0.0};
+  long long is[4] = {0, 0, 0, 0};
+  for (int q0 = 0; q0 < a.slices; q0 += 8 * kTailRounds) {
+    unsigned long long v[kTailRounds][4];
+#pragma unroll
+    for (int r = 0; r < kTailRounds; r++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const int q = q0 + 8 * r + half + 2 * j;
+        v[r][j] = q < a.slices ? __hip_atomic_load(g8 + (size_t)q * (kRecWords / 2), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      }
+#pragma unroll
+    for (int r = 0; r < kTailRounds; r++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        cs[j] += __longlong_as_double((long long)v[r][j]);
+        is[j] += (long long)(slot == 27 ? (v[r][j] & 0xffffffffull) : v[r][j]);   // slot 27: n_valid in the low word
+      }
+  }
+  double fs = 0.0;
+  long long ls = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {   // parts 2j (this half's when half == 0) and 2j + 1 (the other half's), in part order
+    const double of = __shfl_xor(cs[j], 32);
+    const long long oi = __shfl_xor(is[j], 32);
+    if (j == 0) { fs = cs[0]; ls = is[0]; } else { fs += cs[j]; ls += is[j]; }
+    fs += of;
+    ls += oi;
+  }
+  if (lane < 32) {
+    if (lane < kAccFloats) t_sums[lane] = fs;
+    else if (lane == 27) t_isums[0] = (long long)(uint32_t)ls;
+    else if (lane == 28) t_isums[1] = ls;
+    else if (lane == 29) t_sums[kAccFloats] = a.tail.general ? fs : 0.0;
+  }
+  __builtin_amdgcn_wave_barrier();
+  UpdateArgs u;
+  u.k = a.tail.k;
+  u.max_iters = a.tail.max_iters;
+  u.early_exit = a.tail.early_exit;
+  u.epsilon = a.tail.epsilon;
+  u.gain = a.tail.gain;
+  u.general = a.tail.general;
+  u.active = a.tail.active;
+  PairState st = a.tail.state[pair];   // as every block of the pair read it at the start: nobody has written it since
+  update_solve_wave(u, st, t_sums, t_isums, true, lane);
+  if (lane == 0) a.tail.state[pair] = st;
+}
+
 __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const uint32_t* __restrict__ recs, const PairState* __restrict__ st_in,
                                                     unsigned char* __restrict__ lds, bool count_active) {
   const int tid = threadIdx.x, lane = tid & 63;
@@ -2089,46 +2232,7 @@ __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const u
   __builtin_amdgcn_wave_barrier();   // the sums were written by lanes of wave 0, which alone reads them
   EXP_STAMP(5);
   if (tid < 64) {   // wave 0 runs the tail together on the same (uniform) values
-    if (live) {
-      const int n = (int)isums[0];
-      const long long sr2 = isums[1];
-      st.iters += 1;
-      st.n_valid = n;
-      bool update = true;
-      if (n == 0) {
-        st.status = 2;  // UWT_ERR_NO_VALID_POINTS
-        st.level_done = 1;
-        update = false;
-      } else {
-        const float inv_n = (float)(1.0 / (double)n);                 // src/Tracker.cpp:499
-        const float error = a.general ? (float)((double)inv_n * sums[kAccFloats])   // Σ r·(r·w): float / weighted residuals
-                                      : (float)((double)inv_n * (double)sr2);       // :501, scaled-gemm form (exact integer Σr²)
-        st.error = error;
-        if (a.early_exit &&
-            (error >= st.last_error || a.k == a.max_iters - 1 || fabsf(error - st.last_error) < a.epsilon)) {  // :508
-          st.level_done = 1;
-          update = false;
-        } else {
-          st.last_error = error;  // :529
-        }
-      }
-      if (update) {
-        float b[6], delta[6];
-#pragma unroll
-        for (int i = 0; i < 6; i++)
-          b[i] = a.general ? (float)(-sums[21 + i]) : (float)(-((double)a.gain * sums[21 + i]));  // :559-561
-        EXP_STAMP(6);
-        solve_delta_wave(sums, b, delta);                                                // :554-564, A = (float)sums[0..20]
-        EXP_STAMP(7);
-        Pose d, np;
-        se3_exp_wave(delta, d);                                                         // :574
-        EXP_STAMP(8);
-        se3_mul(st.pose, d, np);
-        st.pose = np;
-        EXP_STAMP(9);
-        if (count_active && a.active && lane == 0) atomicAdd(a.active, 1);
-      }
-    }
+    if (live) update_solve_wave(a, st, sums, isums, count_active, lane);
     if (lane == 0) *s_state = st;
   }
   __syncthreads();
