@@ -435,3 +435,46 @@ print("ok")
     r = _run([sys.executable, "-c", code])
     assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]
 
+
+
+@pytest.mark.gpu
+def test_update_launch_form_matches_the_tail_update():
+    """The Gauss-Newton update runs in the tail of the evaluation's own launch by default (tail_update_wave: the pair's last
+    block folds the records and solves); UWT_TAIL_UPDATE=0 keeps the k_gn_update launch behind every evaluation.  Both forms
+    add the records in the same order: a batch with several blocks per pair on every level — fixed schedule and the
+    reference's early-exit schedule (whose polls count the pairs still iterating through the same code), identity and Huber
+    weights — gives the oracle's poses bit for bit in either form.  Child processes: the switch is read when a context is
+    created."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import importlib, sys, numpy as np
+sys.path.insert(0, %r)
+capi = importlib.import_module("uw-slam_amd.capi"); synth = importlib.import_module("uw-slam_amd.synth")
+from oracle import oracle as O
+w, h, intr = 320, 240, (262.5, 262.5, 159.5, 119.5)
+n = 24
+pairs = [synth.render_pair(w, h, *intr, seed=900 + i, z=0.8 + 0.02 * i, with_depth=True) for i in range(n)]
+frames = np.stack([f for p in pairs for f in (p[0], p[1])]); depth = np.stack([p[2] for p in pairs for _ in (0, 1)])
+out = []
+for over in (dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0, has_depth=1),
+             dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0, has_depth=1, weights=2),
+             dict(n_levels=5, first_level=4, last_level=1, max_iters=50, early_exit=1, has_depth=1)):
+    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
+    ctx.upload_frames(0, frames, depth); ctx.build_pyramids(0, 2 * n); ctx.apply_gradient(0, 2 * n)
+    for rep in range(3):
+        poses, stats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1, raise_on_pair_failure=True)
+        po = O.default_params(w, h, *intr, **over)
+        for i, p in enumerate(pairs if rep == 0 else pairs[:4]):
+            st, pose_cpu, tr = O.align_pair(po, p[0], p[1], p[2], want_trace=True)
+            assert st == 0 and np.array_equal(poses[i].view(np.uint32), pose_cpu.view(np.uint32)), (over, i, poses[i], pose_cpu)
+            assert stats[i]["iterations"] == len(tr), (over, i)
+    ctx.close()
+print("ok")
+''' % root
+    for switch in ("0", "1"):
+        env = dict(os.environ, UWT_TAIL_UPDATE=switch)
+        r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=540)
+        assert r.returncode == 0 and b"ok" in r.stdout, (switch, r.stderr.decode()[-2000:])
