@@ -439,8 +439,9 @@ print("ok")
 
 @pytest.mark.gpu
 def test_update_launch_form_matches_the_tail_update():
-    """The Gauss-Newton update runs in the tail of the evaluation's own launch by default (tail_update_wave: the pair's last
-    block folds the records and solves); UWT_TAIL_UPDATE=0 keeps the k_gn_update launch behind every evaluation.  Both forms
+    """Where a batch runs as two parts on two streams the Gauss-Newton update runs in the tail of the evaluation's own launch
+    (tail_update_wave: the pair's last block folds the records and solves); elsewhere a k_gn_update launch follows every
+    evaluation.  UWT_TAIL_UPDATE=0 / 2 selects the launch form / the tail form everywhere.  Both forms
     add the records in the same order: a batch with several blocks per pair on every level — fixed schedule and the
     reference's early-exit schedule (whose polls count the pairs still iterating through the same code), identity and Huber
     weights — gives the oracle's poses bit for bit in either form.  Child processes: the switch is read when a context is
@@ -474,7 +475,7 @@ for over in (dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_ex
     ctx.close()
 print("ok")
 ''' % root
-    for switch in ("0", "1"):
+    for switch in ("0", "2"):
         env = dict(os.environ, UWT_TAIL_UPDATE=switch)
         r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=540)
         assert r.returncode == 0 and b"ok" in r.stdout, (switch, r.stderr.decode()[-2000:])

@@ -76,7 +76,11 @@ struct uwt_ctx {
   PairScale* scale = nullptr;           // general path: [pair]
   int* d_active = nullptr;              // early-exit polling counters
   unsigned int* d_tickets = nullptr;    // tail update: one counter per pair, zero between launches
-  bool tail_update = true;              // the update in the tail of the residual launch (UWT_TAIL_UPDATE=0: k_gn_update launches)
+  int tail_update = 1;                  // the update in the tail of the residual launch instead of a k_gn_update launch: 1 = where a
+                                        // batch runs as parts on streams of their own (the tail's ~10 us of dependent round trips
+                                        // and the solve run under the other part's launches: +1.2 % at 1024 pairs, +3 % with Huber
+                                        // weights at 256; on one stream the tail is exposed at the end of every launch and loses
+                                        // ~3 us per evaluation to the update launch), 0 = never, 2 = always (UWT_TAIL_UPDATE)
   int target_blocks = 0;                // blocks per residual launch the batch-dependent slicing aims at (UWT_TARGET_BLOCKS);
                                         // 0: 1024 for a batch that runs as two halves (one block per slot of the chip), else 4096
   int* h_active = nullptr;              // pinned
@@ -810,7 +814,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         ua.active = poll ? c->d_active + slot : nullptr;
         if (poll) HIPCHK(c, hipMemsetAsync(c->d_active + slot, 0, sizeof(int), c->stream));
         const bool fused = general && takes_fused(c, lvl);
-        const bool tail = c->tail_update && !fused && !c->compute_only;   // the update in the tail of the evaluation's launch
+        const bool tail = c->tail_update >= 2 && !fused && !c->compute_only;   // (one stream: only when forced, see tail_update)
         if (tail) arm_tail(c, ra, ua);
         int st = general ? launch_general(c, ra, cnt, fused) : launch_residual(c, ra, cnt, false);
         if (st) return st;
@@ -906,7 +910,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         q.ua.k = k;
         q.ua.active = nullptr;
         const bool fused = general && takes_fused(c, lvl);
-        const bool tail = c->tail_update && !fused && !c->compute_only;   // the update in the tail of the evaluation's launch
+        const bool tail = c->tail_update >= 1 && !fused && !c->compute_only;   // the update in the tail of the evaluation's launch
         if (tail) arm_tail(c, q.ra, q.ua);
         c->stream = q.s;      // every launch helper enqueues on c->stream
         st = general ? launch_general(c, q.ra, q.cnt, fused) : launch_residual(c, q.ra, q.cnt, false);
@@ -1142,7 +1146,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_active, 2 * sizeof(int)));
   CREATE_CHK(hipMalloc((void**)&c->d_tickets, sizeof(unsigned int) * (size_t)c->p.max_pairs));
   CREATE_CHK(hipMemset(c->d_tickets, 0, sizeof(unsigned int) * (size_t)c->p.max_pairs));
-  if (const char* e = std::getenv("UWT_TAIL_UPDATE")) c->tail_update = std::atoi(e) != 0;
+  if (const char* e = std::getenv("UWT_TAIL_UPDATE")) c->tail_update = std::max(0, std::min(2, std::atoi(e)));
   for (int i = 0; i < 2; i++) CREATE_CHK(hipEventCreateWithFlags(&c->ev_poll[i], hipEventDisableTiming));
   CREATE_CHK(hipHostMalloc((void**)&c->h_small, sizeof(uwt_ctx::SmallResults)));
   CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_small, c->h_small, 0));
