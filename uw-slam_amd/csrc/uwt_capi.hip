@@ -855,7 +855,10 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   // launch, the update launch, the kernel boundaries: +2..4 % at 256..1024 pairs, +7..9 % at 32..64 in a pipeline of calls;
   // three parts gain nothing more, four lose (measured).  Results do not depend on it (a pair's blocks, records and state
   // are its own; the slicing is the whole batch's).
-  if (parts < 2) return run(0, n_pairs);
+  if (parts < 2) {
+    if (c->tail_update >= 2) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, sizeof(unsigned int) * (size_t)n_pairs, c->stream));
+    return run(0, n_pairs);
+  }
   // (fixed schedule, not profiled: no read-backs, no events around launches).  The parts' launches are enqueued in turns,
   // iteration by iteration, so that both streams have work from the start.
   struct Part { int base, cnt; hipStream_t s; ResidualArgs ra; UpdateArgs ua; };
@@ -871,6 +874,8 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
       for (int i = 1; i < parts; i++) (void)hipStreamSynchronize(c->part_stream[i]);
     }
   } guard{c, parts, main_stream};
+  // (the pairs' ticket counters are zero between launches by construction; a call that an error cut short may have left some)
+  if (c->tail_update >= 1) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, sizeof(unsigned int) * (size_t)n_pairs, main_stream));
   HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
   for (int i = 0; i < parts; i++) {
     Part& q = pt[i];
