@@ -455,8 +455,11 @@ import importlib, sys, numpy as np
 sys.path.insert(0, %r)
 capi = importlib.import_module("uw-slam_amd.capi"); synth = importlib.import_module("uw-slam_amd.synth")
 from oracle import oracle as O
-w, h, intr = 320, 240, (262.5, 262.5, 159.5, 119.5)
-n = 24
+import os
+if os.environ.get("TEST_FEW_LARGE"):   # two pairs of 640x480 off the chained flow: 150 records per pair at level 0 (five rounds of the tail's fold)
+    w, h, intr, n = 640, 480, (525.0, 525.0, 319.5, 239.5), 2
+else:
+    w, h, intr, n = 320, 240, (262.5, 262.5, 159.5, 119.5), 24
 pairs = [synth.render_pair(w, h, *intr, seed=900 + i, z=0.8 + 0.02 * i, with_depth=True) for i in range(n)]
 frames = np.stack([f for p in pairs for f in (p[0], p[1])]); depth = np.stack([p[2] for p in pairs for _ in (0, 1)])
 out = []
@@ -475,7 +478,7 @@ for over in (dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_ex
     ctx.close()
 print("ok")
 ''' % root
-    for switch in ("0", "2"):
-        env = dict(os.environ, UWT_TAIL_UPDATE=switch)
+    for switch, extra in (("0", {}), ("2", {}), ("2", dict(TEST_FEW_LARGE="1", UWT_CHAINED="0"))):
+        env = dict(os.environ, UWT_TAIL_UPDATE=switch, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=540)
-        assert r.returncode == 0 and b"ok" in r.stdout, (switch, r.stderr.decode()[-2000:])
+        assert r.returncode == 0 and b"ok" in r.stdout, (switch, extra, r.stderr.decode()[-2000:])
