@@ -411,8 +411,9 @@ def main(args):
                 "traffic_source": facts.get("hbm_bytes_source") if traffic_px else None,
                 "launches": int(res_launches), "avg_launch_ms": round(res_ms / res_launches, 5),
                 "algorithmic_bytes_per_launch_avg": int(alg_bytes / res_launches),
-                "launch_form": "whole-batch launches, one at a time (the profiled step after the timed region; the timed steps "
-                               "run the batch as two halves on two streams, whose overlapping launches have no duration of their own)",
+                "launch_form": "whole-batch launches, one at a time, a k_gn_update launch behind each (the profiled step after the "
+                               "timed region; the timed steps run the batch as two halves on two streams, whose overlapping launches "
+                               "have no duration of their own, with the update in the tail of the evaluation's own launch)",
                 "whole_job_effective_GBs": round(value / world * (ALG_BYTES_PER_PIXEL_ITER * px_per_align * args.iters
                                                                   + 5 * px_per_align + 2.5 * px_per_align) / 1e9, 1),
             }
