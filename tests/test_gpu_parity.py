@@ -62,7 +62,8 @@ def test_halve_bit_exact(capi, O, shape):
     assert np.array_equal(ctx.halve_u16(np.full(shape, 65535, np.uint16)), np.full((shape[0] // 2, shape[1] // 2), 65535))
 
 
-@pytest.mark.parametrize("shape", [(12, 16), (5, 5), (1, 7), (9, 1), (17, 65), (30, 40), (480, 640), (96, 130)])
+@pytest.mark.parametrize("shape", [(12, 16), (5, 5), (1, 7), (9, 1), (17, 65), (30, 40), (480, 640), (96, 130),
+                                   (1, 8), (2, 4), (3, 132), (33, 260), (64, 4), (65, 128)])   # vector path: one row, ragged tiles
 def test_scharr_bit_exact(capi, O, shape):
     rng = np.random.default_rng(shape[1])
     ctx = make_ctx(capi, 64, 48, SMALL, n_levels=3, first_level=2, last_level=0)

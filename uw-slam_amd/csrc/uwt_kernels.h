@@ -244,7 +244,7 @@ __device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, 
   const int rows = min(TH, h - y0) + 2; // patch rows this tile needs
   const int ly = threadIdx.x / WPR, c = threadIdx.x - ly * WPR;
   // reflect-101 of a row index in [-1, h]: |y|, then folded at the bottom edge
-  auto reflect_row = [&](int y) { const int ay = y < 0 ? -y : y; return min(ay, 2 * h - 2 - ay); };
+  auto reflect_row = [&](int y) { const int ay = y < 0 ? -y : y; return max(min(ay, 2 * h - 2 - ay), 0); };   // (h = 1: row 0)
   // a thread stages its own column of words: rows ly, ly + 8, ...  All of its loads are issued before the first is waited
   // for: rows / columns past the tile's patch read a clamped (valid) address and are not written to LDS.
   constexpr int kStage = (TH + 2 + kGradVRows - 1) / kGradVRows;
