@@ -78,6 +78,25 @@ def test_scharr_bit_exact(capi, O, shape):
     assert np.array_equal(gx, ox) and np.array_equal(gy, oy)
 
 
+def test_stage_kernels_on_random_shapes(capi, O):
+    """Scharr and the 2x2 mean on 60 random shapes (the vector tiles' widths — multiples of 4 — and odd widths, one to a few
+    hundred rows, ragged last tiles), every output compared with the oracle's."""
+    rng = np.random.default_rng(77)
+    ctx = make_ctx(capi, 64, 48, SMALL, n_levels=3, first_level=2, last_level=0)
+    for k in range(60):
+        h = int(rng.integers(1, 200))
+        w = int(rng.integers(1, 90)) * 4 if k % 3 else int(rng.integers(1, 300))
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        gx, gy = ctx.scharr3(img)
+        ox, oy = O.scharr3(img)
+        assert np.array_equal(gx, ox) and np.array_equal(gy, oy), (h, w)
+        if h >= 2 and w >= 2:
+            ev = img[: h // 2 * 2, : w // 2 * 2]
+            assert np.array_equal(ctx.halve_u8(ev), O.halve_u8(ev)), (h, w)
+            d16 = rng.integers(0, 65536, ev.shape).astype(np.uint16)
+            assert np.array_equal(ctx.halve_u16(d16), O.halve_u16(d16)), (h, w)
+
+
 def test_golden_stage_vectors(capi, golden_dir):
     g = np.load(os.path.join(golden_dir, "stages.npz"))
     ctx = make_ctx(capi, 64, 48, SMALL, n_levels=3, first_level=2, last_level=0)
