@@ -860,6 +860,8 @@ __device__ __forceinline__ float sample_bilinear(const uint8_t* __restrict__ I2,
   return __builtin_fmaf(ay, bot - top, top);
 }
 
+// FINITE: rf is a finite residual of the alignment loop (|rf| <= 255): the Huber quotient may take the short division
+template <bool FINITE = false>
 __device__ __forceinline__ float robust_weight(int mode, float rf, float inv_mad) {
   if (mode == kWeightsTukeyRef) {  // Tracker::TukeyFunctionWeights, src/Tracker.cpp:1626-1654
     const float b = 4.6851f;
@@ -874,6 +876,9 @@ __device__ __forceinline__ float robust_weight(int mode, float rf, float inv_mad
   if (mode == kWeightsHuber) {  // EXTENSION
     const float k = 1.345f;
     const float ax = fabsf(rf * inv_mad);
+    // k / ax as the refined reciprocal + two residual corrections (div_by: bit-identical to the IEEE quotient for normal-range
+    // operands — ax is in (1.345, 255 / MAD] where the quotient is used — at half the instructions of the compiler's sequence)
+    if constexpr (FINITE) return ax <= k ? 1.0f : div_by<float>(k, ax, refined_rcp<float>(ax));
     return ax <= k ? 1.0f : k / ax;
   }
   return 1.0f;
@@ -1279,7 +1284,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
         float rf;
         if constexpr (SAMPLER == 0) rf = (float)(i2[j] - (int)i1[j]);
         else rf = s2[j] - (float)i1[j];
-        const float w = robust_weight(WEIGHTS, rf, inv_mad);
+        const float w = robust_weight<true>(WEIGHTS, rf, inv_mad);
         double Jd[6];
 #pragma unroll
         for (int k = 0; k < 6; k++) Jd[k] = (double)(w * Jp[k]);
