@@ -146,7 +146,7 @@ int uwt_apply_gradient(uwt_ctx* ctx, int32_t first_slot, int32_t n);
  * the chained flow (one launch per evaluation, the coarsest levels in one launch, results written straight into
  * page-locked memory; one or two pairs of an early-exit schedule are launched without read-backs and redone the careful
  * way if a level was cut short), batches take one residual and one update launch per evaluation, large fixed-schedule
- * batches as two halves on two streams. */
+ * batches run as two halves on two streams with the update in the tail of the residual launch. */
 int uwt_estimate_pose_batch(uwt_ctx* ctx, int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
                             float* poses_out, uwt_stats* stats_out_or_null);
 
