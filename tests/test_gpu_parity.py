@@ -169,6 +169,34 @@ def test_one_launch_pyramid_and_gradient_forms(capi, O, synth, monkeypatch, shap
     ctx.close()
 
 
+@pytest.mark.parametrize("shape", [(640, 480, 4), (320, 240, 5), (128, 64, 4), (144, 72, 4), (1280, 960, 6), (160, 96, 3)])
+def test_batch_pyramids_in_one_pass(capi, O, monkeypatch, shape):
+    """More than a few frames take levels 1..3 of their pyramids in one pass over level 0 (k_pyramid_batch: level-0 width a
+    multiple of 16, height of 8, four levels or more; the levels beyond and every other shape by the per-level chain):
+    white-noise frames (every rounding case of the 2x2 mean), u8 and u16, a range that does not start at slot 0, tiles that
+    end inside the 128 x 64 block — every level equal to the oracle's chain of halvings, with and without the batch form."""
+    w, h, levels = shape
+    f = 525.0 * w / 640.0
+    n = 11
+    rng = np.random.default_rng(w * 7 + levels)
+    frames = rng.integers(0, 256, (n, h, w)).astype(np.uint8)
+    depth = rng.integers(0, 65536, (n, h, w)).astype(np.uint16)
+    for switch in ("0", "1"):
+        if switch == "1":
+            monkeypatch.setenv("UWT_NO_PYRAMID_BATCH", "1")
+        ctx = capi.Context(capi.default_params(w, h, f, f, w / 2 - 0.5, h / 2 - 0.5, n_levels=levels, first_level=levels - 1,
+                                               last_level=0, max_frames=n, max_pairs=2, has_depth=1))
+        ctx.upload_frames(0, frames, depth)
+        ctx.build_pyramids(1, n - 1)
+        for s in (1, 5, n - 1):
+            im, dp = frames[s], depth[s]
+            for l in range(1, levels):
+                im, dp = O.halve_u8(im), O.halve_u16(dp)
+                assert np.array_equal(ctx.get_plane(s, l, capi.PLANE_IMAGE), im), (switch, s, l)
+                assert np.array_equal(ctx.get_plane(s, l, capi.PLANE_DEPTH), dp), (switch, s, l)
+        ctx.close()
+
+
 def test_level_info_matches_oracle(capi, O):
     ctx = make_ctx(capi, 640, 480, TUM)
     p = O.default_params(640, 480, *TUM)

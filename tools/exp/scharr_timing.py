@@ -13,7 +13,7 @@ if len(sys.argv) > 1:
 synth = importlib.import_module("uw-slam_amd.synth")
 w, h, n = 640, 480, 256
 intr = (525.0, 525.0, 319.5, 239.5)
-ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=n, max_pairs=1, has_depth=1))
+ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=n, max_pairs=1, has_depth=1, n_levels=4, first_level=3, last_level=0))
 ref, _, dep, _, _ = synth.render_pair(w, h, *intr, seed=1, with_depth=True)
 ctx.upload_frames(0, np.stack([ref] * n), np.stack([dep] * n))
 def timed(f, reps=20):

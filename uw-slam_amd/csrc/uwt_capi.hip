@@ -1369,7 +1369,29 @@ static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n, const int* depth_
     HIPCHK(c, hipGetLastError());
     return UWT_OK;
   }
-  for (int l = 1; l < c->p.n_levels; l++) {
+  // batches: levels 1..3 in one pass over level 0 (k_pyramid_batch), the levels beyond by the per-level chain
+  int l0 = 1;
+  if (c->p.n_levels >= 4 && c->lv[0].w % 16 == 0 && c->lv[0].h % 8 == 0 && !std::getenv("UWT_NO_PYRAMID_BATCH")) {
+    const int tiles = ((c->lv[0].w + 127) / 128) * ((c->lv[0].h + 63) / 64);
+    if (n) {
+      PyramidBatchArgs<uint8_t> a;
+      a.src = c->img[0];
+      for (int l = 0; l < 4; l++) { a.stride[l] = c->lv[l].n; if (l) a.dst[l - 1] = c->img[l]; }
+      a.w = c->lv[0].w; a.h = c->lv[0].h; a.slots = nullptr; a.first_slot = first_slot;
+      hipLaunchKernelGGL(k_pyramid_batch<uint8_t>, dim3(tiles, n), dim3(kBlock), 0, c->stream, a);
+    }
+    const int nd16 = !c->p.has_depth ? 0 : (depth_slots ? n_depth : n);
+    if (nd16) {
+      PyramidBatchArgs<uint16_t> a;
+      a.src = c->depth[0];
+      for (int l = 0; l < 4; l++) { a.stride[l] = c->lv[l].n; if (l) a.dst[l - 1] = c->depth[l]; }
+      a.w = c->lv[0].w; a.h = c->lv[0].h; a.slots = depth_slots; a.first_slot = depth_slots ? 0 : first_slot;
+      hipLaunchKernelGGL(k_pyramid_batch<uint16_t>, dim3(tiles, nd16), dim3(kBlock), 0, c->stream, a);
+    }
+    HIPCHK(c, hipGetLastError());
+    l0 = 4;
+  }
+  for (int l = l0; l < c->p.n_levels; l++) {
     const size_t ns = c->lv[l - 1].n, nd = c->lv[l].n;
     int st = launch_halve<uint8_t>(c, c->img[l - 1], c->img[l], c->lv[l].w, c->lv[l].h, ns, nd, n, nullptr, first_slot);
     if (st) return st;

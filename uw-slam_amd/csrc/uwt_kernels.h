@@ -164,6 +164,88 @@ __global__ __launch_bounds__(kBlock) void k_pyramid_all(const PyramidArgs<T> a) 
   }
 }
 
+// Levels 1..3 of a BATCH of frames in one pass over level 0 (round 3): the per-level k_halve chain reads level 0, level 1
+// and level 2 again (1.64 bytes moved per level-0 byte); here a block takes a 128 x 64 tile of level 0 down three levels,
+// reads it once with 16-byte loads and writes the three results (1.33).  Thread (tx = t mod 8, ty = t div 8) loads 16
+// pixels of rows 2 ty, 2 ty + 1 and makes 8 pixels of level-1 row ty; the level-1 row below belongs to the lane 8 on, the
+// level-2 row below to the lane 16 on (same wave: a wave holds ty = 8 k .. 8 k + 7), so levels 2 and 3 come out of two
+// lane exchanges — no LDS, no barrier.  Same integers as k_halve level by level ((a + b + c + d + 2) >> 2 of the rounded
+// values of the level above).  Needs the level-0 width divisible by 16 and the height by 8; frames by slot range or list.
+template <typename T>
+struct PyramidBatchArgs {
+  const T* src;     // level 0, slot 0
+  T* dst[3];        // levels 1, 2, 3, slot 0
+  size_t stride[4]; // pixels per frame at levels 0..3
+  int w, h;         // level 0
+  const int* slots;
+  int first_slot;
+};
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pyramid_batch(const PyramidBatchArgs<T> a) {
+  const size_t frame = a.slots ? a.slots[blockIdx.y] : a.first_slot + (int)blockIdx.y;
+  const int tiles_x = (a.w + 127) / 128;
+  const int tyb = blockIdx.x / tiles_x, txb = blockIdx.x - tyb * tiles_x;
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int x = txb * 128 + 16 * tx, y = tyb * 64 + 2 * ty;   // level-0 corner of this thread's 16 x 2 patch
+  const bool in = x < a.w && y < a.h;
+  uint32_t p1[8];   // level-1 pixels (x / 2 .. x / 2 + 7, y / 2)
+  {
+    T r0[16], r1[16];
+    const uint32_t off = in ? (uint32_t)y * (uint32_t)a.w + (uint32_t)x : 0u;   // (lanes outside the image read the frame's first pixels)
+    const unsigned char* s = reinterpret_cast<const unsigned char*>(a.src + frame * a.stride[0]);
+    if constexpr (sizeof(T) == 1) {
+      *reinterpret_cast<uint4*>(r0) = *reinterpret_cast<const uint4*>(s + off);
+      *reinterpret_cast<uint4*>(r1) = *reinterpret_cast<const uint4*>(s + off + (uint32_t)a.w);
+    } else {
+      const uint32_t o2 = off * 2u, w2 = (uint32_t)a.w * 2u;
+      *reinterpret_cast<uint4*>(r0) = *reinterpret_cast<const uint4*>(s + o2);
+      *reinterpret_cast<uint4*>(r0 + 8) = *reinterpret_cast<const uint4*>(s + o2 + 16u);
+      *reinterpret_cast<uint4*>(r1) = *reinterpret_cast<const uint4*>(s + o2 + w2);
+      *reinterpret_cast<uint4*>(r1 + 8) = *reinterpret_cast<const uint4*>(s + o2 + w2 + 16u);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) p1[i] = ((uint32_t)r0[2 * i] + (uint32_t)r0[2 * i + 1] + (uint32_t)r1[2 * i] + (uint32_t)r1[2 * i + 1] + 2u) >> 2;
+  }
+  const int w1 = a.w >> 1, w2 = a.w >> 2, w3 = a.w >> 3;
+  if (in) {
+    T o[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[i] = (T)p1[i];
+    T* d = a.dst[0] + frame * a.stride[1] + (size_t)(y >> 1) * w1 + (x >> 1);
+    if constexpr (sizeof(T) == 1) *reinterpret_cast<uint2*>(d) = *reinterpret_cast<uint2*>(o);
+    else *reinterpret_cast<uint4*>(d) = *reinterpret_cast<uint4*>(o);
+  }
+  // level 2: level-1 rows ty (this lane, ty even) and ty + 1 (the lane 8 on)
+  uint32_t p2[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const uint32_t below0 = (uint32_t)__shfl_xor((int)p1[2 * i], 8), below1 = (uint32_t)__shfl_xor((int)p1[2 * i + 1], 8);
+    p2[i] = (p1[2 * i] + p1[2 * i + 1] + below0 + below1 + 2u) >> 2;
+  }
+  if (in && (ty & 1) == 0) {
+    T o[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) o[i] = (T)p2[i];
+    T* d = a.dst[1] + frame * a.stride[2] + (size_t)(y >> 2) * w2 + (x >> 2);
+    if constexpr (sizeof(T) == 1) *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<uint32_t*>(o);
+    else *reinterpret_cast<uint2*>(d) = *reinterpret_cast<uint2*>(o);
+  }
+  // level 3: level-2 rows ty / 2 (this lane, ty a multiple of 4) and ty / 2 + 1 (the lane 16 on)
+  uint32_t p3[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const uint32_t below0 = (uint32_t)__shfl_xor((int)p2[2 * i], 16), below1 = (uint32_t)__shfl_xor((int)p2[2 * i + 1], 16);
+    p3[i] = (p2[2 * i] + p2[2 * i + 1] + below0 + below1 + 2u) >> 2;
+  }
+  if (in && (ty & 3) == 0) {
+    T o[2] = {(T)p3[0], (T)p3[1]};
+    T* d = a.dst[2] + frame * a.stride[3] + (size_t)(y >> 3) * w3 + (x >> 3);
+    if constexpr (sizeof(T) == 1) *reinterpret_cast<uint16_t*>(d) = *reinterpret_cast<uint16_t*>(o);
+    else *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<uint32_t*>(o);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // gradients: 3 x Scharr, reflect-101 border, exact in int (src/Tracker.cpp:1133-1134).
 // A 64x16 output tile per block; the (64+2)x(16+2) u8 source patch is staged in LDS once, every output then
