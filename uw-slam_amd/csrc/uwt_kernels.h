@@ -1,12 +1,13 @@
 // uwt_kernels.h — gfx950 kernels of the direct SE(3) tracking path.
 //
-//   k_halve, k_pyramid_all      System::AddFrame pyramid loop (a launch per level / every level of a few frames in one)
-//                               (src/System.cpp:246-251)
+//   k_halve, k_pyramid_all, k_pyramid_batch   System::AddFrame pyramid loop (a launch per level / every level of a few frames in
+//                               one / levels 1..3 of a batch in one pass over level 0)   (src/System.cpp:246-251)
 //   k_scharr3*, k_scharr3_levels   Tracker::ApplyGradient (per level / every level of a few frames in one launch)
 //                               (src/Tracker.cpp:1133-1134)
 //   k_residual     WarpFunction + per-point loop + the 28-accumulator LS reduction, fused
 //                  (src/Tracker.cpp:1417-1471, 432-490; src/LeastSquares.cpp:148-209)
-//   k_gn_update    error / exit test / normal equations / solve / pose update (src/Tracker.cpp:495-574)
+//   k_gn_update    error / exit test / normal equations / solve / pose update (src/Tracker.cpp:495-574);
+//                  tail_update_wave: the same in the tail of the residual launch (the pair's last block, by ticket)
 //   k_level_end    level hand-off                           (src/Tracker.cpp:580-590)
 //   k_iterate, k_finish   the same loop chained: update + hand-off at the head of the next evaluation (a few pairs per call)
 //   k_coarse       the coarsest levels of such a call — and the coarsest level of a batch — run to their end in one launch,
