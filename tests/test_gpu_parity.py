@@ -169,7 +169,8 @@ def test_one_launch_pyramid_and_gradient_forms(capi, O, synth, monkeypatch, shap
     ctx.close()
 
 
-@pytest.mark.parametrize("shape", [(640, 480, 4), (320, 240, 5), (128, 64, 4), (144, 72, 4), (1280, 960, 6), (160, 96, 3)])
+@pytest.mark.parametrize("shape", [(640, 480, 4), (320, 240, 5), (128, 64, 4), (144, 72, 4), (1280, 960, 6), (160, 96, 3),
+                                   (48, 24, 4), (16, 8, 4)])   # (the last two: level widths 6 and 2, odd frame strides)
 def test_batch_pyramids_in_one_pass(capi, O, monkeypatch, shape):
     """More than a few frames take levels 1..3 of their pyramids in one pass over level 0 (k_pyramid_batch: level-0 width a
     multiple of 16, height of 8, four levels or more; the levels beyond and every other shape by the per-level chain):
