@@ -408,8 +408,17 @@ __global__ __launch_bounds__(kBlock) void k_scharr3_v4(const uint8_t* __restrict
                                                        int16_t* __restrict__ gy, int w, int h, size_t frame_stride,
                                                        const int* __restrict__ slots, int first_slot) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[scharr_v4_lds_rows(RPT) * (kGradVW / 4 + 2) * 4];
-  const int slot = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;
-  scharr_tile_v4<RPT>(lds, src, gx, gy, w, h, frame_stride, slot, (int)blockIdx.x);
+  // XCD-aware order of the tiles: blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own
+  // L2), and a tile's halo bytes — one 128-byte line to the left and one to the right of every patch row — are its
+  // neighbours' data: with the tiles in launch order every XCD fetched them for itself (2.75 x the plane per launch in
+  // FETCH_SIZE).  Block b takes tile start(b mod 8) + b div 8, so that consecutive tiles (neighbours along x, then the next
+  // tile row, then the next frame) run on ONE XCD one after the other and find those lines in its L2.
+  const unsigned nb = gridDim.x * gridDim.y, b = blockIdx.y * gridDim.x + blockIdx.x;
+  const unsigned xcd = b & 7u, q = nb >> 3, r = nb & 7u;
+  const unsigned t = xcd * q + min(xcd, r) + (b >> 3);   // XCD x owns q + (x < r) consecutive tiles
+  const unsigned fy = t / gridDim.x, tile = t - fy * gridDim.x;
+  const int slot = slots ? slots[fy] : first_slot + (int)fy;
+  scharr_tile_v4<RPT>(lds, src, gx, gy, w, h, frame_stride, slot, (int)tile);
 }
 
 // The gradients of every level of a frame (or a few) in one launch: block -> (level, tile) through the levels' tile
