@@ -431,6 +431,10 @@ def main(args):
             for k in ("valu_instructions_per_pixel", "f64_fma_per_pixel", "instruction_mix_source"):
                 if k in facts:
                     valu[k] = facts[k]
+            valu["waves_per_simd"] = 4
+            valu["occupancy_note"] = ("120 VGPRs (54 of them the 27 f64 accumulators) and 34.9 KB of LDS per block: four waves per SIMD; an "
+                                      "independent v_fmac_f64 stream takes a SIMD 1.16 ns per wave instruction at 4 waves, 1.00 at 6, 0.83 at 8 "
+                                      "(profiles/r03/ubench_exec_toggle.txt)")
             roof["valu"] = valu
             if args.reference_schedule:
                 # early exit: a launch is counted (and its level's pixels with it) whether or not its pairs have already left
