@@ -65,6 +65,9 @@ def parse_args(argv=None):
     ap.add_argument("--levels", type=int, default=4)
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--acc", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--arith", choices=["opencv", "legacy"], default="opencv",
+                    help="arithmetic set of the OpenCV steps (include/uwt.h uwt_arith): opencv = what OpenCV 3.x's generic gemm / "
+                         "MatExpr / solve paths compute (default, the parity target); legacy = rounds 1-3 (f32 FMA chains, inverse then multiply)")
     ap.add_argument("--no-depth", action="store_true")
     ap.add_argument("--weights", choices=["identity", "tukey", "huber"], default="identity",
                     help="robust weights (general path; identity is the reference's live setting)")
@@ -88,7 +91,7 @@ def streaming_figure(capi, params, frames, depth, P, rounds, resident_poses):
     the resident run."""
     h, w = frames.shape[1:]
     over = {k: getattr(params, k) for k in ("n_levels", "first_level", "last_level", "max_iters", "early_exit", "has_depth",
-                                            "accumulate_f64", "weights", "sampler", "device")}
+                                            "accumulate_f64", "weights", "sampler", "device", "arith")}
     ctx = capi.Context(capi.default_params(w, h, params.fx, params.fy, params.cx, params.cy, max_frames=4 * P, max_pairs=P, **over))
     g_ref = capi.pinned_empty((P, h, w), np.uint8); g_ref[:] = frames[0::2]
     g_tgt = capi.pinned_empty((P, h, w), np.uint8); g_tgt[:] = frames[1::2]
@@ -146,9 +149,9 @@ def latency_figure(capi, params, frames, depth, resident_pose, reps=200):
     h, w = frames.shape[1:]
     out = {"unit": "ms per alignment, one pair per call", "calls_timed": reps}
     keep = {k: getattr(params, k) for k in ("n_levels", "first_level", "last_level", "max_iters", "early_exit", "has_depth",
-                                            "accumulate_f64", "device")}
+                                            "accumulate_f64", "device", "arith")}
     for name in ("bench_schedule", "reference_schedule"):
-        over = dict(keep) if name == "bench_schedule" else dict(has_depth=keep["has_depth"], accumulate_f64=keep["accumulate_f64"], device=keep["device"])
+        over = dict(keep) if name == "bench_schedule" else dict(has_depth=keep["has_depth"], accumulate_f64=keep["accumulate_f64"], device=keep["device"], arith=keep["arith"])
         if name == "reference_schedule" and (w % 16 or h % 16):
             continue
         ctx = capi.Context(capi.default_params(w, h, params.fx, params.fy, params.cx, params.cy, max_frames=2, max_pairs=1, **over))
@@ -210,7 +213,8 @@ def main(args):
     has_depth = 0 if args.no_depth else 1
     over = dict(n_levels=args.levels, first_level=args.levels - 1, last_level=0, max_iters=args.iters, early_exit=0,
                 has_depth=has_depth, accumulate_f64=1 if args.acc == "f64" else 0,
-                weights={"identity": 0, "tukey": 1, "huber": 2}[args.weights], sampler=int(args.bilinear))
+                weights={"identity": 0, "tukey": 1, "huber": 2}[args.weights], sampler=int(args.bilinear),
+                arith={"opencv": 0, "legacy": 1}[args.arith])
     if args.reference_schedule:
         over.update(n_levels=5, first_level=4, last_level=1, max_iters=50, early_exit=1)
     params = capi.default_params(w, h, *intr, max_frames=2 * P, max_pairs=P, device=local_rank, **over)
@@ -364,6 +368,10 @@ def main(args):
                             if args.reference_schedule else
                             "%d pyramid levels (0..%d), %d GN iterations/level, no early exit" % (args.levels, args.levels - 1, args.iters),
                             ", u16 depth plane" if has_depth else ", z=1", total, P, U)),
+            "arithmetic": ("opencv: cv::gemm products (4-term rigid, 2-term Jacobian row, N-long normal equations) accumulated in f64 and "
+                           "rounded once, MatExpr-folded unprojection, A.inv()*b as cv::solve (LU on the right-hand side)"
+                           if args.arith == "opencv" else
+                           "legacy (rounds 1-3): 4-/2-term products as f32 FMA chains, (x-cx)*invfx as written, inverse then f64-accumulated product"),
             "normal_equation_accumulation": args.acc, "weights": args.weights,
             "sampler": "bilinear" if args.bilinear else "nearest", "total_pairs": total, "pairs_on_rank0": P,
             "sharding": "round-robin pairs, RCCL all_gather of poses, global order on every rank" if use_dist else "single GPU",

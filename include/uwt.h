@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 #define UWT_MAX_LEVELS 8
-#define UWT_ABI_VERSION 1
+#define UWT_ABI_VERSION 2   /* 2: uwt_params::arith */
 
 enum uwt_status_code {
   UWT_OK = 0,
@@ -33,6 +33,19 @@ enum uwt_status_code {
 };
 
 enum uwt_plane { UWT_PLANE_IMAGE = 0, UWT_PLANE_DEPTH = 1, UWT_PLANE_GRADX = 2, UWT_PLANE_GRADY = 3 };
+
+/* Arithmetic of the OpenCV steps on the path (the reference pins no OpenCV build; "3.2", README.md:15).
+ * UWT_ARITH_OPENCV: what OpenCV 3.x's generic (non-BLAS, non-IPP) code computes for the reference's expressions —
+ *   - every cv::gemm on CV_32F accumulates in double and rounds to float once (matmul.cpp GEMMSingleMul<float,double>):
+ *     rigid * points.t() (src/Tracker.cpp:1450) = (float)(((T0*X + T1*Y) + T2*Z) + T3*w), Jl * Jw (:479) =
+ *     (float)(g0*Jw0k + g1*Jw1k), and the N-long JtJ / Jtr / rtr sums (:501, :560-561);
+ *   - "(col - cx) * invfx" (:1439, :1443) is folded by the MatExpr algebra (matop.cpp MatOp_AddEx::multiply) into one scaled
+ *     convert: x * invfx + (float)(-(double)cx * invfx);
+ *   - "A.inv() * b" (:564) is MatOp_Invert::matmul -> cv::solve(A, b, DECOMP_LU) = hal::LU32f(A, 6, b, 1): elimination on
+ *     the right-hand side and f32 back substitution, no inverse and no product.
+ * UWT_ARITH_LEGACY: rounds 1-3 of this library: the 4-/2-term products as f32 FMA chains, (x - cx) * invfx as written, the
+ *   inverse formed and multiplied with f64 accumulation.  Cheaper; differs from the above by <= 1 ulp per pixel term. */
+enum uwt_arith { UWT_ARITH_OPENCV = 0, UWT_ARITH_LEGACY = 1 };
 
 /* All solver constants the reference hard-codes as locals of Tracker::EstimatePose* (src/Tracker.cpp:364-372,
  * 634-640) and as link-time globals (src/Options.cpp:26-28), as one POD. */
@@ -60,6 +73,7 @@ typedef struct uwt_params {
   int32_t max_frames;        /* frame-slot capacity of the context                                       */
   int32_t max_pairs;         /* largest batch of pairs per call                                          */
   int32_t device;            /* HIP device ordinal                                                       */
+  int32_t arith;             /* uwt_arith: UWT_ARITH_OPENCV (default) or UWT_ARITH_LEGACY                */
 } uwt_params;
 
 /* per-level camera model = the vectors Tracker::InitializePyramid fills (include/Tracker.h:516-528) */
@@ -96,7 +110,7 @@ int uwt_default_params(uwt_params* p, int32_t width, int32_t height, float fx, f
 int uwt_create(const uwt_params* p, uwt_ctx** out);
 /* Changes the solver constants of a live context — the locals the reference re-declares at the top of each
  * EstimatePose* variant (src/Tracker.cpp:364-372, 634-640, 877-885): first/last level, max_iters, epsilon, gain, z_factor,
- * angle_factor, initial_error, early_exit, handoff_scale_t, accumulate_f64, sampler, weights.  Geometry and capacity
+ * angle_factor, initial_error, early_exit, handoff_scale_t, accumulate_f64, sampler, weights, arith.  Geometry and capacity
  * (size, intrinsics, n_levels, has_depth, max_frames, max_pairs, device) must equal the context's. */
 int uwt_update_params(uwt_ctx* ctx, const uwt_params* p);
 /* the context's current parameters */

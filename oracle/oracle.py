@@ -14,6 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libuwt_oracle.so")
 
 MAX_LEVELS = 8
+ARITH_OPENCV, ARITH_LEGACY = 0, 1   # uwo_params.arith (oracle/uwt_oracle.h: G1..G4 / S1, S3, S4)
+ARITH_NAMES = {ARITH_OPENCV: "opencv", ARITH_LEGACY: "legacy"}
 
 
 class Params(C.Structure):
@@ -25,7 +27,7 @@ class Params(C.Structure):
         ("epsilon", C.c_float), ("gain", C.c_float), ("z_factor", C.c_float), ("angle_factor", C.c_float),
         ("depth_scale", C.c_float), ("initial_error", C.c_float),
         ("early_exit", C.c_int32), ("has_depth", C.c_int32), ("handoff_scale_t", C.c_int32),
-        ("weights", C.c_int32), ("sampler", C.c_int32), ("small_products_f64", C.c_int32),
+        ("weights", C.c_int32), ("sampler", C.c_int32), ("arith", C.c_int32),
     ]
 
 
@@ -75,10 +77,18 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
+# what default_params() fills in when the caller names no set: UWT_ARITH=legacy in the environment (the parity suite's child
+# processes; the HIP library's uwt_default_params reads the same variable), else OpenCV's; tests/conftest.py switches it per test
+DEFAULT_ARITH = ARITH_LEGACY if os.environ.get("UWT_ARITH") == "legacy" else ARITH_OPENCV
+
+
 def default_params(width, height, fx, fy, cx, cy, **over):
     p = Params()
     lib().uwo_default_params(C.byref(p), width, height, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy))
+    p.arith = DEFAULT_ARITH
     for k, v in over.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
         setattr(p, k, v)
     return p
 
@@ -229,6 +239,21 @@ def solve_delta(A, b):
     d = np.empty(6, np.float32)
     lib().uwo_solve_delta(_p(A, C.c_float), _p(b, C.c_float), _p(d, C.c_float))
     return d
+
+
+def set_arith(arith):
+    """Arithmetic set of the per-stage functions (warp, residual_jacobian, normal_equations, error, solve_delta);
+    returns the previous one.  align_pair* set it from Params.arith."""
+    return lib().uwo_set_arith(int(arith))
+
+
+def solve6(A, b):
+    """cv::solve(A, b, x, DECOMP_LU): (x, ok)."""
+    A = np.ascontiguousarray(A, np.float32).reshape(36)
+    b = np.ascontiguousarray(b, np.float32).reshape(6)
+    out = np.empty(6, np.float32)
+    ok = lib().uwo_solve6(_p(A, C.c_float), _p(b, C.c_float), _p(out, C.c_float))
+    return out, bool(ok)
 
 
 def median_mat(v):

@@ -1,6 +1,6 @@
 /*
  * uwt_oracle.c — CPU ORACLE (test infrastructure; see uwt_oracle.h for the contract and the
- * pinned semantics S1..S8).  Plain C restatement of the UW-SLAM direct-tracking path.
+ * arithmetic sets: G1..G4 = OpenCV 3.x's published generic paths, the default; S1/S3/S4 = the legacy set).  Plain C restatement of the UW-SLAM direct-tracking path.
  * Reference citations are relative to /root/reference.  PARITY UNPINNED (no reference goldens exist).
  *
  * Compile with -ffp-contract=off: every FMA in here is an explicit fmaf().
@@ -36,6 +36,7 @@ void uwo_default_params(uwo_params* p, int width, int height, float fx, float fy
   p->handoff_scale_t = 0;
   p->weights = UWO_WEIGHTS_IDENTITY;
   p->sampler = UWO_SAMPLER_NEAREST;
+  p->arith = UWO_ARITH_OPENCV;
 }
 
 /* Tracker::InitializePyramid, Tracker.cpp:297-340.  fx halves in double then narrows
@@ -296,10 +297,30 @@ int uwo_se3_handoff(float pose[7], int scale_t) {
 /* warp + per-point terms                                                                       */
 /* ------------------------------------------------------------------------------------------ */
 
-static int g_small_f64 = 0;
-void uwo_set_small_products_f64(int on) { g_small_f64 = on; }
+static int g_arith = UWO_ARITH_OPENCV;
+int uwo_set_arith(int arith) {
+  int prev = g_arith;
+  g_arith = arith == UWO_ARITH_LEGACY ? UWO_ARITH_LEGACY : UWO_ARITH_OPENCV;
+  return prev;
+}
 
-/* Tracker::WarpFunction, Tracker.cpp:1417-1471.  The 4x4·4xN product follows S1. */
+/* "(col - c) * inv" of Tracker.cpp:1439 / :1443 on one element.
+ * G3: operator-(Mat, Scalar) makes MatOp_AddEx(a, alpha = 1, s = -(double)c); operator*(MatExpr, double) is
+ * MatOp_AddEx::multiply: alpha *= inv, s *= inv — both in double; Mat::operator=(MatExpr) runs MatOp_AddEx::assign:
+ * |alpha| != 1  ->  a.convertTo(m, type, alpha, s)  ->  cvtScale32f: x * (float)alpha + (float)s;
+ * alpha == 1 -> cv::add(a, s); alpha == -1 -> cv::subtract(s, a) (scalar narrowed to f32 by arithm_op).
+ * Legacy: the expression as written. */
+static inline float unproject_scaled(float x, float c, float inv) {
+  if (g_arith == UWO_ARITH_LEGACY) return (x - c) * inv;
+  double alpha = (double)inv;
+  double sc = -(double)c * (double)inv;
+  if (alpha == 1.0) return x + (float)sc;
+  if (alpha == -1.0) return (float)sc - x;
+  float m = x * (float)alpha;
+  return m + (float)sc;
+}
+
+/* Tracker::WarpFunction, Tracker.cpp:1417-1471.  The 4x4·4xN product follows G1 (legacy: S1). */
 void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, float* warped) {
   float T[16];
   uwo_se3_matrix(pose, T);
@@ -307,14 +328,18 @@ void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, 
   for (int i = 0; i < n; i++) {
     const float* p = pts + 4 * (size_t)i;
     float z = p[2], w = p[3];
-    float X = (p[0] - cx) * invfx; /* :1439 */
-    X = X * z;                     /* :1440 */
-    float Y = (p[1] - cy) * invfy; /* :1443 */
-    Y = Y * z;                     /* :1444 */
+    float X = unproject_scaled(p[0], cx, invfx); /* :1439 */
+    X = X * z;                                   /* :1440 cv::multiply */
+    float Y = unproject_scaled(p[1], cy, invfy); /* :1443 */
+    Y = Y * z;                                   /* :1444 */
     float o[4];
     for (int k = 0; k < 4; k++) {  /* :1450 rigid * P^T */
-      if (g_small_f64) { /* sensitivity study: double accumulation of the generic cv::gemm path */
-        o[k] = (float)((double)T[4 * k] * X + (double)T[4 * k + 1] * Y + (double)T[4 * k + 2] * z + (double)T[4 * k + 3] * w);
+      if (g_arith != UWO_ARITH_LEGACY) {
+        /* G1: gemm(rigid, P, 1, GEMM_2_T) -> GEMMSingleMul<float,double>, "A * Bt" branch, n = 4: the unrolled loop
+         * runs once, s0 = a0*b0, s1 = a1*b1, s2 = a2*b2, s3 = a3*b3 (exact in double), d = T((s0+s1+s2+s3)*alpha), alpha = 1 */
+        double s0 = (double)T[4 * k] * (double)X, s1 = (double)T[4 * k + 1] * (double)Y;
+        double s2 = (double)T[4 * k + 2] * (double)z, s3 = (double)T[4 * k + 3] * (double)w;
+        o[k] = (float)(((s0 + s1) + s2) + s3);
         continue;
       }
       float s = T[4 * k] * X;
@@ -393,8 +418,17 @@ int uwo_residual_jacobian_ex(const uint8_t* img1, const uint8_t* img2, const int
         float jl0 = (float)gx1[(size_t)iy1 * w + ix1]; /* :476 */
         float jl1 = (float)gy1[(size_t)iy1 * w + ix1]; /* :477 */
         float* Jr = J + 6 * (size_t)nv;
-        for (int k = 0; k < 6; k++) { /* :479 Jl * Jw (S1) */
-          if (g_small_f64) { Jr[k] = (float)((double)jl0 * Jw[0][k] + (double)jl1 * Jw[1][k]); continue; }
+        for (int k = 0; k < 6; k++) { /* :479 Jl * Jw */
+          if (g_arith != UWO_ARITH_LEGACY) {
+            /* G1: gemm(Jl 1x2, Jw 2x6): flags 0, len 2, d_size 6x1 -> no inline special case (needs len == width|height);
+             * GEMMSingleMul<float,double>, "d_size.width * sizeof <= 1600" branch: WT s(0); for k: s += WT(a[k]) * WT(b[k][j]);
+             * d[j] = T(s * alpha) */
+            double sj = 0.0;
+            sj += (double)jl0 * (double)Jw[0][k];
+            sj += (double)jl1 * (double)Jw[1][k];
+            Jr[k] = (float)sj;
+            continue;
+          }
           float s = jl0 * Jw[0][k];
           s = fmaf(jl1, Jw[1][k], s);
           Jr[k] = s;
@@ -500,38 +534,96 @@ void uwo_huber_weights(const float* r, int n, float* w) {
 /* error, normal equations, solve                                                               */
 /* ------------------------------------------------------------------------------------------ */
 
-/* Tracker.cpp:499-502 (S2, S8). w may be NULL (identity). */
+/* A cv::gemm on CV_32F whose result is one column wide, len = n: row `a` (n floats, stride sa) times the vector b.
+ * matmul.cpp gemmImpl: "(d_size.width == 1 || len == 1) && !(flags & GEMM_2_T) && B.isContinuous()" sets b_step = 0 and
+ * GEMM_2_T, so both code paths below run their "A * Bt" branch.  `rows` = d_size.height (6 for Jᵀr, 1 for rᵀr).
+ *  - single pass ("(d_size.height <= 64 || d_size.width <= 64) && len <= 10000"): GEMMSingleMul<float,double>, four partial
+ *    sums over k, k+1, k+2, k+3 (CV_ENABLE_UNROLLED is 1 outside ICC / CV_DISABLE_OPTIMIZATION), the tail into s0, then
+ *    (s0+s1+s2+s3) * alpha;
+ *  - otherwise the block algorithm: dm0 = min(128, rows), dn0 = 1, dk0 = min(16384 / dm0, 16384 / dn0, len); per block
+ *    [k, k + dk): GEMMBlockMul<float,double>: s0 = (first block ? 0 : d_buf), s1 = 0, pairs into s0 / s1, an odd last term
+ *    into s0, d_buf = s0 + s1; a block absorbs the remainder when "k + dk >= len || 8*(k + dk) + dk > 8*len";
+ *    GEMMStore: alpha * d_buf.
+ * Returns the double before the final (float) store.  Legacy set: one sequential sum. */
+static double gemm_dot_width1(const float* a, size_t sa, const float* b, int n, int rows, double alpha) {
+  if (g_arith == UWO_ARITH_LEGACY) {
+    double s = 0.0;
+    for (int k = 0; k < n; k++) s += (double)a[sa * (size_t)k] * (double)b[k];
+    return s * alpha;
+  }
+  if (n <= 10000) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int k = 0;
+    for (; k <= n - 4; k += 4) {
+      s0 += (double)a[sa * (size_t)k] * (double)b[k];
+      s1 += (double)a[sa * (size_t)(k + 1)] * (double)b[k + 1];
+      s2 += (double)a[sa * (size_t)(k + 2)] * (double)b[k + 2];
+      s3 += (double)a[sa * (size_t)(k + 3)] * (double)b[k + 3];
+    }
+    for (; k < n; k++) s0 += (double)a[sa * (size_t)k] * (double)b[k];
+    return (s0 + s1 + s2 + s3) * alpha;
+  }
+  const int block_size = 128 * 128;
+  int dm0 = rows < 128 ? rows : 128;
+  int dk0 = block_size / dm0;
+  if (dk0 > block_size) dk0 = block_size; /* block_size / dn0, dn0 = 1 */
+  if (dk0 > n) dk0 = n;
+  double d = 0.0;
+  int dk;
+  for (int k = 0; k < n; k += dk) {
+    dk = dk0;
+    if (k + dk >= n || 8 * (long long)(k + dk) + dk > 8 * (long long)n) dk = n - k;
+    double s0 = d, s1 = 0.0; /* do_acc: the first block starts from 0 */
+    int q = 0;
+    for (; q <= dk - 2; q += 2) {
+      s0 += (double)a[sa * (size_t)(k + q)] * (double)b[k + q];
+      s1 += (double)a[sa * (size_t)(k + q + 1)] * (double)b[k + q + 1];
+    }
+    for (; q < dk; q++) s0 += (double)a[sa * (size_t)(k + q)] * (double)b[k + q];
+    d = s0 + s1;
+  }
+  return alpha * d;
+}
+
+/* Tracker.cpp:499-502 (S2, S8): errorMat = inv_num_residuals * Residuals.t() * ResidualsW — MatOp_T::multiply folds the
+ * scalar into the transpose's alpha, MatOp::matmul makes one gemm(R, RW, alpha = inv_n, GEMM_1_T) with a 1x1 result.
+ * w may be NULL (identity). */
 float uwo_error(const float* r, const float* w, int n, int64_t* sum_r2_out) {
-  double s = 0.0;
   int64_t si = 0;
+  float* rw = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
   for (int i = 0; i < n; i++) {
-    float rw = w ? r[i] * w[i] : r[i];
-    s += (double)r[i] * (double)rw;
+    rw[i] = w ? r[i] * w[i] : r[i]; /* :500 Residuals.mul(W) */
     si += (int64_t)lrintf(r[i]) * (int64_t)lrintf(r[i]);
   }
   if (sum_r2_out) *sum_r2_out = si;
   float inv_n = (float)(1.0 / (double)n); /* :499 */
-  return (float)((double)inv_n * s);
+  float e = (float)gemm_dot_width1(r, 1, rw, n, 1, (double)inv_n);
+  free(rw);
+  return e;
 }
 
-/* Tracker.cpp:554-561 (S2).  J <- w∘J ; r <- gain·r ; A = JᵀJ ; b = -Jᵀ(r∘w). */
+/* Tracker.cpp:554-561 (S2).  J <- w∘J ; r <- gain·r ; A = JᵀJ ; b = -Jᵀ(r∘w).
+ * A: gemm(J, J, 1, GEMM_1_T), 6x6, len N — GEMMSingleMul's "d_size.width * sizeof <= 1600" branch (N <= 10000) and
+ * GEMMBlockMul's non-transposed branch (N > 10000, do_acc carrying d_buf) both add the N products of an entry one after
+ * the other in double.  b: "-Jacobians.t()" is MatOp::subtract(Scalar(0), T) = the materialised transpose scaled by -1,
+ * times the materialised Residuals.mul(W): gemm(Jt, RW, alpha = -1) with a 6x1 result — gemm_dot_width1. */
 void uwo_normal_equations(const float* J, const float* r, const float* w, int n, float gain, float A[36], float b[6]) {
-  double Ad[36], bd[6];
+  double Ad[36];
   memset(Ad, 0, sizeof(Ad));
-  memset(bd, 0, sizeof(bd));
+  float* Jw = (float*)malloc(sizeof(float) * 6 * (size_t)(n > 0 ? n : 1));
+  float* rw = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
   for (int i = 0; i < n; i++) {
     float wi = w ? w[i] : 1.0f;
-    float Jr[6];
+    float* Jr = Jw + 6 * (size_t)i;
     for (int k = 0; k < 6; k++) Jr[k] = wi * J[6 * (size_t)i + k]; /* :556 */
     float rg = r[i] * gain;                                        /* :559 */
-    float rw = rg * wi;                                            /* :561 Residuals.mul(W) */
-    for (int a = 0; a < 6; a++) {
+    rw[i] = rg * wi;                                               /* :561 Residuals.mul(W) */
+    for (int a = 0; a < 6; a++)
       for (int c = 0; c < 6; c++) Ad[6 * a + c] += (double)Jr[a] * (double)Jr[c];
-      bd[a] += (double)Jr[a] * (double)rw;
-    }
   }
   for (int k = 0; k < 36; k++) A[k] = (float)Ad[k];
-  for (int k = 0; k < 6; k++) b[k] = (float)(-bd[k]);
+  for (int k = 0; k < 6; k++) b[k] = (float)gemm_dot_width1(Jw + k, 6, rw, n, 6, -1.0);
+  free(Jw); free(rw);
 }
 
 /* cv::Mat::inv() default DECOMP_LU on CV_32F (Tracker.cpp:564; S3): OpenCV 3.x hal LU —
@@ -574,8 +666,52 @@ int uwo_inv6(const float Ain[36], float X[36]) {
   return 1;
 }
 
-/* Tracker.cpp:564 deltaMat = A.inv() * b (S4). */
+/* cv::solve(A, b, x, DECOMP_LU) on CV_32F, 6x6 with one right-hand side (G2): src.copyTo(a), src2.copyTo(dst),
+ * hal::LU32f(a, astep, 6, dst, dstep, 1) = LUImpl<float>(.., eps = FLT_EPSILON*10); "if (!result) dst = Scalar(0)".
+ * The same elimination as uwo_inv6 with the 6x1 right-hand side in place of the identity.  Returns 0 when singular. */
+int uwo_solve6(const float Ain[36], const float bin[6], float x[6]) {
+  const int m = 6;
+  float A[36], b[6];
+  memcpy(A, Ain, sizeof(A));
+  memcpy(b, bin, sizeof(b));
+  const float eps = FLT_EPSILON * 10;
+  for (int i = 0; i < m; i++) {
+    int k = i;
+    for (int j = i + 1; j < m; j++)
+      if (fabsf(A[j * m + i]) > fabsf(A[k * m + i])) k = j;
+    if (fabsf(A[k * m + i]) < eps) {
+      for (int q = 0; q < m; q++) x[q] = 0.0f;
+      return 0;
+    }
+    if (k != i) {
+      for (int j = i; j < m; j++) { float t = A[i * m + j]; A[i * m + j] = A[k * m + j]; A[k * m + j] = t; }
+      float t = b[i]; b[i] = b[k]; b[k] = t;
+    }
+    float d = -1.0f / A[i * m + i];
+    for (int j = i + 1; j < m; j++) {
+      float alpha = A[j * m + i] * d;
+      for (int q = i + 1; q < m; q++) A[j * m + q] = A[j * m + q] + alpha * A[i * m + q];
+      b[j] = b[j] + alpha * b[i];
+    }
+    A[i * m + i] = -d;
+  }
+  for (int i = m - 1; i >= 0; i--) {
+    float s = b[i];
+    for (int q = i + 1; q < m; q++) s = s - A[i * m + q] * b[q];
+    b[i] = s * A[i * m + i];
+  }
+  memcpy(x, b, sizeof(b));
+  return 1;
+}
+
+/* Tracker.cpp:564 deltaMat = A.inv() * b.  G2: MatOp_Invert::matmul turns "A.inv() * b" into MatOp_Solve — cv::solve, no
+ * inverse, no product (the MatExpr class documentation lists it: "A.inv([method]) * B (~ X: AX = B)").
+ * Legacy (S3 + S4): the inverse formed first, then the 6x6·6x1 product accumulated in double. */
 void uwo_solve_delta(const float A[36], const float b[6], float delta[6]) {
+  if (g_arith != UWO_ARITH_LEGACY) {
+    uwo_solve6(A, b, delta);
+    return;
+  }
   float Ai[36];
   uwo_inv6(A, Ai);
   for (int i = 0; i < 6; i++) {
@@ -600,7 +736,7 @@ int uwo_estimate_pose(const uwo_params* p, const uwo_frame* prev, const uwo_fram
 int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const uwo_frame* cur,
                              const float* const* tables, const int32_t* n_points,
                              float pose_out[7], uwo_trace* trace, int32_t* n_trace) {
-  g_small_f64 = p->small_products_f64;
+  uwo_set_arith(p->arith);
   if (p->first_level >= p->n_levels || p->last_level < 0 || p->last_level > p->first_level) return UWO_ERR_INVALID_ARG;
   int cap = (trace && n_trace) ? *n_trace : 0;
   int nt = 0;

@@ -11,23 +11,48 @@
  * of the reference algorithm; every function cites the reference file:line it follows.
  * Third-party arithmetic that is not under /root/reference (OpenCV 3.2 resize / Scharr /
  * gemm / Mat::inv, Eigen3 quaternion kernels) is restated from the published algorithms;
- * the choices are listed under "Pinned semantics" below and in DESIGN.md.
+ * the choices are listed below (G1..G4, S1..S8) and in DESIGN.md.
  *
- * Pinned semantics (S1..S8), all IEEE-754 binary32 unless stated:
- *  S1  small products (4x4·4xN warp, 1x2·2x6 Jacobian row): k-sequential f32 FMA chain
- *      s = a0*b0; s = fma(a1,b1,s); ...
- *  S2  N-long reductions (JᵀJ, Jᵀr, rᵀr): sequential f64 accumulation of exact f32 products,
- *      rounded to f32 once (OpenCV's non-BLAS gemm accumulates f32 data in double).
- *      Σr² is an exact integer (residuals are integer differences of u8).
- *  S3  cv::Mat::inv() = DECOMP_LU: f32 Gaussian elimination with partial pivoting,
- *      pivot threshold 10·FLT_EPSILON, singular ⇒ all-zero inverse; no FMA contraction.
- *  S4  6x6·6x1 solve product: f64 accumulate, round to f32.
+ * Third-party arithmetic, two selectable sets (uwo_params::arith).  All IEEE-754 binary32 unless stated.
+ *
+ * UWO_ARITH_OPENCV (0, the default): OpenCV 3.x's published generic (non-BLAS, non-IPP) code paths, restated from
+ * modules/core/src/matop.cpp (MatExpr algebra), matmul.cpp (gemmImpl / GEMMSingleMul / GEMMBlockMul / GEMMStore),
+ * lapack.cpp + hal (cv::solve / LUImpl), convert.cpp (cvtScale32f), arithm.cpp (multiply / divide / add with a scalar):
+ *  G1  every cv::gemm on CV_32F runs GEMMSingleMul<float,double> / GEMMBlockMul<float,double>: operands widened to
+ *      double, products exact, partial sums in double, ONE rounding to float on store:
+ *      - rigid * points.t() (Tracker.cpp:1450; GEMM_2_T, len 4): s0..s3 take one product each, stored value
+ *        (float)(((T0*X + T1*Y) + T2*Z) + T3*w);
+ *      - Jl * Jw (:479; flags 0, len 2, 1x6 result — the inline len-2 case needs len == d_size.width|height, so the
+ *        generic branch runs): (float)((0 + g0*Jw0k) + g1*Jw1k);
+ *      - Jacobians.t() * Jacobians (:560; GEMM_1_T, 6x6, len N): one sequential double sum per entry (also through
+ *        the block algorithm for N > 10000, whose d_buf carries the sum from block to block);
+ *      - 1-wide results (-Jacobians.t() * Residuals.mul(W) :561, inv_n * Residuals.t() * ResidualsW :501): gemmImpl
+ *        turns them into A*Bt with b_step 0; N <= 10000: four interleaved partial sums ((s0+s1)+s2)+s3 (CV_ENABLE_UNROLLED);
+ *        N > 10000: blocks of dk0 = min(16384/rows, N) terms, two interleaved partial sums per block, the total carried
+ *        in double across blocks; alpha (-1, inv_n) applied in double before the store.
+ *  G2  A.inv() * b (:564) is MatOp_Invert::matmul -> MatOp_Solve -> cv::solve(A, b, x, DECOMP_LU) -> hal::LU32f(A, 6, b, 1):
+ *      f32 Gaussian elimination with partial pivoting applied to the 6x1 right-hand side, back substitution in f32
+ *      (pivot slot holds 1/pivot), |pivot| < 10*FLT_EPSILON => x = 0.  No inverse is formed, no product follows.
+ *  G3  ((col - cx) * invfx) (:1439, :1443) is MatOp_AddEx::multiply folding the scalar into alpha and s (in double),
+ *      assigned through convertTo(alpha, beta) -> cvtScale32f: x*(float)alpha + (float)beta, beta = (float)(-(double)cx *
+ *      (double)invfx): one f32 multiply and one f32 add.
+ *  G4  row *= fx, row /= row2, row += cx, .mul(): separate f32 operations (convertTo scale / cv::divide / cv::add /
+ *      cv::multiply); cv::divide yields 0 for a zero divisor (OpenCV 3.x), such a point fails "z2 != 0" (:451) either way.
+ *
+ * UWO_ARITH_LEGACY (1): the set rounds 1-3 pinned (kept selectable; it is cheaper on the GPU and NOT what OpenCV computes):
+ *  S1  small products (4x4·4xN warp, 1x2·2x6 Jacobian row): k-sequential f32 FMA chain s = a0*b0; s = fma(a1,b1,s); ...
+ *  S3  cv::Mat::inv() as its own step: f32 LU on [A | I] (same elimination as G2), then
+ *  S4  the 6x6·6x1 product with f64 accumulation, rounded to f32;
+ *      unprojection as written, (x - cx) * invfx; N-long sums sequential in double (the 1-wide ones too).
+ *
+ * Common to both sets:
+ *  S2  N-long reductions accumulate exact f32 products in double and round to f32 once; Σr² is an exact integer
+ *      (residuals are integer differences of u8).
  *  S5  sinf/cosf := (float)sin/cos((double)x); sqrtf, 1/x, a/b correctly rounded.
  *  S6  Sophus / Eigen quaternion formulas: generic (non-SIMD) left-to-right f32, no FMA.
  *  S7  nearest-neighbour index round(x2) may equal the dimension (reference reads out of
  *      bounds, Tracker.cpp:450,472); the oracle clamps the index to dim-1.
- *  S8  error = (float)((double)(float)(1.0/N) * (double)Σ w r²)  (scaled-gemm form of
- *      Tracker.cpp:499-502).
+ *  S8  error = (float)((double)(float)(1.0/N) * (double)Σ w r²)  (scaled-gemm form of Tracker.cpp:499-502).
  *
  * Build with -ffp-contract=off (oracle/Makefile does).
  */
@@ -51,6 +76,7 @@ enum {
 
 enum { UWO_WEIGHTS_IDENTITY = 0, UWO_WEIGHTS_TUKEY_REFERENCE = 1, UWO_WEIGHTS_HUBER = 2 };
 enum { UWO_SAMPLER_NEAREST = 0, UWO_SAMPLER_BILINEAR = 1 };
+enum { UWO_ARITH_OPENCV = 0, UWO_ARITH_LEGACY = 1 };
 
 typedef struct uwo_params {
   int32_t width, height;     /* level-0 size */
@@ -70,9 +96,7 @@ typedef struct uwo_params {
   int32_t handoff_scale_t;   /* 0: EstimatePose (:580-590); 1: EstimatePoseFeatures (:856) */
   int32_t weights;           /* UWO_WEIGHTS_* */
   int32_t sampler;           /* UWO_SAMPLER_* (bilinear is a north-star extension, not in the reference) */
-  int32_t small_products_f64;/* 0 (pinned default, S1): 4-term / 2-term products as f32 FMA chains; 1: accumulate them in
-                                f64 and round once, as OpenCV's generic gemm path would.  Sensitivity study only: the GPU
-                                implements S1. */
+  int32_t arith;             /* UWO_ARITH_OPENCV (0, default: G1..G4 above) or UWO_ARITH_LEGACY (1: S1, S3, S4) */
 } uwo_params;
 
 typedef struct uwo_level {
@@ -117,8 +141,9 @@ int  uwo_se3_handoff(float pose[7], int scale_t);                   /* Tracker.c
 
 /* Tracker::WarpFunction, Tracker.cpp:1417-1471 */
 void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, float* warped);
-/* process-wide switch for the sensitivity study (see uwo_params::small_products_f64) */
-void uwo_set_small_products_f64(int on);
+/* Process-wide arithmetic set of the per-stage functions (uwo_warp, uwo_residual_jacobian*, uwo_normal_equations,
+ * uwo_error, uwo_solve_delta); uwo_estimate_pose* set it from uwo_params::arith on entry.  Returns the previous one. */
+int uwo_set_arith(int arith);
 
 /* per-point loop of Tracker::EstimatePose, Tracker.cpp:432-490.
  * J (n x 6) and r (n) receive the valid rows compacted; idx (n, optional) their point index. */
@@ -144,7 +169,8 @@ void  uwo_tukey_weights(const float* r, int n, float* w);
 float uwo_error(const float* r, const float* w, int n, int64_t* sum_r2_out);
 void  uwo_normal_equations(const float* J, const float* r, const float* w, int n, float gain, float A[36], float b[6]);
 int   uwo_inv6(const float A[36], float Ainv[36]);  /* returns 0 when singular (Ainv zeroed) */
-void  uwo_solve_delta(const float A[36], const float b[6], float delta[6]);
+int   uwo_solve6(const float A[36], const float b[6], float x[6]);  /* cv::solve(A, b, x, DECOMP_LU); 0 when singular (x zeroed) */
+void  uwo_solve_delta(const float A[36], const float b[6], float delta[6]);  /* "A.inv() * b" under the current set */
 
 /* one frame's pyramid data as the tracker consumes it */
 typedef struct uwo_frame {

@@ -5,6 +5,9 @@ and cannot be built here, so these fixtures pin the ORACLE's behaviour (regressi
 tests committed expected values.  Independent cross-checks of the oracle's math (scipy expm, numpy inv,
 scipy.ndimage correlate) live in tests/test_oracle.py.
 
+Every arithmetic-dependent vector exists twice: under its plain key for the default set (OpenCV's generic paths,
+O.ARITH_OPENCV) and under "legacy_<key>" for the legacy set (tests/conftest.py::GoldenView picks by the active set).
+
 Run from the repo root:  python tests/golden/make_golden.py
 """
 import importlib
@@ -33,18 +36,20 @@ def pair_case(name, w, h, intr, seed, over, with_depth=False, z=1.0, max_t=0.01,
     fx, fy, cx, cy = intr
     ref, tgt, depth, R, t = synth.render_pair(w, h, fx, fy, cx, cy, seed, z=z, max_t=max_t, max_deg=max_deg,
                                               with_depth=with_depth)
-    p = O.default_params(w, h, fx, fy, cx, cy, **over)
-    if with_depth:
-        p.has_depth = 1
-    st, pose, tr = O.align_pair(p, ref, tgt, depth if with_depth else None, want_trace=True)
-    d = pack_trace(tr)
-    d = {"trace_" + k: v for k, v in d.items()}
-    d.update(ref=ref, tgt=tgt, pose=pose, status=np.int32(st), intr=np.array(intr, np.float32),
+    d = dict(ref=ref, tgt=tgt, intr=np.array(intr, np.float32),
              over_keys=np.array(list(over.keys())), over_vals=np.array([float(v) for v in over.values()]))
     if with_depth:
         d["depth"] = depth
+    for arith, prefix in ((O.ARITH_OPENCV, ""), (O.ARITH_LEGACY, "legacy_")):
+        p = O.default_params(w, h, fx, fy, cx, cy, arith=arith, **over)
+        if with_depth:
+            p.has_depth = 1
+        st, pose, tr = O.align_pair(p, ref, tgt, depth if with_depth else None, want_trace=True)
+        d.update({prefix + "trace_" + k: v for k, v in pack_trace(tr).items()})
+        d[prefix + "pose"] = pose
+        d[prefix + "status"] = np.int32(st)
+        print(name, O.ARITH_NAMES[arith], "status", st, "rows", len(tr), "pose", pose)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
-    print(name, "status", st, "rows", len(tr), "pose", pose)
 
 
 def main():
@@ -71,8 +76,12 @@ def main():
     inv = np.stack([O.inv6(a)[0] for a in As])
     ok = np.array([O.inv6(a)[1] for a in As])
     bs = rng.normal(0, 1, (len(As), 6)).astype(np.float32)
+    O.set_arith(O.ARITH_OPENCV)   # "A.inv() * b" = cv::solve: LU on the right-hand side
     delta = np.stack([O.solve_delta(a, b) for a, b in zip(As, bs)])
-    np.savez_compressed(os.path.join(OUT, "inv6.npz"), A=As, inv=inv, ok=ok, b=bs, delta=delta)
+    O.set_arith(O.ARITH_LEGACY)   # the inverse formed, then multiplied
+    delta_legacy = np.stack([O.solve_delta(a, b) for a, b in zip(As, bs)])
+    O.set_arith(O.ARITH_OPENCV)
+    np.savez_compressed(os.path.join(OUT, "inv6.npz"), A=As, inv=inv, ok=ok, b=bs, delta=delta, legacy_delta=delta_legacy)
 
     # (3) frame pairs + per-iteration traces
     small = (64.0, 64.0, 31.5, 23.5)

@@ -4,6 +4,8 @@ import importlib
 import os
 import re
 
+ARITH_INDEPENDENT = True   # nothing here depends on the arithmetic set (tests/conftest.py): run once
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -28,12 +30,12 @@ def test_library_exports_every_declared_symbol(capi):
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(capi.SYMBOLS) == declared
-    assert lib.uwt_abi_version() == 1
+    assert lib.uwt_abi_version() == 2   # 2: uwt_params::arith
 
 
 def test_struct_layouts_match_header(capi):
     import ctypes as C
-    assert C.sizeof(capi.Params) == 25 * 4
+    assert C.sizeof(capi.Params) == 26 * 4
     assert C.sizeof(capi.Level) == 8 * 4
     assert C.sizeof(capi.Stats) == 16
     assert C.sizeof(capi.Accum) == 21 * 8 + 6 * 8 + 8 + 8

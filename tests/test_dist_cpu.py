@@ -4,6 +4,8 @@ import importlib
 import os
 import socket
 
+ARITH_INDEPENDENT = True   # nothing here depends on the arithmetic set (tests/conftest.py): run once
+
 import numpy as np
 import pytest
 import torch

@@ -97,8 +97,8 @@ def test_stage_kernels_on_random_shapes(capi, O):
             assert np.array_equal(ctx.halve_u16(d16), O.halve_u16(d16)), (h, w)
 
 
-def test_golden_stage_vectors(capi, golden_dir):
-    g = np.load(os.path.join(golden_dir, "stages.npz"))
+def test_golden_stage_vectors(capi, golden):
+    g = golden("stages.npz")
     ctx = make_ctx(capi, 64, 48, SMALL, n_levels=3, first_level=2, last_level=0)
     assert np.array_equal(ctx.halve_u8(g["img"]), g["half"])
     assert np.array_equal(ctx.halve_u16(g["dep"]), g["dep_half"])
@@ -209,8 +209,8 @@ def test_level_info_matches_oracle(capi, O):
 
 # ------------------------------------------------------------------ SE(3), solve
 
-def test_se3_ops_match_oracle_and_golden(capi, O, golden_dir):
-    g = np.load(os.path.join(golden_dir, "se3.npz"))
+def test_se3_ops_match_oracle_and_golden(capi, O, golden):
+    g = golden("se3.npz")
     ctx = make_ctx(capi, 64, 48, SMALL, n_levels=3, first_level=2, last_level=0)
     e = g["exp"]
     for i, xi in enumerate(g["xi"]):
@@ -226,8 +226,8 @@ def test_se3_ops_match_oracle_and_golden(capi, O, golden_dir):
         assert np.array_equal(ctx.se3_exp(xi), O.se3_exp(xi))
 
 
-def test_solve_delta_matches_oracle_and_golden(capi, O, golden_dir):
-    g = np.load(os.path.join(golden_dir, "inv6.npz"))
+def test_solve_delta_matches_oracle_and_golden(capi, O, golden):
+    g = golden("inv6.npz")
     ctx = make_ctx(capi, 64, 48, SMALL, n_levels=3, first_level=2, last_level=0)
     for A, inv, ok, b, d in zip(g["A"], g["inv"], g["ok"], g["b"], g["delta"]):
         dd, Ai, good = ctx.solve_delta(A, b)
@@ -321,8 +321,8 @@ def test_residual_all_invalid_and_nan_safe(capi, O, synth):
 
 # ------------------------------------------------------------------ LS mirror
 
-def test_ls_accumulate_matches_oracle_ls(capi, O, golden_dir):
-    g = np.load(os.path.join(golden_dir, "ls.npz"))
+def test_ls_accumulate_matches_oracle_ls(capi, O, golden):
+    g = golden("ls.npz")
     ctx = make_ctx(capi, 64, 48, SMALL, n_levels=3, first_level=2, last_level=0)
     A, b, err, n = ctx.ls_accumulate(g["J"], g["r"], g["w"], divide=True)
     assert n == 16
@@ -370,8 +370,8 @@ def _golden_over(g):
 
 
 @pytest.mark.parametrize("name", GOLDEN_PAIRS)
-def test_alignment_matches_golden_trace(capi, golden_dir, name):
-    g = np.load(os.path.join(golden_dir, name + ".npz"))
+def test_alignment_matches_golden_trace(capi, golden, name):
+    g = golden(name)
     h, w = g["ref"].shape
     over = _golden_over(g)
     depth = g["depth"] if "depth" in g else None

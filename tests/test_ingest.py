@@ -2,6 +2,8 @@
 CalculateROI, fused remap+crop into a tracker slot."""
 import importlib
 
+ARITH_INDEPENDENT = True   # nothing here depends on the arithmetic set (tests/conftest.py): run once
+
 import numpy as np
 import pytest
 

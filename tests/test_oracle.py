@@ -21,8 +21,8 @@ def hat6(xi):
 
 # ---------------------------------------------------------------- SE(3) (sophus/se3.hpp, so3.hpp)
 
-def test_se3_exp_matches_expm(O, golden_dir):
-    g = np.load(os.path.join(golden_dir, "se3.npz"))
+def test_se3_exp_matches_expm(O, golden):
+    g = golden("se3.npz")
     for xi, e in zip(g["xi"], g["exp"]):
         got = O.se3_exp(xi)
         assert np.array_equal(got, e)  # regression, bit-exact
@@ -43,8 +43,8 @@ def test_se3_exp_small_angle_branch(O):
     assert np.array_equal(ident, np.array([0, 0, 0, 1, 0, 0, 0], np.float32))
 
 
-def test_se3_mul_matches_matrix_product(O, golden_dir):
-    g = np.load(os.path.join(golden_dir, "se3.npz"))
+def test_se3_mul_matches_matrix_product(O, golden):
+    g = golden("se3.npz")
     e = g["exp"]
     for i in range(len(e)):
         a, b = e[i], e[(i + 1) % len(e)]
@@ -54,9 +54,9 @@ def test_se3_mul_matches_matrix_product(O, golden_dir):
         assert np.allclose(O.se3_matrix(got), ref, atol=5e-6 * max(1.0, np.abs(ref).max()))
 
 
-def test_se3_handoff(O, golden_dir):
+def test_se3_handoff(O, golden):
     # Tracker.cpp:580-590: q.xyz *= 2 then normalise; t unchanged (EstimatePose) or doubled (EstimatePoseFeatures :856)
-    g = np.load(os.path.join(golden_dir, "se3.npz"))
+    g = golden("se3.npz")
     for e, h0, h1 in zip(g["exp"], g["handoff"], g["handoff_t"]):
         a = O.se3_handoff(e, 0)
         b = O.se3_handoff(e, 1)
@@ -71,8 +71,8 @@ def test_se3_handoff(O, golden_dir):
 
 # ---------------------------------------------------------------- 6x6 LU inverse (cv::Mat::inv, Tracker.cpp:564)
 
-def test_inv6_matches_numpy_and_singular_is_zero(O, golden_dir):
-    g = np.load(os.path.join(golden_dir, "inv6.npz"))
+def test_inv6_matches_numpy_and_singular_is_zero(O, golden):
+    g = golden("inv6.npz")
     for A, inv, ok, b, d in zip(g["A"], g["inv"], g["ok"], g["b"], g["delta"]):
         X, good = O.inv6(A)
         assert good == bool(ok)
@@ -92,8 +92,8 @@ def test_inv6_matches_numpy_and_singular_is_zero(O, golden_dir):
 
 # ---------------------------------------------------------------- pyramid / gradients (System.cpp:246-251, Tracker.cpp:1133-1142)
 
-def test_halve_is_rounded_2x2_mean(O, golden_dir):
-    g = np.load(os.path.join(golden_dir, "stages.npz"))
+def test_halve_is_rounded_2x2_mean(O, golden):
+    g = golden("stages.npz")
     img = g["img"]
     ref = (img[0::2, 0::2].astype(int) + img[0::2, 1::2] + img[1::2, 0::2] + img[1::2, 1::2] + 2) >> 2
     assert np.array_equal(O.halve_u8(img), ref)
@@ -104,8 +104,8 @@ def test_halve_is_rounded_2x2_mean(O, golden_dir):
     assert np.array_equal(O.halve_u16(dep), g["dep_half"])
 
 
-def test_scharr3_matches_scipy_correlate(O, golden_dir):
-    g = np.load(os.path.join(golden_dir, "stages.npz"))
+def test_scharr3_matches_scipy_correlate(O, golden):
+    g = golden("stages.npz")
     img = g["img"]
     kx = 3 * np.array([[-3, 0, 3], [-10, 0, 10], [-3, 0, 3]])
     gx_ref = ndimage.correlate(img.astype(np.int32), kx, mode="mirror")  # scipy 'mirror' == OpenCV BORDER_REFLECT_101
@@ -236,8 +236,8 @@ def test_tukey_weights_reference_quirks(O):
 
 # ---------------------------------------------------------------- LS (LeastSquares.cpp)
 
-def test_ls_closed_forms_and_sse_equivalence(O, golden_dir):
-    g = np.load(os.path.join(golden_dir, "ls.npz"))
+def test_ls_closed_forms_and_sse_equivalence(O, golden):
+    g = golden("ls.npz")
     J, r, w = g["J"], g["r"], g["w"]
     ls = O.ls_new()
     O.ls_update(ls, J[0], r[0], w[0])
@@ -290,7 +290,7 @@ def test_shift_is_recovered_in_sign_and_scale(O, synth):
     st, pose, _ = O.align_pair(p, ref, tgt)
     assert st == 0
     assert 0.3 * 2 / fx < pose[4] < 2.0 * 2 / fx
-    assert abs(pose[5]) < 0.5 * pose[4]
+    assert abs(pose[5]) < 0.6 * pose[4]   # (0.54 under the OpenCV set, 0.4 under the legacy one: the fixed schedule amplifies 1-ulp differences)
 
 
 def test_no_valid_points_status(O, synth):
@@ -317,8 +317,8 @@ def params_from_golden(O, g):
 
 
 @pytest.mark.parametrize("name", GOLDEN_PAIRS)
-def test_golden_pair_regression(O, golden_dir, name):
-    g = np.load(os.path.join(golden_dir, name + ".npz"))
+def test_golden_pair_regression(O, golden, name):
+    g = golden(name)
     p = params_from_golden(O, g)
     st, pose, tr = O.align_pair(p, g["ref"], g["tgt"], g["depth"] if "depth" in g else None, want_trace=True)
     assert st == int(g["status"])
@@ -332,9 +332,9 @@ def test_golden_pair_regression(O, golden_dir, name):
         assert np.array_equal(t["pose"], g["trace_pose"][i])
 
 
-def test_golden_trace_is_self_consistent_with_float64(O, golden_dir):
+def test_golden_trace_is_self_consistent_with_float64(O, golden):
     """Brute-force float64 recomputation of A, b, error for one iteration of a golden trace."""
-    g = np.load(os.path.join(golden_dir, "pair_160x96_fixed.npz"))
+    g = golden("pair_160x96_fixed.npz")
     p = params_from_golden(O, g)
     ref, tgt = g["ref"], g["tgt"]
     lvl, it = int(g["trace_level"][3]), 3
@@ -355,19 +355,31 @@ def test_golden_trace_is_self_consistent_with_float64(O, golden_dir):
     assert np.allclose(g["trace_b"][it], -(Jd.T @ (50.0 * r.astype(np.float64))), rtol=1e-6, atol=1e-3)
 
 
-def test_small_product_semantics_sensitivity(O, synth):
-    """The pinned choice S1 (f32 FMA chains for the 4-term warp product and the 2-term Jacobian row) against the other
-    plausible reading of cv::gemm (accumulate in double, round once): same algorithm, different last bits per pixel —
-    and, because the iteration is not a contraction, poses that differ by more than the 1e-4 parity
-    tolerance.  This is why parity is only meaningful against a bit-pinned oracle."""
+@pytest.mark.one_arith
+def test_arithmetic_set_sensitivity(O, synth):
+    """Distance between the two arithmetic sets (OpenCV's generic paths — double-accumulated 4-/2-term gemm products, the
+    folded unprojection, A.inv()*b as a solve — against the legacy f32 FMA chains / inverse-then-multiply): the same
+    algorithm, last bits per pixel term apart.  In the reference's own schedule (levels 4 -> 1, early exit: one or two updates
+    per level) the poses stay within 2e-5 m of each other — inside the 1e-4 parity tolerance; in the fixed 4 x 10 schedule
+    the non-contractive iteration amplifies the same differences to 1e-3 m.  This is why parity is only
+    meaningful against a bit-pinned oracle, and why the pinned set has to be OpenCV's.  (tools/exp/arith_distance.py prints
+    the table for 320x240 and 640x480, with and without depth.)"""
     w, h, f = 320, 240, 262.5
-    over = dict(n_levels=4, first_level=3, last_level=0, max_iters=10, early_exit=0)
-    dts = []
-    for s in (4000, 4007):
+    fixed = dict(n_levels=4, first_level=3, last_level=0, max_iters=10, early_exit=0)
+    dist = {"fixed": [], "reference": []}
+    for s in (4000, 4007, 4011):
         ref, tgt, _, _, _ = synth.render_pair(w, h, f, f, 159.5, 119.5, seed=s)
-        a = O.align_pair(O.default_params(w, h, f, f, 159.5, 119.5, **over), ref, tgt)[1]
-        b = O.align_pair(O.default_params(w, h, f, f, 159.5, 119.5, small_products_f64=1, **over), ref, tgt)[1]
-        c = O.align_pair(O.default_params(w, h, f, f, 159.5, 119.5, **over), ref, tgt)[1]
-        assert np.array_equal(a, c)                     # the switch does not leak between calls
-        dts.append(float(np.linalg.norm(a[4:] - b[4:])))
-    assert all(0 < d < 1e-2 for d in dts)
+        for name, over in (("fixed", fixed), ("reference", {})):
+            a = O.align_pair(O.default_params(w, h, f, f, 159.5, 119.5, arith=O.ARITH_OPENCV, **over), ref, tgt)[1]
+            b = O.align_pair(O.default_params(w, h, f, f, 159.5, 119.5, arith=O.ARITH_LEGACY, **over), ref, tgt)[1]
+            c = O.align_pair(O.default_params(w, h, f, f, 159.5, 119.5, arith=O.ARITH_OPENCV, **over), ref, tgt)[1]
+            assert np.array_equal(a, c)                     # the switch does not leak between calls
+            dist[name].append(float(np.linalg.norm(a[4:].astype(np.float64) - b[4:].astype(np.float64))))
+    assert all(0 < d < 1e-2 for d in dist["fixed"]), dist
+    assert max(dist["fixed"]) > 1e-5, dist                # the fixed schedule does amplify
+    assert all(d < 1e-4 for d in dist["reference"]), dist   # the reference's schedule does not
+
+
+def test_oracle_params_reject_unknown_fields(O):
+    with pytest.raises(AttributeError):
+        O.default_params(64, 48, 64.0, 64.0, 31.5, 23.5, small_products_f64=1)

@@ -195,38 +195,3 @@ def test_tracker_mirror_weight_helpers(O):
     ox, oy = O.scharr3(img)
     assert np.array_equal(gx, ox) and np.array_equal(gy, oy)
 
-
-@pytest.mark.gpu
-def test_fused_robust_launch_is_bit_identical_when_selected():
-    """UWT_FUSED=1 selects k_residual_fused (scale pass and weighted accumulation in one launch, a pair's blocks waiting for the
-    pair's scale) — measured slower than the two launches and therefore not the default, but kept, and kept correct: a batch
-    of pairs (several blocks per pair on every level), depth with holes, Tukey and Huber, every pose bit-identical to the
-    oracle's.  A child process: the switch is read when a context is created."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
-import importlib, sys, numpy as np
-sys.path.insert(0, %r)
-capi = importlib.import_module("uw-slam_amd.capi"); synth = importlib.import_module("uw-slam_amd.synth")
-from oracle import oracle as O
-w, h, intr = 320, 240, (262.5, 262.5, 159.5, 119.5)
-n = 12
-pairs = [synth.render_pair(w, h, *intr, seed=500 + i, z=0.85 + 0.03 * i, with_depth=True) for i in range(n)]
-frames = np.stack([f for p in pairs for f in (p[0], p[1])]); depth = np.stack([p[2] for p in pairs for _ in (0, 1)])
-for weights in (1, 2):
-    over = dict(n_levels=4, first_level=3, last_level=0, max_iters=5, early_exit=0, has_depth=1, weights=weights)
-    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
-    ctx.upload_frames(0, frames, depth); ctx.build_pyramids(0, 2 * n); ctx.apply_gradient(0, 2 * n)
-    poses, stats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1, raise_on_pair_failure=True)
-    po = O.default_params(w, h, *intr, **over)
-    for i, p in enumerate(pairs):
-        st, pose_cpu, _ = O.align_pair(po, p[0], p[1], p[2])
-        assert st == 0 and np.array_equal(poses[i].view(np.uint32), pose_cpu.view(np.uint32)), (weights, i, poses[i], pose_cpu)
-    ctx.close()
-print("ok")
-''' % root
-    env = dict(os.environ, UWT_FUSED="1")
-    r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=540)
-    assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]

@@ -1,6 +1,8 @@
 """trajectory accumulation (Visualizer::UpdateMessages) and its file formats."""
 import importlib
 
+ARITH_INDEPENDENT = True   # nothing here depends on the arithmetic set (tests/conftest.py): run once
+
 import numpy as np
 import pytest
 

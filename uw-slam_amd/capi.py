@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libuwt_hip.so")
 OK, ERR_INVALID_ARG, ERR_NO_VALID_POINTS, ERR_HIP, ERR_NO_DEVICE, ERR_CAPACITY, ERR_PAIR_FAILED = range(7)
 PLANE_IMAGE, PLANE_DEPTH, PLANE_GRADX, PLANE_GRADY = range(4)
 MAX_LEVELS = 8
+ARITH_OPENCV, ARITH_LEGACY = 0, 1   # uwt_params.arith (include/uwt.h: enum uwt_arith)
 
 
 class Params(C.Structure):
@@ -24,6 +25,7 @@ class Params(C.Structure):
         ("depth_scale", C.c_float), ("initial_error", C.c_float),
         ("early_exit", C.c_int32), ("has_depth", C.c_int32), ("handoff_scale_t", C.c_int32),
         ("accumulate_f64", C.c_int32), ("sampler", C.c_int32), ("weights", C.c_int32), ("max_frames", C.c_int32), ("max_pairs", C.c_int32), ("device", C.c_int32),
+        ("arith", C.c_int32),
     ]
 
 
@@ -98,11 +100,16 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
+DEFAULT_ARITH = None   # None: the library's default (ARITH_OPENCV); the parity suite sets it to run every test under both sets
+
+
 def default_params(width, height, fx, fy, cx, cy, **over):
     p = Params()
     st = lib().uwt_default_params(C.byref(p), width, height, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy))
     if st:
         raise UwtError(st, "uwt_default_params")
+    if DEFAULT_ARITH is not None:
+        p.arith = DEFAULT_ARITH
     for k, v in over.items():
         if not hasattr(p, k):
             raise AttributeError(k)

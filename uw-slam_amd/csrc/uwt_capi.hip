@@ -98,13 +98,6 @@ struct uwt_ctx {
   bool inline_pairs = false;
   bool deferred = false;                // uwt_set_deferred: stage calls return once enqueued
   bool coarse = true;                   // k_coarse for the coarsest levels of the chained flow (UWT_NO_COARSE=1: off)
-  bool fused = false;                   // UWT_FUSED=1: robust weights through k_residual_fused (scale pass + weighted accumulation in one
-                                        // launch); built in round 3, bit-identical, and slower than the two launches (37 k against 47 k
-                                        // alignments/s at 256 pairs): off unless asked for
-  unsigned long long* d_ready = nullptr;   // [max_pairs] {epoch, 1 / MAD} words of k_residual_fused
-  int* d_fused_err = nullptr;           // raised by a block whose poll ran out
-  unsigned fused_epoch = 0;
-  bool fused_used = false;              // a fused launch has been enqueued since the flag was last looked at
   int coarse_batch_px = 0;              // batches: levels of up to this many pixels run in one k_coarse launch (UWT_COARSE_BATCH_PX)
   int pair_slots[4] = {0, 0, 0, 0};
   int first_poll = 3;                   // evaluations of a level before the first early-exit read-back
@@ -136,6 +129,13 @@ int fail(uwt_ctx* c, int code, const std::string& msg) {
   if (c) c->last_error = msg;
   return code;
 }
+
+// runs the statements with AR a compile-time constant: the context's arithmetic set (uwt_params::arith)
+#define UWT_WITH_ARITH(ctx, ...)                                             \
+  do {                                                                       \
+    if ((ctx)->p.arith == UWT_ARITH_LEGACY) { constexpr int AR = kArithLegacy; __VA_ARGS__; }  \
+    else { constexpr int AR = kArithOpenCV; __VA_ARGS__; }                   \
+  } while (0)
 
 #define HIPCHK(ctx, expr)                                                                                   \
   do {                                                                                                      \
@@ -178,6 +178,9 @@ void init_levels(uwt_ctx* c) {
     LevelK& L = c->lv[l];
     L.w = I.w; L.h = I.h; L.n = I.w * I.h;
     L.fx = I.fx; L.fy = I.fy; L.cx = I.cx; L.cy = I.cy; L.invfx = I.invfx; L.invfy = I.invfy;
+    // "(col - cx) * invfx" (src/Tracker.cpp:1439): MatOp_AddEx::multiply scales s = -cx by invfx in double, convertTo narrows
+    L.bx = (float)(-(double)I.cx * (double)I.invfx);
+    L.by = (float)(-(double)I.cy * (double)I.invfy);
     L.zscale = (float)((double)p.depth_scale / std::pow(2.0, (double)l));  // src/Tracker.cpp:1266
     L.magic = (uint32_t)((0x100000000ull + (uint64_t)I.w - 1) / (uint64_t)I.w);
   }
@@ -246,20 +249,20 @@ int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int 
   return UWT_OK;
 }
 
-template <int VEC, bool DEPTH, bool UNIT, bool DUMP>
+template <int AR, int VEC, bool DEPTH, bool UNIT, bool DUMP>
 void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64, bool compute_only) {
   if constexpr (VEC == 4 && UNIT && !DUMP) {
     if (compute_only && acc64 && a.L.fx == a.L.fy) {  // diagnostic twin of the production instantiation
-      hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+      hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
       return;
     }
   }
   if (acc64 && UNIT && VEC == 4 && !DUMP && a.L.fx == a.L.fy)
-    hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, double, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
   else if (acc64)
-    hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, double>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
   else
-    hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, DUMP, float>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+    hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, float>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
 }
 
 int launch_residual(uwt_ctx* c, const ResidualArgs& a, int n_pairs, bool dump) {
@@ -269,24 +272,25 @@ int launch_residual(uwt_ctx* c, const ResidualArgs& a, int n_pairs, bool dump) {
   hipStream_t s = c->stream;
   const bool acc64 = c->p.accumulate_f64 != 0;
   const bool co = c->compute_only && !dump;
+  UWT_WITH_ARITH(c,
   switch (key) {
-    case 0: launch_residual_t<1, false, false, false>(s, a, n_pairs, acc64, co); break;
-    case 1: launch_residual_t<1, false, false, true>(s, a, n_pairs, acc64, co); break;
-    case 2: launch_residual_t<1, false, true, false>(s, a, n_pairs, acc64, co); break;
-    case 3: launch_residual_t<1, false, true, true>(s, a, n_pairs, acc64, co); break;
-    case 4: launch_residual_t<1, true, false, false>(s, a, n_pairs, acc64, co); break;
-    case 5: launch_residual_t<1, true, false, true>(s, a, n_pairs, acc64, co); break;
-    case 6: launch_residual_t<1, true, true, false>(s, a, n_pairs, acc64, co); break;
-    case 7: launch_residual_t<1, true, true, true>(s, a, n_pairs, acc64, co); break;
-    case 8: launch_residual_t<4, false, false, false>(s, a, n_pairs, acc64, co); break;
-    case 9: launch_residual_t<4, false, false, true>(s, a, n_pairs, acc64, co); break;
-    case 10: launch_residual_t<4, false, true, false>(s, a, n_pairs, acc64, co); break;
-    case 11: launch_residual_t<4, false, true, true>(s, a, n_pairs, acc64, co); break;
-    case 12: launch_residual_t<4, true, false, false>(s, a, n_pairs, acc64, co); break;
-    case 13: launch_residual_t<4, true, false, true>(s, a, n_pairs, acc64, co); break;
-    case 14: launch_residual_t<4, true, true, false>(s, a, n_pairs, acc64, co); break;
-    default: launch_residual_t<4, true, true, true>(s, a, n_pairs, acc64, co); break;
-  }
+    case 0: launch_residual_t<AR, 1, false, false, false>(s, a, n_pairs, acc64, co); break;
+    case 1: launch_residual_t<AR, 1, false, false, true>(s, a, n_pairs, acc64, co); break;
+    case 2: launch_residual_t<AR, 1, false, true, false>(s, a, n_pairs, acc64, co); break;
+    case 3: launch_residual_t<AR, 1, false, true, true>(s, a, n_pairs, acc64, co); break;
+    case 4: launch_residual_t<AR, 1, true, false, false>(s, a, n_pairs, acc64, co); break;
+    case 5: launch_residual_t<AR, 1, true, false, true>(s, a, n_pairs, acc64, co); break;
+    case 6: launch_residual_t<AR, 1, true, true, false>(s, a, n_pairs, acc64, co); break;
+    case 7: launch_residual_t<AR, 1, true, true, true>(s, a, n_pairs, acc64, co); break;
+    case 8: launch_residual_t<AR, 4, false, false, false>(s, a, n_pairs, acc64, co); break;
+    case 9: launch_residual_t<AR, 4, false, false, true>(s, a, n_pairs, acc64, co); break;
+    case 10: launch_residual_t<AR, 4, false, true, false>(s, a, n_pairs, acc64, co); break;
+    case 11: launch_residual_t<AR, 4, false, true, true>(s, a, n_pairs, acc64, co); break;
+    case 12: launch_residual_t<AR, 4, true, false, false>(s, a, n_pairs, acc64, co); break;
+    case 13: launch_residual_t<AR, 4, true, false, true>(s, a, n_pairs, acc64, co); break;
+    case 14: launch_residual_t<AR, 4, true, true, false>(s, a, n_pairs, acc64, co); break;
+    default: launch_residual_t<AR, 4, true, true, true>(s, a, n_pairs, acc64, co); break;
+  });
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
 }
@@ -355,105 +359,65 @@ GeneralArgs general_args(uwt_ctx* c) {
 // One residual evaluation on the general path (robust weights and/or bilinear sampler) for pairs [pair_base, +n):
 // with weights on, one histogram pass estimates the scale first (MedianMat / MedianAbsoluteDeviation,
 // src/Tracker.cpp:1571-1619), then the weighted accumulation runs.  Records use one pixel per point and 8192 per block.
-template <int VEC, bool DEPTH, bool UNIT>
+template <int AR, int VEC, bool DEPTH, bool UNIT>
 void launch_general_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sampler, int weights) {
   const dim3 grid(a.slices, n_pairs), blk(kBlock);
   const int key = sampler * 3 + weights;
   if constexpr (VEC == 4 && UNIT) {
     if (a.L.fx == a.L.fy) {   // SQUARE: the Jacobian's coinciding products once (pixel_jacobian), as on the identity path
       switch (key) {
-        case 1: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, true, 0, 1>), grid, blk, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, true, 0, 2>), grid, blk, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, true, 1, 0>), grid, blk, 0, s, a); break;
-        default: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, true, 1, 2>), grid, blk, 0, s, a); break;
+        case 1: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 1>), grid, blk, 0, s, a); break;
+        case 2: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 2>), grid, blk, 0, s, a); break;
+        case 3: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 1, 0>), grid, blk, 0, s, a); break;
+        default: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 1, 2>), grid, blk, 0, s, a); break;
       }
       return;
     }
   }
   switch (key) {
-    case 1: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, false, 0, 1>), grid, blk, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, false, 0, 2>), grid, blk, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, false, 1, 0>), grid, blk, 0, s, a); break;
-    default: hipLaunchKernelGGL((k_residual<VEC, DEPTH, UNIT, false, double, false, 1, 2>), grid, blk, 0, s, a); break;
-  }
-}
-
-// Robust weights over integer residuals take the fused launch (k_residual_fused: scale pass and weighted accumulation in one,
-// a pair's blocks waiting for the pair's scale) on the levels where a pair's blocks — kFusedG groups per thread each — are
-// few enough to be resident together many times over, and where the records the context holds per pair suffice.
-constexpr int kFusedMaxSlices = 256;
-int fused_slices(const uwt_ctx* c, int lvl) {
-  const int n_groups = c->lv[lvl].n / 4;
-  return (n_groups + kFusedG * kBlock - 1) / (kFusedG * kBlock);
-}
-bool takes_fused(const uwt_ctx* c, int lvl) {
-  if (!c->fused || c->vec != 4 || !c->p.weights || c->p.sampler || !c->p.accumulate_f64 || c->compute_only) return false;
-  const int sl = fused_slices(c, lvl);
-  return sl <= kFusedMaxSlices && sl <= c->slices[lvl];
-}
-
-template <bool DEPTH, bool UNIT>
-void launch_fused_t(hipStream_t s, const ResidualArgs& a, const FusedArgs& fa, int n_pairs) {
-  const dim3 grid(a.slices, n_pairs), blk(kBlock);
-  const bool sq = UNIT && a.L.fx == a.L.fy;
-  if (fa.weights == kWeightsTukeyRef) {
-    if (sq) hipLaunchKernelGGL((k_residual_fused<DEPTH, UNIT, true, kWeightsTukeyRef>), grid, blk, 0, s, a, fa);
-    else hipLaunchKernelGGL((k_residual_fused<DEPTH, UNIT, false, kWeightsTukeyRef>), grid, blk, 0, s, a, fa);
-  } else {
-    if (sq) hipLaunchKernelGGL((k_residual_fused<DEPTH, UNIT, true, kWeightsHuber>), grid, blk, 0, s, a, fa);
-    else hipLaunchKernelGGL((k_residual_fused<DEPTH, UNIT, false, kWeightsHuber>), grid, blk, 0, s, a, fa);
+    case 1: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 0, 1>), grid, blk, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 0, 2>), grid, blk, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 1, 0>), grid, blk, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 1, 2>), grid, blk, 0, s, a); break;
   }
 }
 
 // The alignment loop's launch on the general path: the scale pass (weights only), then the dense kernel specialised for
 // the sampler / weights.  Same slicing as the fast path.
-int launch_general(uwt_ctx* c, const ResidualArgs& ra, int n_pairs, bool fused = false) {
+int launch_general(uwt_ctx* c, const ResidualArgs& ra, int n_pairs) {
   const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f);
   GeneralArgs ga = general_args(c);
-  if (fused) {   // (the caller sliced the level for it: kFusedG groups per thread)
-    FusedArgs fa;
-    fa.hist = c->hist;
-    fa.ready = c->d_ready;
-    fa.scale_out = c->scale;
-    fa.error = c->d_fused_err;
-    if (++c->fused_epoch == 0) ++c->fused_epoch;
-    fa.epoch = c->fused_epoch;
-    fa.weights = ga.weights;
-    c->fused_used = true;
-    if (depth) { if (unit) launch_fused_t<true, true>(c->stream, ra, fa, n_pairs); else launch_fused_t<true, false>(c->stream, ra, fa, n_pairs); }
-    else { if (unit) launch_fused_t<false, true>(c->stream, ra, fa, n_pairs); else launch_fused_t<false, false>(c->stream, ra, fa, n_pairs); }
-    HIPCHK(c, hipGetLastError());
-    return UWT_OK;
-  }
   if (ga.weights) {
     // the scale pass: residual histograms per pair, the scale derived in the tail of the pair's last block; the histograms
     // are all-zero before and after (cleared once per alignment call, enqueue_estimate)
     const dim3 grid(ra.slices, n_pairs), blk(kBlock);
     const int hk = (c->vec == 4 ? 4 : 0) | (depth ? 2 : 0) | (ga.sampler ? 1 : 0);
+    UWT_WITH_ARITH(c,
     switch (hk) {
-      case 0: hipLaunchKernelGGL((k_resid_hist_v<1, false, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 1: hipLaunchKernelGGL((k_resid_hist_v<1, false, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 2: hipLaunchKernelGGL((k_resid_hist_v<1, true, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 3: hipLaunchKernelGGL((k_resid_hist_v<1, true, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 4: hipLaunchKernelGGL((k_resid_hist_v<4, false, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 5: hipLaunchKernelGGL((k_resid_hist_v<4, false, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 6: hipLaunchKernelGGL((k_resid_hist_v<4, true, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      default: hipLaunchKernelGGL((k_resid_hist_v<4, true, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-    }
+      case 0: hipLaunchKernelGGL((k_resid_hist_v<AR, 1, false, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 1: hipLaunchKernelGGL((k_resid_hist_v<AR, 1, false, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 2: hipLaunchKernelGGL((k_resid_hist_v<AR, 1, true, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 3: hipLaunchKernelGGL((k_resid_hist_v<AR, 1, true, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 4: hipLaunchKernelGGL((k_resid_hist_v<AR, 4, false, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 5: hipLaunchKernelGGL((k_resid_hist_v<AR, 4, false, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      case 6: hipLaunchKernelGGL((k_resid_hist_v<AR, 4, true, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+      default: hipLaunchKernelGGL((k_resid_hist_v<AR, 4, true, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
+    });
     HIPCHK(c, hipGetLastError());
   }
   const int key = (c->vec == 4 ? 4 : 0) | (depth ? 2 : 0) | (unit ? 1 : 0);
   hipStream_t s = c->stream;
+  UWT_WITH_ARITH(c,
   switch (key) {
-    case 0: launch_general_t<1, false, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 1: launch_general_t<1, false, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 2: launch_general_t<1, true, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 3: launch_general_t<1, true, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 4: launch_general_t<4, false, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 5: launch_general_t<4, false, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 6: launch_general_t<4, true, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    default: launch_general_t<4, true, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-  }
+    case 0: launch_general_t<AR, 1, false, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 1: launch_general_t<AR, 1, false, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 2: launch_general_t<AR, 1, true, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 3: launch_general_t<AR, 1, true, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 4: launch_general_t<AR, 4, false, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 5: launch_general_t<AR, 4, false, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    case 6: launch_general_t<AR, 4, true, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+    default: launch_general_t<AR, 4, true, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
+  });
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
 }
@@ -474,16 +438,18 @@ int launch_general_dump(uwt_ctx* c, ResidualArgs ra, int n_pairs, int* slices_ou
   const dim3 grid(ra.slices, n_pairs), blk(kBlock);
   if (ga.weights) {
     HIPCHK(c, hipMemsetAsync(c->hist + (size_t)ra.pair_base * kHistBins, 0, sizeof(unsigned int) * kHistBins * n_pairs, c->stream));
-    if (depth) hipLaunchKernelGGL(k_resid_hist<true>, grid, blk, 0, c->stream, ra, ga);
-    else hipLaunchKernelGGL(k_resid_hist<false>, grid, blk, 0, c->stream, ra, ga);
+    UWT_WITH_ARITH(c,
+      if (depth) hipLaunchKernelGGL((k_resid_hist<AR, true>), grid, blk, 0, c->stream, ra, ga);
+      else hipLaunchKernelGGL((k_resid_hist<AR, false>), grid, blk, 0, c->stream, ra, ga));
     HIPCHK(c, hipGetLastError());
     hipLaunchKernelGGL(k_scale_stage, dim3((n_pairs + 3) / 4), dim3(256), 0, c->stream, ga, ra.state, n_pairs, ra.pair_base);
     HIPCHK(c, hipGetLastError());
   }
-  if (depth && unit) hipLaunchKernelGGL((k_residual_general<true, true>), grid, blk, 0, c->stream, ra, ga);
-  else if (depth) hipLaunchKernelGGL((k_residual_general<true, false>), grid, blk, 0, c->stream, ra, ga);
-  else if (unit) hipLaunchKernelGGL((k_residual_general<false, true>), grid, blk, 0, c->stream, ra, ga);
-  else hipLaunchKernelGGL((k_residual_general<false, false>), grid, blk, 0, c->stream, ra, ga);
+  UWT_WITH_ARITH(c,
+    if (depth && unit) hipLaunchKernelGGL((k_residual_general<AR, true, true>), grid, blk, 0, c->stream, ra, ga);
+    else if (depth) hipLaunchKernelGGL((k_residual_general<AR, true, false>), grid, blk, 0, c->stream, ra, ga);
+    else if (unit) hipLaunchKernelGGL((k_residual_general<AR, false, true>), grid, blk, 0, c->stream, ra, ga);
+    else hipLaunchKernelGGL((k_residual_general<AR, false, false>), grid, blk, 0, c->stream, ra, ga));
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
 }
@@ -498,6 +464,7 @@ UpdateArgs update_args(uwt_ctx* c, int lvl) {
   ua.early_exit = c->p.early_exit;
   ua.epsilon = c->p.epsilon;
   ua.gain = c->p.gain;
+  ua.legacy_solve = c->p.arith == UWT_ARITH_LEGACY ? 1 : 0;
   return ua;
 }
 
@@ -511,30 +478,32 @@ void arm_tail(uwt_ctx* c, ResidualArgs& ra, const UpdateArgs& ua) {
   ra.tail.max_iters = ua.max_iters;
   ra.tail.early_exit = ua.early_exit;
   ra.tail.general = ua.general;
+  ra.tail.legacy_solve = ua.legacy_solve;
   ra.tail.epsilon = ua.epsilon;
   ra.tail.gain = ua.gain;
 }
 
 // k_iterate launch for the dense nearest-neighbour / identity-weights path (VEC = 4)
-template <bool DEPTH, bool UNIT>
+template <int AR, bool DEPTH, bool UNIT>
 void launch_iterate_t(hipStream_t s, const ResidualArgs& a, const IterArgs& ia, int n_pairs, bool acc64, bool compute_only) {
   const dim3 grid(a.slices, n_pairs), blk(kBlock);
   const bool square = a.L.fx == a.L.fy;
   const bool wide = n_pairs > 3;   // four blocks per CU (two-pass reduction) instead of blocks alone on their CUs
-  if (acc64 && square && UNIT && compute_only) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, true, true>), grid, blk, 0, s, a, ia);
-  else if (acc64 && square && UNIT && wide) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, true, false, 14>), grid, blk, 0, s, a, ia);
-  else if (acc64 && square && UNIT) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, true>), grid, blk, 0, s, a, ia);
-  else if (acc64 && wide) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, false, false, 14>), grid, blk, 0, s, a, ia);
-  else if (acc64) hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, double, false>), grid, blk, 0, s, a, ia);
-  else hipLaunchKernelGGL((k_iterate<4, DEPTH, UNIT, float, false>), grid, blk, 0, s, a, ia);
+  if (acc64 && square && UNIT && compute_only) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, double, true, true>), grid, blk, 0, s, a, ia);
+  else if (acc64 && square && UNIT && wide) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, double, true, false, 14>), grid, blk, 0, s, a, ia);
+  else if (acc64 && square && UNIT) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, double, true>), grid, blk, 0, s, a, ia);
+  else if (acc64 && wide) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, double, false, false, 14>), grid, blk, 0, s, a, ia);
+  else if (acc64) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, double, false>), grid, blk, 0, s, a, ia);
+  else hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, float, false>), grid, blk, 0, s, a, ia);
 }
 
 int launch_iterate(uwt_ctx* c, const ResidualArgs& a, const IterArgs& ia, int n_pairs) {
   const bool depth = c->p.has_depth != 0, unit = (a.zf == 1.0f && a.af == 1.0f), acc64 = c->p.accumulate_f64 != 0;
-  if (depth && unit) launch_iterate_t<true, true>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
-  else if (depth) launch_iterate_t<true, false>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
-  else if (unit) launch_iterate_t<false, true>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
-  else launch_iterate_t<false, false>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
+  UWT_WITH_ARITH(c,
+    if (depth && unit) launch_iterate_t<AR, true, true>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
+    else if (depth) launch_iterate_t<AR, true, false>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
+    else if (unit) launch_iterate_t<AR, false, true>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
+    else launch_iterate_t<AR, false, false>(c->stream, a, ia, n_pairs, acc64, c->compute_only));
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
 }
@@ -554,6 +523,7 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
   ia.u.early_exit = p.early_exit;
   ia.u.epsilon = p.epsilon;
   ia.u.gain = p.gain;
+  ia.u.legacy_solve = p.arith == UWT_ARITH_LEGACY ? 1 : 0;
   ia.scale_t = p.handoff_scale_t;
   ia.initial_error = p.initial_error;
   bool first = true;
@@ -594,8 +564,9 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
       ca.initial_error = ia.initial_error;
       ca.inline_pairs = ia.inline_pairs;
       for (int i = 0; i < 4; i++) ca.pair_slots[i] = ia.pair_slots[i];
-      if (p.has_depth) hipLaunchKernelGGL((k_coarse<true, true, double, true>), dim3(n_pairs), dim3(kBlock), 0, c->stream, ca);
-      else hipLaunchKernelGGL((k_coarse<false, true, double, true>), dim3(n_pairs), dim3(kBlock), 0, c->stream, ca);
+      UWT_WITH_ARITH(c,
+        if (p.has_depth) hipLaunchKernelGGL((k_coarse<AR, true, true, double, true>), dim3(n_pairs), dim3(kBlock), 0, c->stream, ca);
+        else hipLaunchKernelGGL((k_coarse<AR, false, true, double, true>), dim3(n_pairs), dim3(kBlock), 0, c->stream, ca));
       HIPCHK(c, hipGetLastError());
       start_lvl = p.first_level - nc;
       after_coarse = true;
@@ -698,11 +669,6 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
                         ? 1 : std::min(c->split, n_pairs / std::max(1, c->split_min));
   const int target_blocks = c->target_blocks ? c->target_blocks : (parts >= 2 ? 1024 : 4096);
   auto slicing = [&](int lvl, int& groups_per_block, int& slices) {
-    if (general && takes_fused(c, lvl)) {   // the fused robust launch: what a block can keep on chip between its two phases
-      groups_per_block = kFusedG * kBlock;
-      slices = fused_slices(c, lvl);
-      return;
-    }
     const int n_groups = c->lv[lvl].n / c->vec;
     int want = (target_blocks + n_pairs - 1) / n_pairs;
     want = std::max(1, std::min(want, c->slices[lvl]));
@@ -754,8 +720,9 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         int st = prof_begin(c, &ev, lvl, p.max_iters);
         if (st) return st;
       }
-      if (p.has_depth) hipLaunchKernelGGL((k_coarse<true, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
-      else hipLaunchKernelGGL((k_coarse<false, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
+      UWT_WITH_ARITH(c,
+        if (p.has_depth) hipLaunchKernelGGL((k_coarse<AR, true, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
+        else hipLaunchKernelGGL((k_coarse<AR, false, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca));
       HIPCHK(c, hipGetLastError());
       if (c->profiling) {   // (fixed schedules only: the level runs max_iters evaluations; the launch stands for that many)
         HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], s));
@@ -813,10 +780,9 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         const int slot = c->poll_seq & 1;
         ua.active = poll ? c->d_active + slot : nullptr;
         if (poll) HIPCHK(c, hipMemsetAsync(c->d_active + slot, 0, sizeof(int), c->stream));
-        const bool fused = general && takes_fused(c, lvl);
-        const bool tail = c->tail_update >= 2 && !fused && !c->compute_only;   // (one stream: only when forced, see tail_update)
+        const bool tail = c->tail_update >= 2 && !c->compute_only;   // (one stream: only when forced, see tail_update)
         if (tail) arm_tail(c, ra, ua);
-        int st = general ? launch_general(c, ra, cnt, fused) : launch_residual(c, ra, cnt, false);
+        int st = general ? launch_general(c, ra, cnt) : launch_residual(c, ra, cnt, false);
         if (st) return st;
         if (c->profiling) {
           HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
@@ -914,11 +880,10 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         Part& q = pt[i];
         q.ua.k = k;
         q.ua.active = nullptr;
-        const bool fused = general && takes_fused(c, lvl);
-        const bool tail = c->tail_update >= 1 && !fused && !c->compute_only;   // the update in the tail of the evaluation's launch
+        const bool tail = c->tail_update >= 1 && !c->compute_only;   // the update in the tail of the evaluation's launch
         if (tail) arm_tail(c, q.ra, q.ua);
         c->stream = q.s;      // every launch helper enqueues on c->stream
-        st = general ? launch_general(c, q.ra, q.cnt, fused) : launch_residual(c, q.ra, q.cnt, false);
+        st = general ? launch_general(c, q.ra, q.cnt) : launch_residual(c, q.ra, q.cnt, false);
         c->stream = main_stream;
         if (st) break;
         if (!tail) hipLaunchKernelGGL(k_gn_update, dim3(q.cnt), dim3(kUpdateBlock), 0, q.s, q.ua);
@@ -1059,6 +1024,11 @@ int uwt_default_params(uwt_params* p, int32_t width, int32_t height, float fx, f
   p->max_frames = 2;
   p->max_pairs = 1;
   p->device = 0;
+  p->arith = UWT_ARITH_OPENCV;
+  // UWT_ARITH=legacy: the default of processes that take their parameters from here (A/B runs, the parity suite's children)
+  if (const char* e = std::getenv("UWT_ARITH")) {
+    if (!std::strcmp(e, "legacy")) p->arith = UWT_ARITH_LEGACY;
+  }
   return UWT_OK;
 }
 
@@ -1073,6 +1043,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   if ((uint64_t)p->width * p->height * p->width >= 0x100000000ull) return UWT_ERR_INVALID_ARG;
   if (p->sampler < 0 || p->sampler > 1 || p->weights < 0 || p->weights > 2) return UWT_ERR_INVALID_ARG;
   if (p->sampler == 1 && p->weights == 1) return UWT_ERR_INVALID_ARG;  // the reference's Tukey medians are defined on integer residuals
+  if (p->arith != UWT_ARITH_OPENCV && p->arith != UWT_ARITH_LEGACY) return UWT_ERR_INVALID_ARG;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1 || p->device < 0 || p->device >= ndev) return UWT_ERR_NO_DEVICE;
   hipDeviceProp_t prop;
@@ -1116,7 +1087,6 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
   if (const char* e = std::getenv("UWT_SPLIT")) c->split = std::max(1, std::min(uwt_ctx::kMaxParts, std::atoi(e)));
   if (std::getenv("UWT_NO_COARSE")) c->coarse = false;
-  if (std::getenv("UWT_FUSED")) c->fused = true;
   c->coarse_batch_px = kCoarseMaxPixels;   // e.g. level 3 of 640x480: +0.8 % on the default batch; larger levels lose (2 waves / SIMD)
   if (const char* e = std::getenv("UWT_COARSE_BATCH_PX")) c->coarse_batch_px = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("UWT_SPLIT_MIN")) c->split_min = std::max(1, std::atoi(e));
@@ -1160,10 +1130,6 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->hist, sizeof(unsigned int) * kHistBins * p->max_pairs));
     CREATE_CHK(hipMalloc((void**)&c->scale, sizeof(PairScale) * p->max_pairs));
     CREATE_CHK(hipMemset(c->scale, 0, sizeof(PairScale) * p->max_pairs));
-    CREATE_CHK(hipMalloc((void**)&c->d_ready, sizeof(unsigned long long) * p->max_pairs));
-    CREATE_CHK(hipMemset(c->d_ready, 0, sizeof(unsigned long long) * p->max_pairs));
-    CREATE_CHK(hipMalloc((void**)&c->d_fused_err, sizeof(int)));
-    CREATE_CHK(hipMemset(c->d_fused_err, 0, sizeof(int)));
   }
   CREATE_CHK(hipHostMalloc((void**)&c->h_active, 2 * sizeof(int)));
   CREATE_CHK(hipHostMalloc((void**)&c->h_pairs, sizeof(int) * 2 * p->max_pairs * uwt_ctx::kPairStages));
@@ -1202,8 +1168,6 @@ int uwt_destroy(uwt_ctx* c) {
   if (c->h_small) (void)hipHostFree(c->h_small);
   if (c->hist) (void)hipFree(c->hist);
   if (c->scale) (void)hipFree(c->scale);
-  if (c->d_ready) (void)hipFree(c->d_ready);
-  if (c->d_fused_err) (void)hipFree(c->d_fused_err);
   if (c->h_active) (void)hipHostFree(c->h_active);
   if (c->h_pairs) (void)hipHostFree(c->h_pairs);
   if (c->scratch) (void)hipFree(c->scratch);
@@ -1244,7 +1208,8 @@ int uwt_update_params(uwt_ctx* c, const uwt_params* p) {
       p->max_pairs != o.max_pairs || p->device != o.device || p->depth_scale != o.depth_scale)
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_update_params: geometry / capacity fields differ from the context's");
   if (p->first_level >= p->n_levels || p->last_level < 0 || p->last_level > p->first_level || p->max_iters < 1 ||
-      p->sampler < 0 || p->sampler > 1 || p->weights < 0 || p->weights > 2 || (p->sampler == 1 && p->weights == 1))
+      p->sampler < 0 || p->sampler > 1 || p->weights < 0 || p->weights > 2 || (p->sampler == 1 && p->weights == 1) ||
+      (p->arith != UWT_ARITH_OPENCV && p->arith != UWT_ARITH_LEGACY))
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_update_params: bad solver constants");
   (void)hipSetDevice(o.device);
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1252,10 +1217,6 @@ int uwt_update_params(uwt_ctx* c, const uwt_params* p) {
     HIPCHK(c, hipMalloc((void**)&c->hist, sizeof(unsigned int) * kHistBins * o.max_pairs));
     HIPCHK(c, hipMalloc((void**)&c->scale, sizeof(PairScale) * o.max_pairs));
     HIPCHK(c, hipMemset(c->scale, 0, sizeof(PairScale) * o.max_pairs));
-    HIPCHK(c, hipMalloc((void**)&c->d_ready, sizeof(unsigned long long) * o.max_pairs));
-    HIPCHK(c, hipMemset(c->d_ready, 0, sizeof(unsigned long long) * o.max_pairs));
-    HIPCHK(c, hipMalloc((void**)&c->d_fused_err, sizeof(int)));
-    HIPCHK(c, hipMemset(c->d_fused_err, 0, sizeof(int)));
   }
   c->p = *p;
   return UWT_OK;
@@ -1464,17 +1425,6 @@ int uwt_apply_gradient(uwt_ctx* c, int32_t first_slot, int32_t n) {
   return UWT_OK;
 }
 
-// after a wait for the context's stream: has a block of a fused robust launch given up waiting for its pair's scale?
-static int check_fused(uwt_ctx* c) {
-  if (!c->fused_used) return UWT_OK;
-  c->fused_used = false;
-  int e = 0;
-  HIPCHK(c, hipMemcpy(&e, c->d_fused_err, sizeof(int), hipMemcpyDeviceToHost));
-  if (!e) return UWT_OK;
-  HIPCHK(c, hipMemset(c->d_fused_err, 0, sizeof(int)));
-  return fail(c, UWT_ERR_HIP, "k_residual_fused: a pair's scale never arrived (blocks of a pair not resident together?); unset UWT_FUSED");
-}
-
 int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
                             float* poses_out, uwt_stats* stats_out) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
@@ -1526,8 +1476,6 @@ int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slot
     st = prof_collect(c);
     if (st) return st;
   }
-  st = check_fused(c);
-  if (st) return st;
   int worst = UWT_OK;
   for (int i = 0; i < n_pairs; i++) {
     if (stats_out) stats_out[i] = tmp[i];
@@ -1648,7 +1596,7 @@ int uwt_sync(uwt_ctx* c) {
     int st = prof_collect(c);
     if (st) return st;
   }
-  return check_fused(c);
+  return UWT_OK;
 }
 
 int uwt_stream(uwt_ctx* c, void** out) {
@@ -1774,7 +1722,7 @@ int uwt_warp(uwt_ctx* c, int32_t lvl, const float* pts, int32_t n, const float p
   Pose P;
   for (int k = 0; k < 4; k++) P.q[k] = pose[k];
   for (int k = 0; k < 3; k++) P.t[k] = pose[4 + k];
-  hipLaunchKernelGGL(k_warp_table, dim3((n + 255) / 256), dim3(256), 0, c->stream, din, dout, n, P, c->lv[lvl]);
+  UWT_WITH_ARITH(c, hipLaunchKernelGGL(k_warp_table<AR>, dim3((n + 255) / 256), dim3(256), 0, c->stream, din, dout, n, P, c->lv[lvl]));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(warped_out, dout, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1969,7 +1917,7 @@ int uwt_solve_delta(uwt_ctx* c, const float A[36], const float b[6], float delta
   if (!A || !b || !delta_out) return UWT_ERR_INVALID_ARG;
   float out[42];
   int flag = 0;
-  int st = run_se3_op(c, 5, A, 36, b, 6, out, 42, &flag);
+  int st = run_se3_op(c, (c && c->p.arith == UWT_ARITH_LEGACY) ? 6 : 5, A, 36, b, 6, out, 42, &flag);
   if (st) return st;
   std::memcpy(delta_out, out, 6 * sizeof(float));
   if (Ainv_out) std::memcpy(Ainv_out, out + 6, 36 * sizeof(float));
@@ -2017,10 +1965,11 @@ int uwt_estimate_pose_points(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, con
     int next_poll = 2;
     for (int k = 0; k < p.max_iters; k++) {
       const dim3 grid(ra.slices), blk(kBlock);
-      if (unit && acc64) hipLaunchKernelGGL((k_residual_points<true, false, double>), grid, blk, 0, c->stream, ra, pa);
-      else if (unit) hipLaunchKernelGGL((k_residual_points<true, false, float>), grid, blk, 0, c->stream, ra, pa);
-      else if (acc64) hipLaunchKernelGGL((k_residual_points<false, false, double>), grid, blk, 0, c->stream, ra, pa);
-      else hipLaunchKernelGGL((k_residual_points<false, false, float>), grid, blk, 0, c->stream, ra, pa);
+      UWT_WITH_ARITH(c,
+        if (unit && acc64) hipLaunchKernelGGL((k_residual_points<AR, true, false, double>), grid, blk, 0, c->stream, ra, pa);
+        else if (unit) hipLaunchKernelGGL((k_residual_points<AR, true, false, float>), grid, blk, 0, c->stream, ra, pa);
+        else if (acc64) hipLaunchKernelGGL((k_residual_points<AR, false, false, double>), grid, blk, 0, c->stream, ra, pa);
+        else hipLaunchKernelGGL((k_residual_points<AR, false, false, float>), grid, blk, 0, c->stream, ra, pa));
       HIPCHK(c, hipGetLastError());
       ua.k = k;
       const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);

@@ -13,7 +13,7 @@
 //   k_coarse       the coarsest levels of such a call — and the coarsest level of a batch — run to their end in one launch,
 //                  one block per pair
 //   k_resid_hist_v (scale pass with the scale stage in its tail) + k_residual<.., WEIGHTS>   robust weights in the alignment loop;
-//                  k_residual_fused: both in one launch (opt-in); k_residual<.., SAMPLER = 1>: bilinear sampler
+//                  k_residual<.., SAMPLER = 1>: bilinear sampler
 //   k_residual_points, k_residual_general, k_resid_hist, k_scale_stage   explicit point tables; per-stage (dump) forms
 //   k_grad_mag*, k_candidates_batch, k_scan_counts, k_patch_points, k_add_patch_points, k_remap_crop, k_trajectory*   the rows
 //                  next to the path
@@ -37,9 +37,20 @@ constexpr int kAccFloats = 27;   // 21 upper-triangle JᵀJ + 6 Jᵀr
 constexpr int kRecWords = 64;    // one partial record (256 B): 27 f64 | n_valid u32 @ word 54 | Σr² u64 @ words 56-57
 constexpr int kMaxSlices = 160;  // slices per pair and level at most (a 1280x960 level 0 has 150 at 2 groups per thread)
 
+// Arithmetic set of the third-party (OpenCV) steps on the path, a template parameter of every kernel that warps a point or
+// forms a Jacobian row (uwt_params::arith; include/uwt.h has the published-algorithm citations):
+//   kArithOpenCV  what OpenCV 3.x's generic code paths compute: cv::gemm products of CV_32F data accumulated in double and
+//                 rounded to float once (GEMMSingleMul<float,double>: the 4-term rigid * points.t() of src/Tracker.cpp:1450,
+//                 the 2-term Jl * Jw of :479), "(col - cx) * invfx" (:1439) folded by the MatExpr algebra into one scaled
+//                 convert x * invfx + (float)(-cx * invfx), "A.inv() * b" (:564) solved by LU on the right-hand side.
+//   kArithLegacy  rounds 1-3: the small products as k-sequential f32 FMA chains, the unprojection as written, the inverse
+//                 formed and multiplied.  Cheaper, and not what OpenCV computes; kept selectable.
+constexpr int kArithOpenCV = 0, kArithLegacy = 1;
+
 struct LevelK {
   int w, h, n;
   float fx, fy, cx, cy, invfx, invfy;
+  float bx, by;     // (float)(-(double)cx * (double)invfx), likewise y: beta of the folded unprojection (kArithOpenCV)
   float zscale;     // depth_scale / 2^lvl (src/Tracker.cpp:1266)
   uint32_t magic;   // ceil(2^32 / w): idx / w == umulhi(idx, magic) for idx * w < 2^32
 };
@@ -462,7 +473,24 @@ __global__ __launch_bounds__(kBlock) void k_scharr3_levels(const GradLevelsArgs 
 // ------------------------------------------------------------------------------------------------------------
 struct WarpK {
   float T[12];
+  double Td[12];   // the same entries widened (kArithOpenCV: the rigid product runs in double); block-uniform
 };
+
+// the rigid matrix of `pose` as block-uniform values (scalar registers); AR == kArithOpenCV also fills Td
+template <int AR>
+__device__ __forceinline__ void warp_setup(const Pose& pose, WarpK& K) {
+  pose_to_T12(pose, K.T);
+#pragma unroll
+  for (int i = 0; i < 12; i++) {
+    K.T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(K.T[i])));
+    if constexpr (AR == kArithOpenCV) {
+      const unsigned long long b = (unsigned long long)__double_as_longlong((double)K.T[i]);
+      const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+      const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+      K.Td[i] = __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+    }
+  }
+}
 
 // Packed f32.  On gfx950 a plain f32 multiply / add / fma issues in 2 cycles per wave only while every operand is a VGPR,
 // an inline constant or a literal; with a scalar-register operand (the rigid matrix, the intrinsics) it takes 4, like
@@ -506,24 +534,60 @@ __device__ __forceinline__ F div_by(F n, F d, F r) {
   return fma_(e, r, q);
 }
 
-template <typename F>
+// One row of rigid * points.t() (src/Tracker.cpp:1450) as cv::gemm computes it on CV_32F (GEMMSingleMul<float,double>,
+// GEMM_2_T, len 4: s0 = a0*b0, s1 = a1*b1, s2 = a2*b2, s3 = a3*b3 in double — exact — then T((s0+s1+s2+s3)*alpha)).
+// A product of two widened floats is exact in double, so fma(a, b, s) = RN(s + a*b) is the separate add.
+__device__ __forceinline__ float rigid_row_f64(const double* Td, double Xd, double Yd, double zd) {   // w = 1
+  double s = Td[0] * Xd;
+  s = __builtin_fma(Td[1], Yd, s);
+  s = __builtin_fma(Td[2], zd, s);
+  s = s + Td[3];
+  return (float)s;
+}
+__device__ __forceinline__ float rigid_row_f64(const double* Td, double Xd, double Yd, double zd, double wd) {
+  double s = Td[0] * Xd;
+  s = __builtin_fma(Td[1], Yd, s);
+  s = __builtin_fma(Td[2], zd, s);
+  s = __builtin_fma(Td[3], wd, s);
+  return (float)s;
+}
+
+template <int AR, typename F>
 __device__ __forceinline__ void warp_point(const LevelK& L, const WarpK& K, F xf, F yf, F z, F& u, F& v, F& zp, F& iz) {
-  F X = (xf - bc<F>(L.cx)) * bc<F>(L.invfx);
+  F X, Y, xp, yp;
+  if constexpr (AR == kArithLegacy) {
+    X = (xf - bc<F>(L.cx)) * bc<F>(L.invfx);
+    Y = (yf - bc<F>(L.cy)) * bc<F>(L.invfy);
+  } else {   // convertTo(alpha = invfx, beta = -cx * invfx) -> cvtScale32f: x * alpha + beta, two f32 operations
+    X = xf * bc<F>(L.invfx);
+    X = X + bc<F>(L.bx);
+    Y = yf * bc<F>(L.invfy);
+    Y = Y + bc<F>(L.by);
+  }
   X = X * z;
-  F Y = (yf - bc<F>(L.cy)) * bc<F>(L.invfy);
   Y = Y * z;
-  F xp = bc<F>(K.T[0]) * X;
-  xp = fma_(bc<F>(K.T[1]), Y, xp);
-  xp = fma_(bc<F>(K.T[2]), z, xp);
-  xp = xp + bc<F>(K.T[3]);  // fma(T03, w = 1, xp)
-  F yp = bc<F>(K.T[4]) * X;
-  yp = fma_(bc<F>(K.T[5]), Y, yp);
-  yp = fma_(bc<F>(K.T[6]), z, yp);
-  yp = yp + bc<F>(K.T[7]);
-  zp = bc<F>(K.T[8]) * X;
-  zp = fma_(bc<F>(K.T[9]), Y, zp);
-  zp = fma_(bc<F>(K.T[10]), z, zp);
-  zp = zp + bc<F>(K.T[11]);
+  if constexpr (AR == kArithLegacy) {
+    xp = bc<F>(K.T[0]) * X;
+    xp = fma_(bc<F>(K.T[1]), Y, xp);
+    xp = fma_(bc<F>(K.T[2]), z, xp);
+    xp = xp + bc<F>(K.T[3]);  // fma(T03, w = 1, xp)
+    yp = bc<F>(K.T[4]) * X;
+    yp = fma_(bc<F>(K.T[5]), Y, yp);
+    yp = fma_(bc<F>(K.T[6]), z, yp);
+    yp = yp + bc<F>(K.T[7]);
+    zp = bc<F>(K.T[8]) * X;
+    zp = fma_(bc<F>(K.T[9]), Y, zp);
+    zp = fma_(bc<F>(K.T[10]), z, zp);
+    zp = zp + bc<F>(K.T[11]);
+  } else {
+#pragma unroll
+    for (int c = 0; c < lanes<F>::n; c++) {
+      const double Xd = (double)get(X, c), Yd = (double)get(Y, c), zd = (double)get(z, c);
+      put(xp, c, rigid_row_f64(K.Td, Xd, Yd, zd));
+      put(yp, c, rigid_row_f64(K.Td + 4, Xd, Yd, zd));
+      put(zp, c, rigid_row_f64(K.Td + 8, Xd, Yd, zd));
+    }
+  }
   const F r = refined_rcp(zp);
   u = xp * bc<F>(L.fx);
   u = div_by(u, zp, r);
@@ -568,12 +632,12 @@ constexpr int kFcmpOGT = 2, kFcmpOLT = 4, kFcmpUGE = 11, kFcmpUNE = 14, kIcmpSGT
 __device__ __forceinline__ bool lane_bit(unsigned long long mask) { return (mask >> (threadIdx.x & 63u)) & 1ull; }
 
 // 1a: warp and validity masks; x2, y2, iz come back raw (possibly NaN / out of range where the mask is clear)
-template <typename F>
+template <int AR, typename F>
 __device__ __forceinline__ void pixel_warp_raw(const LevelK& L, const WarpK& K, F xf, F yf, F z,
                                                const unsigned long long* okin_mask, F& x2, F& y2, F& iz,
                                                unsigned long long* okm) {
   F z2;
-  warp_point(L, K, xf, yf, z, x2, y2, z2, iz);
+  warp_point<AR, F>(L, K, xf, yf, z, x2, y2, z2, iz);
 #pragma unroll
   for (int c = 0; c < lanes<F>::n; c++) {
     const float uc = get(x2, c), vc = get(y2, c);
@@ -603,11 +667,11 @@ __device__ __forceinline__ void pixel_gather_index(const LevelK& L, F x2, F y2, 
     gidx[c] = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;  // 24-bit multiply-add: one op (dims < 2^24)
   }
 }
-template <typename F>
+template <int AR, typename F>
 __device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, F xf, F yf, F z,
                                            const unsigned long long* okin_mask, F& x2, F& y2, F& iz,
                                            unsigned long long* okm, uint32_t* gidx) {
-  pixel_warp_raw(L, K, xf, yf, z, okin_mask, x2, y2, iz, okm);
+  pixel_warp_raw<AR, F>(L, K, xf, yf, z, okin_mask, x2, y2, iz, okm);
   pixel_sanitize(x2, y2, iz, okm);
   pixel_gather_index(L, x2, y2, gidx);
 }
@@ -618,7 +682,12 @@ __device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, F xf
 // SIGNED_ZEROS (the per-stage dump entry points): keep the reference's fma with the structural zero of Jw, which decides
 // the sign of a zero J[0] / J[1] (g0 * a0 = -0, g1 * 0 = +0 -> +0).  The sums never see the difference (x + -0 = x,
 // +0 + -0 = +0), so the solver path drops the two operations.
-template <bool UNIT_FACTORS, bool SQUARE = false, bool SIGNED_ZEROS = false, typename F = float>
+// AR == kArithOpenCV: Jl * Jw is a cv::gemm (flags 0, len 2, 1x6 result: GEMMSingleMul<float,double>, no inline special case —
+// that needs len == d_size.width or height): J[k] = (float)((0 + (double)g0 * Jw0k) + (double)g1 * Jw1k).  The products are
+// exact in double (a gradient has 14 bits), so the second step is one fma; columns 0 and 1 have a structural zero in Jw
+// and reduce to the f32 product (the exact product rounded once).  A zero row entry is +0 there (the sum starts from +0);
+// SIGNED_ZEROS reproduces that for the per-stage dumps, the sums cannot see it.
+template <int AR, bool UNIT_FACTORS, bool SQUARE = false, bool SIGNED_ZEROS = false, typename F = float>
 __device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf_, float af_, F x2, F y2, F iz, F g0, F g1, F J[6]) {
   const F fx = bc<F>(L.fx), fy = bc<F>(L.fy), one = bc<F>(1.0f), zero = bc<F>(0.0f);
   F a0, a2, a3, a5, b1, b2, b4, b5;
@@ -650,17 +719,40 @@ __device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf_, float
     a2 = a2 * zf; a3 = a3 * af; a4 = a4 * af; a5 = a5 * af;
     b2 = b2 * zf; b3 = b3 * af; b4 = b4 * af; b5 = b5 * af;
   }
-  if constexpr (SIGNED_ZEROS) {
-    J[0] = fma_(g1, zero, g0 * a0);
-    J[1] = fma_(g1, b1, g0 * zero);
+  if constexpr (AR == kArithOpenCV) {
+    if constexpr (SIGNED_ZEROS) {   // (0 + p0) + p1 in double: a zero result is +0
+      J[0] = (g0 * a0) + zero;
+      J[1] = (g1 * b1) + zero;
+    } else {
+      J[0] = g0 * a0;
+      J[1] = g1 * b1;
+    }
+#pragma unroll
+    for (int c = 0; c < lanes<F>::n; c++) {
+      const double g0d = (double)get(g0, c), g1d = (double)get(g1, c);
+      const F* as[4] = {&a2, &a3, &a4, &a5};
+      const F* bs[4] = {&b2, &b3, &b4, &b5};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        double p = g0d * (double)get(*as[k], c);
+        if constexpr (SIGNED_ZEROS) p = 0.0 + p;
+        p = __builtin_fma(g1d, (double)get(*bs[k], c), p);
+        put(J[2 + k], c, (float)p);
+      }
+    }
   } else {
-    J[0] = g0 * a0;
-    J[1] = g1 * b1;
+    if constexpr (SIGNED_ZEROS) {
+      J[0] = fma_(g1, zero, g0 * a0);
+      J[1] = fma_(g1, b1, g0 * zero);
+    } else {
+      J[0] = g0 * a0;
+      J[1] = g1 * b1;
+    }
+    J[2] = fma_(g1, b2, g0 * a2);
+    J[3] = fma_(g1, b3, g0 * a3);
+    J[4] = fma_(g1, b4, g0 * a4);
+    J[5] = fma_(g1, b5, g0 * a5);
   }
-  J[2] = fma_(g1, b2, g0 * a2);
-  J[3] = fma_(g1, b3, g0 * a3);
-  J[4] = fma_(g1, b4, g0 * a4);
-  J[5] = fma_(g1, b5, g0 * a5);
 }
 
 // Accumulator type: double reproduces the reference's double-accumulating gemm (src/Tracker.cpp:560-561) to the
@@ -1059,7 +1151,7 @@ struct TailUpdate {
   PairState* state;         // the pairs' states, writable
   int* active;              // see UpdateArgs
   int on;                   // 0: the launch leaves its records to k_gn_update
-  int k, max_iters, early_exit, general;
+  int k, max_iters, early_exit, general, legacy_solve;
   float epsilon, gain;
 };
 
@@ -1125,7 +1217,7 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
 // COMPUTE_ONLY (diagnostic, uwt_profile_enable(ctx, 2)): the same instruction stream with every load of the loop replaced
 // by register arithmetic — results are meaningless, its duration is the kernel's own instruction-issue floor.
 // residual_core evaluates one slice of one pair at `pose`; `lds` (optional) is the caller's buffer for the block reduction.
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
+template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
           bool COMPUTE_ONLY = false, int EXT_LDS = 0>   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first = nullptr, int ref_slot = -1,
@@ -1141,7 +1233,7 @@ __device__ __forceinline__ void load_first_group(RefGroup<VEC>& rg, const Residu
                                        (uint32_t)min(g, n_groups - 1) * VEC);
 }
 
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
+template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
           bool COMPUTE_ONLY = false>
 __device__ __forceinline__ bool residual_block(const ResidualArgs& a, const int pair, const int slice) {   // false: the pair is not iterating
   Pose pose;
@@ -1154,21 +1246,18 @@ __device__ __forceinline__ bool residual_block(const ResidualArgs& a, const int 
   } else {
     pose = a.pose;
   }
-  residual_core<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, slice, pose, nullptr);
+  residual_core<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, slice, pose, nullptr);
   return true;
 }
 
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
+template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
           int EXT_LDS>
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot) {
   // MASKED: f64 sums added under an EXEC mask of the valid lanes (masked_sums_*), nothing of an invalid pixel sanitised
   constexpr bool MASKED = std::is_same<AccT, double>::value && !DUMP;
   WarpK K;
-  pose_to_T12(pose, K.T);
-#pragma unroll
-  for (int i = 0; i < 12; i++)  // the rigid matrix is block-uniform: keep it in scalar registers
-    K.T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(K.T[i])));
+  warp_setup<AR>(pose, K);   // the rigid matrix is block-uniform: scalar registers
   const LevelK L = a.L;
   if (ref_slot < 0) {   // the pair list in memory (batches); k_iterate hands the slots over
     ref_slot = a.ref_slots[pair];
@@ -1262,7 +1351,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
       if constexpr (DEPTH) z = z * bc<F>(L.zscale);
       xf = bc<F>(xf0) + xf;
       if constexpr (MASKED) {
-        pixel_warp_raw<F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N]);
+        pixel_warp_raw<AR, F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N]);
 #pragma unroll
         for (int c = 0; c < N; c++) {
           float r = get(iz[u], c);
@@ -1275,7 +1364,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
           gidx[u * N + c] = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;
         }
       } else {
-        pixel_warp<F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N], &gidx[u * N]);
+        pixel_warp<AR, F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N], &gidx[u * N]);
       }
     }
     // phase 2: the samples of the target level
@@ -1310,7 +1399,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     F J[NU][6];
 #pragma unroll
     for (int u = 0; u < NU; u++)
-      pixel_jacobian<UNIT_FACTORS, SQUARE, DUMP, F>(L, a.zf, a.af, x2[u], y2[u], iz[u], g0[u], g1[u], J[u]);
+      pixel_jacobian<AR, UNIT_FACTORS, SQUARE, DUMP, F>(L, a.zf, a.af, x2[u], y2[u], iz[u], g0[u], g1[u], J[u]);
     __builtin_amdgcn_sched_barrier(0);
     // phase 4: residuals and accumulation
     if constexpr (TABLE) {
@@ -1453,11 +1542,11 @@ __device__ __forceinline__ void tail_update_wave(const ResidualArgs& a, int pair
 #else
 #define UWT_RESIDUAL_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(UWT_EXP_WAVES, UWT_EXP_WAVES)))
 #endif
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
+template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
           bool COMPUTE_ONLY = false>
 __global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
   const int pair = (int)blockIdx.y + a.pair_base;
-  const bool live = residual_block<VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, (int)blockIdx.x);
+  const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, (int)blockIdx.x);
   if constexpr (!COMPUTE_ONLY && !DUMP) {
     if (a.tail.on && live && threadIdx.x < 64) tail_update_wave(a, pair);   // wave 0 wrote the block's record
   }
@@ -1478,7 +1567,7 @@ struct GeneralArgs {
 };
 
 // one pixel of the dense table: warp, validity, residual (either sampler)
-template <bool DEPTH>
+template <int AR, bool DEPTH>
 __device__ __forceinline__ bool general_pixel(const LevelK& L, const WarpK& K, int sampler,
                                               const uint8_t* I1, const uint8_t* I2, const uint16_t* DP, uint32_t idx,
                                               float& x2, float& y2, float& iz, float& rf) {
@@ -1494,14 +1583,14 @@ __device__ __forceinline__ bool general_pixel(const LevelK& L, const WarpK& K, i
   bool valid;
   unsigned long long okm;
   const unsigned long long okin = __builtin_amdgcn_ballot_w64(ok);
-  pixel_warp<float>(L, K, (float)x, (float)y, z, &okin, x2, y2, iz, &okm, &gidx);
+  pixel_warp<AR, float>(L, K, (float)x, (float)y, z, &okin, x2, y2, iz, &okm, &gidx);
   valid = lane_bit(okm);
   const int i1 = I1[idx];
   rf = sampler ? sample_bilinear(I2, L, x2, y2) - (float)i1 : (float)((int)I2[gidx] - i1);
   return valid;
 }
 
-template <bool DEPTH>
+template <int AR, bool DEPTH>
 __global__ __launch_bounds__(kBlock) void k_resid_hist(const ResidualArgs a, const GeneralArgs ga) {
   const int pair = blockIdx.y + a.pair_base;
   const PairState st = a.state[pair];
@@ -1510,7 +1599,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist(const ResidualArgs a, con
   for (int i = threadIdx.x; i < kHistBins; i += kBlock) h[i] = 0;
   __syncthreads();
   WarpK K;
-  pose_to_T12(st.pose, K.T);
+  warp_setup<AR>(st.pose, K);
   const LevelK L = a.L;
   const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
   const uint8_t* I1 = a.img + ref_off;
@@ -1519,7 +1608,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist(const ResidualArgs a, con
   const int p_begin = blockIdx.x * a.groups_per_block, p_end = min(p_begin + a.groups_per_block, L.n);
   for (int p = p_begin + (int)threadIdx.x; p < p_end; p += kBlock) {
     float x2, y2, iz, rf;
-    if (!general_pixel<DEPTH>(L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf)) continue;
+    if (!general_pixel<AR, DEPTH>(L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf)) continue;
     const int q = (int)rintf(rf);   // saturate_cast<uchar> / lrint: round half to even; |q| <= 255
     atomicAdd(&h[q + 255], 1u);     // signed bins; integer atomics are order-independent
   }
@@ -1658,7 +1747,7 @@ __global__ __launch_bounds__(256) void k_scale_stage(const GeneralArgs ga, const
 constexpr int kHistRep = 8;
 constexpr int kHistTicketWord = kHistBins - 1;
 
-template <int VEC, bool DEPTH, int SAMPLER>
+template <int AR, int VEC, bool DEPTH, int SAMPLER>
 __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, unsigned int* __restrict__ hist, PairScale* __restrict__ scale_out,
                                                          int weights) {
   const int pair = blockIdx.y + a.pair_base;
@@ -1669,9 +1758,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
   for (int i = threadIdx.x; i < kHistRep * kHistBins; i += kBlock) h[i] = 0;
   __syncthreads();
   WarpK K;
-  pose_to_T12(st.pose, K.T);
-#pragma unroll
-  for (int i = 0; i < 12; i++) K.T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(K.T[i])));
+  warp_setup<AR>(st.pose, K);
   const LevelK L = a.L;
   const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
   const uint8_t* __restrict__ I1 = a.img + ref_off;
@@ -1725,7 +1812,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
       }
       if constexpr (DEPTH) z = z * bc<F>(L.zscale);
       // the reciprocal's clamp and its select are of no use here: only x2, y2 (the sample position) are read
-      pixel_warp_raw<F>(L, K, xf, bc<F>((float)y), z, okin_m, x2u, y2u, izu, okm);
+      pixel_warp_raw<AR, F>(L, K, xf, bc<F>((float)y), z, okin_m, x2u, y2u, izu, okm);
       if constexpr (SAMPLER == 0) {
         // nothing of an invalid pixel is sanitised: its sample index is clamped both ways (any in-range byte will do) and
         // its count is added under an EXEC mask of the valid lanes, like the sums of the accumulation kernel
@@ -1811,260 +1898,9 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
   if (lane == 0) scale_out[pair] = sc;
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// k_residual_fused (round 3): the scale pass and the weighted accumulation of one evaluation in ONE launch, the warp
-// computed once.  Both passes are bound by vector-instruction issue (SQ counters: 37 + 90 instructions per pixel, the
-// VALU 75-90 % busy), and 30 of the scale pass's 37 are the warp, the validity tests and the sample index all over
-// again.  Handing (x2, y2, 1 / z2, r) from one pass to the other through HBM costs more than it saves (14 B per pixel each
-// way against 8 B of compulsory traffic), so they stay on chip: a block takes kFusedG groups of 4 pixels per thread —
-// what fits — through phase 1 (warp, validity, sample, residual -> the pair's histogram), keeps x2, y2 in LDS and 1 / z2,
-// r, the validity masks in registers, waits for the pair's scale, and runs phase 2 (Jacobian, weight from the
-// per-residual-value table, masked sums) on what it kept.
-//
-// The wait: the pair's blocks add their counts to the pair's global bins and draw tickets (as k_resid_hist_v); the one
-// that draws the last derives the scale and publishes {epoch, 1 / MAD} as one 64-bit word; the others poll that word
-// (one lane, sc1 loads, s_sleep between).  This needs every block of a pair resident before any of them can finish:
-// blocks are dispatched in the order of their index, pair-major (x = slice runs fastest), per XCD in order — the
-// earliest unfinished pair therefore has all its blocks dispatched, finishes, and frees its slots; a level-0 pair of
-// 640x480 is 100 blocks, the chip holds 1024.  (The same forward-progress assumption decoupled look-back scans make.)
-// The poll is bounded: when it runs out the block gives up with NaN sums and raises `fused_error`, which fails the call —
-// a hang is not an outcome.
-//
-// MEASURED AND NOT THE DEFAULT (UWT_FUSED=1 selects it; tests/test_robust_bilinear.py keeps it bit-identical): 37.3 k against
-// 47.0 k alignments/s for Huber at 256 pairs of 640x480, 160 us against 85 + 43 us per evaluation.  What a block can keep on
-// chip is 12 pixels per thread, about 3 us of arithmetic of its own, and the chain it waits through — its counts to the
-// global bins (returning atomics), the ticket, the last block's scale, the poll that sees it — is 6-10 us during which the
-// blocks that share its CU, which belong to the same or the neighbouring pair and so sit at the same point of the same
-// chain, have nothing to issue either.  The two launches repeat 30 instructions per pixel and never wait.
-// ------------------------------------------------------------------------------------------------------------
-constexpr int kFusedG = 3;                                   // groups of 4 pixels per thread (12 pixels: 24 KB of x2, y2 per block)
-constexpr int kFusedRep = 4;                                 // histogram replicas (8 KB: the bytes the weight table takes afterwards)
-constexpr int kFusedHistBytes = kHistBins * kFusedRep * 4;   // 8192
-constexpr int kFusedStashBytes = kFusedG * 4 * kBlock * 8;   // 24576
-constexpr int kFusedLdsBytes = (kFusedHistBytes + kFusedStashBytes) > kReduceLdsBytes ? (kFusedHistBytes + kFusedStashBytes) : kReduceLdsBytes;
-constexpr unsigned kFusedMaxPolls = 1u << 22;
-
-struct FusedArgs {
-  unsigned int* hist;              // [pair][kHistBins] (word 511: the pair's ticket counter), all-zero between evaluations
-  unsigned long long* ready;       // [pair] {epoch << 32 | bits(1 / MAD)} published by the pair's last block
-  PairScale* scale_out;            // [pair] (for the record; phase 2 takes the scale from `ready`)
-  int* error;                      // raised when a poll runs out
-  unsigned int epoch;              // this launch's number (never 0; the same value is not reused while a stale word could match)
-  int weights;
-};
-
-template <bool DEPTH, bool UNIT_FACTORS, bool SQUARE, int WEIGHTS>
-__global__ __launch_bounds__(kBlock) void k_residual_fused(const ResidualArgs a, const FusedArgs fa) {
-  static_assert(WEIGHTS == kWeightsTukeyRef || WEIGHTS == kWeightsHuber, "robust weights over integer residuals");
-  constexpr int VEC = 4, N = 2, NU = 2;
-  using F = v2f;
-  const int pair = (int)blockIdx.y + a.pair_base, slice = (int)blockIdx.x;
-  const PairState st = a.state[pair];
-  if (st.level_done || st.status) return;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kFusedLdsBytes];
-  __shared__ int s_last;
-  __shared__ float s_inv_mad;
-  unsigned int* h = reinterpret_cast<unsigned int*>(lds);                       // phase 1: histogram; phase 2: weight table
-  float2* stash = reinterpret_cast<float2*>(lds + kFusedHistBytes);             // x2, y2 of pixel (j, p) of thread t at [(j * 4 + p) * 256 + t]
-  const int tid = threadIdx.x;
-  for (int i = tid; i < kHistBins * kFusedRep; i += kBlock) h[i] = 0;
-  WarpK K;
-  pose_to_T12(st.pose, K.T);
-#pragma unroll
-  for (int i = 0; i < 12; i++) K.T[i] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(K.T[i])));
-  const LevelK L = a.L;
-  const int ref_slot = a.ref_slots[pair], tgt_slot = a.tgt_slots[pair];
-  const size_t ref_off = (size_t)ref_slot * L.n, tgt_off = (size_t)tgt_slot * L.n;
-  const uint8_t* __restrict__ I1 = a.img + ref_off;
-  const uint8_t* __restrict__ I2 = a.img + tgt_off;
-  const int16_t* __restrict__ GX = a.gx + ref_off;
-  const int16_t* __restrict__ GY = a.gy + ref_off;
-  const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
-  const int n_groups = L.n / VEC;
-  const int g_begin = slice * (kFusedG * kBlock), g_end = min(g_begin + kFusedG * kBlock, n_groups);
-  __syncthreads();
-
-  // ---- phase 1: warp, validity, sample, residual; counts into the block's histogram; x2, y2 -> LDS, 1 / z2, r, masks kept
-  float izs[kFusedG][VEC];
-  uint32_t rpk[kFusedG][2];              // (r + 255) of the four pixels, 16 bits each
-  unsigned long long okm[kFusedG][VEC];  // validity as wave masks (scalar registers)
-  uint32_t n_valid_wave = 0;
-  unsigned int* myh = h + 255 * kFusedRep + (tid & (kFusedRep - 1));
-#pragma unroll
-  for (int j = 0; j < kFusedG; j++) {
-    const int g = g_begin + j * kBlock + tid;
-    const unsigned long long active_mask = __builtin_amdgcn_sicmp(g, g_end, kIcmpSLT);
-    const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
-    const uint32_t y = __umulhi(idx, L.magic), x = idx - y * (uint32_t)L.w;
-    uint8_t i1[VEC];
-    uint16_t dp[VEC];
-    *reinterpret_cast<uint32_t*>(i1) = *reinterpret_cast<const uint32_t*>(I1 + idx);
-    if constexpr (DEPTH) *reinterpret_cast<uint2*>(dp) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(DP) + idx * 2u);
-    uint32_t gidx[VEC];
-#pragma unroll
-    for (int u = 0; u < NU; u++) {
-      F z = bc<F>(1.0f), xf, x2u, y2u, izu;
-      unsigned long long okin[N];
-#pragma unroll
-      for (int c = 0; c < N; c++) {
-        const int p = u * N + c;
-        okin[c] = active_mask;
-        if constexpr (DEPTH) {
-          const int d = (int)(int16_t)dp[p];
-          okin[c] &= __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
-          put(z, c, (float)d);
-        }
-        put(xf, c, (float)x + (float)p);
-      }
-      if constexpr (DEPTH) z = z * bc<F>(L.zscale);
-      pixel_warp_raw<F>(L, K, xf, bc<F>((float)y), z, okin, x2u, y2u, izu, &okm[j][u * N]);
-#pragma unroll
-      for (int c = 0; c < N; c++) {
-        const int p = u * N + c;
-        float r = get(izu, c);
-        asm("v_max_f32 %0, 0, %0" : "+v"(r));   // "if (inv_z2 < 0) inv_z2 = 0" (:452-453)
-        izs[j][p] = r;
-        int ix2 = round_pos(get(x2u, c)), iy2 = round_pos(get(y2u, c));
-        asm("v_med3_i32 %0, %0, 0, %1" : "+v"(ix2) : "s"(L.w - 1));
-        asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy2) : "s"(L.h - 1));
-        gidx[p] = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;
-        stash[(j * VEC + p) * kBlock + tid] = make_float2(get(x2u, c), get(y2u, c));
-      }
-    }
-    int q[VEC];
-#pragma unroll
-    for (int p = 0; p < VEC; p++) q[p] = (int)I2[gidx[p]] - (int)i1[p];
-#pragma unroll
-    for (int p = 0; p < VEC; p++) {
-      const unsigned addr = (unsigned)(uintptr_t)(myh + q[p] * kFusedRep);
-      unsigned long long saved;
-      asm volatile("s_and_saveexec_b64 %0, %1\n\t"
-                   "ds_add_u32 %2, %3\n\t"
-                   "s_mov_b64 exec, %0"
-                   : "=&s"(saved) : "s"(okm[j][p]), "v"(addr), "v"(1u) : "scc", "memory");
-      n_valid_wave += (uint32_t)__builtin_popcountll(okm[j][p]);
-    }
-    rpk[j][0] = (uint32_t)(q[0] + 255) | ((uint32_t)(q[1] + 255) << 16);
-    rpk[j][1] = (uint32_t)(q[2] + 255) | ((uint32_t)(q[3] + 255) << 16);
-  }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the asm's own ds_add_u32
-  __syncthreads();
-
-  // ---- the pair's histogram, the ticket, the scale (see k_resid_hist_v)
-  unsigned int* gh = fa.hist + (size_t)pair * kHistBins;
-  {
-    unsigned int seen = 0;
-    for (int i = tid; i < kHistBins - 1; i += kBlock) {
-      const uint4 v = *reinterpret_cast<const uint4*>(&h[i * kFusedRep]);
-      const unsigned int t = v.x + v.y + v.z + v.w;
-      if (t) seen |= atomicAdd(&gh[i], t);
-    }
-    if (seen == 0xffffffffu) s_last = 0;   // (never true: keeps the returns, i.e. the adds performed before the ticket)
-  }
-  __syncthreads();
-  if (tid == 0) s_last = atomicAdd(&gh[kHistTicketWord], 1u) == gridDim.x - 1 ? 1 : 0;
-  __syncthreads();
-  if (s_last) {
-    if (tid < 64) {
-      unsigned int mine[8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int b = tid * 8 + k;
-        mine[k] = b < 511 ? atomicExch(&gh[b], 0u) : 0u;
-      }
-      if (tid == 0) atomicExch(&gh[kHistTicketWord], 0u);
-      const PairScale sc = wave_scale(mine, h, WEIGHTS == kWeightsTukeyRef, tid);   // (h: every wave is past its flush)
-      if (tid == 0) {
-        fa.scale_out[pair] = sc;
-        s_inv_mad = sc.inv_mad;
-        __hip_atomic_store(fa.ready + pair, ((unsigned long long)fa.epoch << 32) | (unsigned long long)__float_as_uint(sc.inv_mad),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-  } else if (tid == 0) {
-    unsigned long long v = 0;
-    unsigned polls = 0;
-    for (;;) {
-      v = __hip_atomic_load(fa.ready + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((unsigned int)(v >> 32) == fa.epoch) break;
-      if (++polls > kFusedMaxPolls) {   // never seen; a lost forward-progress assumption must not hang the GPU
-        atomicOr(fa.error, 1);
-        v = 0x7fc00000ull;              // NaN scale: the sums come out NaN, the call fails
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    s_inv_mad = __uint_as_float((unsigned int)v);
-  }
-  __syncthreads();
-  const float inv_mad = s_inv_mad;
-
-  // ---- the weight table in the histogram's bytes: w, (r * gain) * w as f32, r * (r * w) as f64, one entry per residual value
-  float* tw = reinterpret_cast<float*>(lds);                 // [511]
-  float* trw = tw + 512;                                     // [511]
-  double* te = reinterpret_cast<double*>(lds + 4096);        // [511]
-  for (int i = tid; i < 511; i += kBlock) {
-    const float rf = (float)(i - 255);
-    const float w = robust_weight(WEIGHTS, rf, inv_mad);
-    tw[i] = w;
-    trw[i] = (rf * a.gain) * w;
-    te[i] = (double)rf * (double)(rf * w);
-  }
-  __syncthreads();
-
-  // ---- phase 2: Jacobian, weight, masked sums
-  double acc[kAccFloats];
-#pragma unroll
-  for (int i = 0; i < kAccFloats; i++) acc[i] = 0.0;
-  double err = 0.0;
-#pragma unroll
-  for (int j = 0; j < kFusedG; j++) {
-    const int g = g_begin + j * kBlock + tid;
-    const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
-    int16_t gxv[VEC], gyv[VEC];
-    *reinterpret_cast<uint2*>(gxv) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(GX) + idx * 2u);
-    *reinterpret_cast<uint2*>(gyv) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(GY) + idx * 2u);
-    F J[NU][6];
-#pragma unroll
-    for (int u = 0; u < NU; u++) {
-      F x2u, y2u, izu, g0, g1, wv;
-#pragma unroll
-      for (int c = 0; c < N; c++) {
-        const int p = u * N + c;
-        const float2 xy = stash[(j * VEC + p) * kBlock + tid];
-        put(x2u, c, xy.x);
-        put(y2u, c, xy.y);
-        put(izu, c, izs[j][p]);
-        put(g0, c, (float)gxv[p]);
-        put(g1, c, (float)gyv[p]);
-        const uint32_t rb = (rpk[j][p >> 1] >> ((p & 1) * 16)) & 0xffffu;
-        put(wv, c, tw[rb]);
-      }
-      pixel_jacobian<UNIT_FACTORS, SQUARE, false, F>(L, a.zf, a.af, x2u, y2u, izu, g0, g1, J[u]);
-#pragma unroll
-      for (int k = 0; k < 6; k++) J[u][k] = wv * J[u][k];   // J <- w * J (src/Tracker.cpp:554-557)
-#pragma unroll
-      for (int c = 0; c < N; c++) {
-        const int p = u * N + c;
-        const uint32_t rb = (rpk[j][p >> 1] >> ((p & 1) * 16)) & 0xffffu;
-        double Jd[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) Jd[k] = (double)get(J[u][k], c);
-        masked_sums_lo(acc, Jd, okm[j][p]);
-        masked_sums_hi<1>(acc, err, Jd, (double)trw[rb], te[rb], okm[j][p]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  }
-  __syncthreads();   // the table and the stash become the reduction's image
-  const uint32_t n_valid = (tid & 63) == 0 ? n_valid_wave : 0u;
-  uint32_t* out_rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
-  block_reduce_store_at<double, true>(lds, acc, 0u, n_valid, out_rec, err);
-}
-
 // weighted / bilinear accumulation: J <- w·J, r <- gain·r, A = Σ(wJ)(wJ)ᵀ, jtr = Σ(wJ)·((gain r)·w) (src/Tracker.cpp:554-561),
 // error numerator Σ r·(r·w) (:499-502).  With identity weights this is the plain sum with float residuals.
-template <bool DEPTH, bool UNIT_FACTORS>
+template <int AR, bool DEPTH, bool UNIT_FACTORS>
 __global__ __launch_bounds__(kBlock) void k_residual_general(const ResidualArgs a, const GeneralArgs ga) {
   const int pair = blockIdx.y + a.pair_base;
   Pose pose;
@@ -2076,7 +1912,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_general(const ResidualArgs 
     pose = a.pose;
   }
   WarpK K;
-  pose_to_T12(pose, K.T);
+  warp_setup<AR>(pose, K);
   const LevelK L = a.L;
   const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
   const uint8_t* I1 = a.img + ref_off;
@@ -2093,10 +1929,10 @@ __global__ __launch_bounds__(kBlock) void k_residual_general(const ResidualArgs 
   const int p_begin = blockIdx.x * a.groups_per_block, p_end = min(p_begin + a.groups_per_block, L.n);
   for (int p = p_begin + (int)threadIdx.x; p < p_end; p += kBlock) {
     float x2, y2, iz, rf;
-    const bool ok = general_pixel<DEPTH>(L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf);
+    const bool ok = general_pixel<AR, DEPTH>(L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf);
     float J[6], w = 1.f;
     if (ok) {
-      pixel_jacobian<UNIT_FACTORS, false, true>(L, a.zf, a.af, x2, y2, iz, (float)GX[p], (float)GY[p], J);
+      pixel_jacobian<AR, UNIT_FACTORS, false, true>(L, a.zf, a.af, x2, y2, iz, (float)GX[p], (float)GY[p], J);
       w = robust_weight(ga.weights, rf, inv_mad);
       const float rw1 = rf * w;                 // Residuals.mul(W) for the error (:500)
       err += (double)rf * (double)rw1;
@@ -2147,6 +1983,7 @@ struct UpdateArgs {
   int pair_base;
   int general;       // 1: records come from k_residual_general (gain already applied, error numerator in slot 29)
   int* active;       // optional: counts the pairs still iterating after this update (early-exit polling)
+  int legacy_solve;  // uwt_params::arith == UWT_ARITH_LEGACY: A.inv() formed, then multiplied (else cv::solve's LU on b)
 };
 
 constexpr int kUpdateBlock = 256;   // threads of an updating block: all fold the records, wave 0 solves
@@ -2185,7 +2022,7 @@ __device__ __forceinline__ void update_solve_wave(const UpdateArgs& a, PairState
     for (int i = 0; i < 6; i++)
       b[i] = a.general ? (float)(-sums[21 + i]) : (float)(-((double)a.gain * sums[21 + i]));  // :559-561
     EXP_STAMP(6);
-    solve_delta_wave(sums, b, delta);                                                // :554-564, A = (float)sums[0..20]
+    solve_delta_wave(sums, b, delta, a.legacy_solve != 0);                                             // :554-564, A = (float)sums[0..20]
     EXP_STAMP(7);
     Pose d, np;
     se3_exp_wave(delta, d);                                                         // :574
@@ -2261,6 +2098,7 @@ __device__ __forceinline__ void tail_update_wave(const ResidualArgs& a, int pair
   u.epsilon = a.tail.epsilon;
   u.gain = a.tail.gain;
   u.general = a.tail.general;
+  u.legacy_solve = a.tail.legacy_solve;
   u.active = a.tail.active;
   PairState st = a.tail.state[pair];   // as every block of the pair read it at the start: nobody has written it since
   update_solve_wave(u, st, t_sums, t_isums, true, lane);
@@ -2400,7 +2238,7 @@ constexpr int iterate_lds_bytes(int pass) { return kUpdateLdsBytes > reduce_lds_
 // PASS: rows per LDS pass of the block reduction — kIteratePass (one pass, 60 KB) while the blocks have their CUs to
 // themselves (up to 3 pairs: 0.40 against 0.42 ms for one), 14 (two passes, 34 KB, four blocks per CU) from 4 pairs on
 // (6 pairs: 0.49 against 0.52 ms).
-template <int VEC, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, bool COMPUTE_ONLY = false, int PASS = kIteratePass>
+template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, bool COMPUTE_ONLY = false, int PASS = kIteratePass>
 __global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterArgs ia) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[iterate_lds_bytes(PASS)];   // the update's staging, then the reduction's image
   const int pair = (int)blockIdx.y + a.pair_base, slice = (int)blockIdx.x;
@@ -2426,7 +2264,7 @@ __global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterAr
   }
   if (st.level_done || st.status) return;
   __syncthreads();   // the staging bytes become the reduction's
-  residual_core<VEC, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, COMPUTE_ONLY, PASS>(a, pair, slice, st.pose, lds, &first, ref_slot, tgt_slot);
+  residual_core<AR, VEC, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, COMPUTE_ONLY, PASS>(a, pair, slice, st.pose, lds, &first, ref_slot, tgt_slot);
 #ifdef UWT_EXP_STAMPS
   if (threadIdx.x == 0) {   // experiment: 100 MHz wall stamps of this block's phases in the record's spare words
     uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
@@ -2466,14 +2304,14 @@ struct CoarseArgs {
 // NLEV: levels the launch can run (the loop over them is unrolled).  The batch form (one block per pair of a whole batch, one
 // level per launch, PASS 14) stays at ~210 registers, two waves per SIMD: forced to 128 it spills and loses (measured), so it
 // pays only on the smallest levels, where the per-evaluation launches run furthest below the level-0 rate.
-template <bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS, int NLEV>
+template <int AR, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS, int NLEV>
 __device__ __forceinline__ void coarse_body(const CoarseArgs& ca);
 
-template <bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS = kIteratePass, int NLEV = kCoarseMaxLevels>
+template <int AR, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS = kIteratePass, int NLEV = kCoarseMaxLevels>
 __global__ UWT_RESIDUAL_BOUNDS void k_coarse(const CoarseArgs ca) {
-  coarse_body<DEPTH, UNIT_FACTORS, AccT, SQUARE, PASS, NLEV>(ca);
+  coarse_body<AR, DEPTH, UNIT_FACTORS, AccT, SQUARE, PASS, NLEV>(ca);
 }
-template <bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS, int NLEV>
+template <int AR, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS, int NLEV>
 __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
   constexpr int kLds = iterate_lds_bytes(PASS);
   __shared__ __attribute__((aligned(16))) unsigned char lds[kLds + kRecWords * 4 + 64];
@@ -2509,7 +2347,7 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
       for (int k = 0; k < u.max_iters; k++) {
         __syncthreads();   // every thread has taken the state out of the update's LDS bytes: they become the reduction's
         if (threadIdx.x == 0) *cur = st;
-        residual_core<4, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot);
+        residual_core<AR, 4, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot);
         __syncthreads();   // the record and the state are in LDS; the reduction's image is free
         u.k = k;
         st = update_compute(u, rec, cur, lds, false);   // ends with a barrier: every thread has the new state
@@ -2601,28 +2439,55 @@ __global__ void k_write_out(const PairState* state, int n, float* poses, StatsOu
 // per-stage helpers (parity entry points)
 // ------------------------------------------------------------------------------------------------------------
 
+// WarpFunction's unprojection and rigid product for one point of an explicit table, the table's own w (src/Tracker.cpp:
+// 1439-1450): o[0..2] = the first three rows, wq = the fourth, (0 0 0 1) * P.  The two arithmetic sets as in warp_point.
+template <int AR>
+__device__ __forceinline__ void warp_table_point(const LevelK& L, const float* T, const float4 p, float o[3], float& wq) {
+  float X, Y;
+  if constexpr (AR == kArithLegacy) {
+    X = (p.x - L.cx) * L.invfx;
+    Y = (p.y - L.cy) * L.invfy;
+  } else {
+    X = p.x * L.invfx; X = X + L.bx;
+    Y = p.y * L.invfy; Y = Y + L.by;
+  }
+  X = X * p.z;
+  Y = Y * p.z;
+  if constexpr (AR == kArithLegacy) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      float s = T[4 * k] * X;
+      s = __builtin_fmaf(T[4 * k + 1], Y, s);
+      s = __builtin_fmaf(T[4 * k + 2], p.z, s);
+      s = __builtin_fmaf(T[4 * k + 3], p.w, s);
+      o[k] = s;
+    }
+    wq = 0.f * X;  // fourth row of the rigid matrix is (0 0 0 1)
+    wq = __builtin_fmaf(0.f, Y, wq);
+    wq = __builtin_fmaf(0.f, p.z, wq);
+    wq = __builtin_fmaf(1.f, p.w, wq);
+  } else {
+    const double Xd = (double)X, Yd = (double)Y, zd = (double)p.z, wd = (double)p.w;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double Td[4] = {(double)T[4 * k], (double)T[4 * k + 1], (double)T[4 * k + 2], (double)T[4 * k + 3]};
+      o[k] = rigid_row_f64(Td, Xd, Yd, zd, wd);
+    }
+    const double last[4] = {0.0, 0.0, 0.0, 1.0};
+    wq = rigid_row_f64(last, Xd, Yd, zd, wd);
+  }
+}
+
 // Tracker::WarpFunction on an explicit N x 4 point table (src/Tracker.cpp:1417-1471)
+template <int AR>
 __global__ void k_warp_table(const float4* __restrict__ pts, float4* __restrict__ out, int n, Pose pose, LevelK L) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   float T[12];
   pose_to_T12(pose, T);
   const float4 p = pts[i];
-  float X = (p.x - L.cx) * L.invfx; X = X * p.z;
-  float Y = (p.y - L.cy) * L.invfy; Y = Y * p.z;
-  float o[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    float s = T[4 * k] * X;
-    s = __builtin_fmaf(T[4 * k + 1], Y, s);
-    s = __builtin_fmaf(T[4 * k + 2], p.z, s);
-    s = __builtin_fmaf(T[4 * k + 3], p.w, s);
-    o[k] = s;
-  }
-  float wq = 0.f * X;  // fourth row of the rigid matrix is (0 0 0 1)
-  wq = __builtin_fmaf(0.f, Y, wq);
-  wq = __builtin_fmaf(0.f, p.z, wq);
-  wq = __builtin_fmaf(1.f, p.w, wq);
+  float o[3], wq;
+  warp_table_point<AR>(L, T, p, o, wq);
   float u = o[0] * L.fx; u = u / o[2]; u = u + L.cx;
   float v = o[1] * L.fy; v = v / o[2]; v = v + L.cy;
   u = u * wq;
@@ -2678,7 +2543,7 @@ struct PointsArgs {
   int pts_per_block;
 };
 
-template <bool UNIT_FACTORS, bool DUMP, typename AccT>
+template <int AR, bool UNIT_FACTORS, bool DUMP, typename AccT>
 __global__ __launch_bounds__(kBlock) void k_residual_points(const ResidualArgs a, const PointsArgs pa) {
   const int pair = a.pair_base;
   Pose pose;
@@ -2706,21 +2571,8 @@ __global__ __launch_bounds__(kBlock) void k_residual_points(const ResidualArgs a
   for (int q = p_begin + (int)threadIdx.x; q < p_end; q += kBlock) {
     const float4 P = pa.pts[q];
     // WarpFunction with the table's own w (src/Tracker.cpp:1439-1467)
-    float X = (P.x - L.cx) * L.invfx; X = X * P.z;
-    float Y = (P.y - L.cy) * L.invfy; Y = Y * P.z;
-    float o[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) {
-      float s = K.T[4 * k] * X;
-      s = __builtin_fmaf(K.T[4 * k + 1], Y, s);
-      s = __builtin_fmaf(K.T[4 * k + 2], P.z, s);
-      s = __builtin_fmaf(K.T[4 * k + 3], P.w, s);
-      o[k] = s;
-    }
-    float wq = 0.f * X;
-    wq = __builtin_fmaf(0.f, Y, wq);
-    wq = __builtin_fmaf(0.f, P.z, wq);
-    wq = __builtin_fmaf(1.f, P.w, wq);
+    float o[3], wq;
+    warp_table_point<AR>(L, K.T, P, o, wq);
     float x2 = o[0] * L.fx; x2 = x2 / o[2]; x2 = x2 + L.cx; x2 = x2 * wq;
     float y2 = o[1] * L.fy; y2 = y2 / o[2]; y2 = y2 + L.cy; y2 = y2 * wq;
     const float z2 = o[2];
@@ -2737,7 +2589,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_points(const ResidualArgs a
       ix2 = min(ix2, L.w - 1);
       iy2 = min(iy2, L.h - 1);
       ri = (int)I2[iy2 * L.w + ix2] - (int)I1[i1x];
-      pixel_jacobian<UNIT_FACTORS, false, DUMP>(L, a.zf, a.af, x2, y2, iz, (float)GX[i1x], (float)GY[i1x], J);
+      pixel_jacobian<AR, UNIT_FACTORS, false, DUMP>(L, a.zf, a.af, x2, y2, iz, (float)GX[i1x], (float)GY[i1x], J);
       accumulate(acc, J, ri);
       sum_r2 += (uint32_t)(ri * ri);
       n_valid += 1;
@@ -3070,9 +2922,9 @@ __global__ void k_se3_ops(int op, const float* in_a, const float* in_b, float* o
     *flag = se3_handoff(a, op == 4) ? 1 : 0;
     for (int k = 0; k < 4; k++) out[k] = a.q[k];
     for (int k = 0; k < 3; k++) out[4 + k] = a.t[k];
-  } else if (op == 5) {  // solve: in_a = A(36), in_b = b(6); out = delta(6) + Ainv(36)
+  } else if (op == 5 || op == 6) {  // "A.inv() * b": in_a = A(36), in_b = b(6); out = delta(6) + Ainv(36); 6: the legacy set
     float d[6], Ai[36];
-    *flag = solve_delta(in_a, in_b, d, Ai) ? 1 : 0;
+    *flag = solve_delta(in_a, in_b, d, Ai, op == 6) ? 1 : 0;
     for (int k = 0; k < 6; k++) out[k] = d[k];
     for (int k = 0; k < 36; k++) out[6 + k] = Ai[k];
   }

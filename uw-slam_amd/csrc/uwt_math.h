@@ -251,16 +251,78 @@ __device__ inline bool inv6_lu(const float Ain[36], float X[36]) {
   return true;
 }
 
-// deltaMat = A.inv() * b (src/Tracker.cpp:564): the 6x6·6x1 product accumulates in f64 and rounds once.
-__device__ inline bool solve_delta(const float A[36], const float b[6], float delta[6], float* Ainv_out) {
-  float Ai[36];
-  const bool ok = inv6_lu(A, Ai);
+// deltaMat = A.inv() * b (src/Tracker.cpp:564), OpenCV's evaluation: MatOp_Invert::matmul makes it MatOp_Solve, i.e.
+// cv::solve(A, b, x, DECOMP_LU) = hal::LU32f(A, 6, b, 1): the elimination of inv6_lu applied to the 6x1 right-hand side,
+// f32 back substitution, singular => x = 0.  No inverse, no product.  Returns false when singular.
+__device__ inline bool solve6_lu(const float Ain[36], const float bin[6], float x[6]) {
+  float A[36], b[6];
+#pragma unroll
+  for (int i = 0; i < 36; i++) A[i] = Ain[i];
+#pragma unroll
+  for (int i = 0; i < 6; i++) b[i] = bin[i];
+  const float eps = 1.1920929e-07f * 10;
+  bool singular = false;
 #pragma unroll
   for (int i = 0; i < 6; i++) {
-    double s = 0.0;
+    int k = i;
+    float best = fabsf(A[i * 6 + i]);
 #pragma unroll
-    for (int j = 0; j < 6; j++) s += (double)Ai[6 * i + j] * (double)b[j];
-    delta[i] = (float)s;
+    for (int j = i + 1; j < 6; j++) {
+      const float v = fabsf(A[j * 6 + i]);
+      if (v > best) { best = v; k = j; }
+    }
+    if (best < eps) { singular = true; break; }
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) {
+      if (k == j) {
+#pragma unroll
+        for (int q = i; q < 6; q++) { const float t = A[i * 6 + q]; A[i * 6 + q] = A[j * 6 + q]; A[j * 6 + q] = t; }
+        const float t = b[i]; b[i] = b[j]; b[j] = t;
+      }
+    }
+    const float d = -1.f / A[i * 6 + i];
+#pragma unroll
+    for (int j = i + 1; j < 6; j++) {
+      const float alpha = A[j * 6 + i] * d;
+#pragma unroll
+      for (int q = i + 1; q < 6; q++) A[j * 6 + q] = A[j * 6 + q] + alpha * A[i * 6 + q];
+      b[j] = b[j] + alpha * b[i];
+    }
+    A[i * 6 + i] = -d;
+  }
+  if (singular) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) x[q] = 0.f;
+    return false;
+  }
+#pragma unroll
+  for (int i = 5; i >= 0; i--) {
+    float s = b[i];
+#pragma unroll
+    for (int q = i + 1; q < 6; q++) s = s - A[i * 6 + q] * b[q];
+    b[i] = s * A[i * 6 + i];
+  }
+#pragma unroll
+  for (int q = 0; q < 6; q++) x[q] = b[q];
+  return true;
+}
+
+// The legacy arithmetic set's A.inv() * b: the inverse formed first (inv6_lu), then the 6x6·6x1 product accumulated in
+// f64 and rounded once.  legacy == false: solve6_lu (Ainv_out, when asked for, still receives inv6_lu's inverse).
+__device__ inline bool solve_delta(const float A[36], const float b[6], float delta[6], float* Ainv_out, bool legacy) {
+  float Ai[36];
+  bool ok = true;
+  if (legacy || Ainv_out) ok = inv6_lu(A, Ai);
+  if (legacy) {
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      double s = 0.0;
+#pragma unroll
+      for (int j = 0; j < 6; j++) s += (double)Ai[6 * i + j] * (double)b[j];
+      delta[i] = (float)s;
+    }
+  } else {
+    ok = solve6_lu(A, b, delta);
   }
   if (Ainv_out) {
 #pragma unroll
@@ -269,8 +331,10 @@ __device__ inline bool solve_delta(const float A[36], const float b[6], float de
   return ok;
 }
 
-// The same A.inv() * b with the 12 columns of [A | X] spread over 12 lanes of a wave (lane c < 6 owns column c of A,
-// lane 6 + j column j of X = I; every lane of the wave must be active and hold the same `sums` / `b`).  Each element goes
+// The same A.inv() * b on a wave.  OpenCV's set (legacy == false): the 7 columns of [A | b] over 7 lanes (lane c < 6 owns
+// column c of A, lanes 6.. the right-hand side): hal::LU32f(A, 6, b, 1), delta = the back-substituted b.  Legacy set: the 12
+// columns of [A | X] over 12 lanes (lane 6 + j column j of X = I), then delta = X * b accumulated in f64.  Every lane of
+// the wave must be active and hold the same `sums` / `b`.  Each element goes
 // through exactly the operations of inv6_lu — the elimination updates every column of a row alike — so the result is
 // bit-identical; what changes is that a row operation is one instruction instead of twelve, and the pivot, the
 // multipliers and the upper triangle travel through v_readlane.  Entries the serial code never reads again (below the
@@ -280,7 +344,7 @@ __device__ __forceinline__ float lane_f(float v, int lane) {
 }
 
 // sums: the 21 upper-triangle entries of A in row-major order (as accumulated); returns false when singular (delta = 0)
-__device__ inline bool solve_delta_wave(const double* sums, const float b[6], float delta[6]) {
+__device__ inline bool solve_delta_wave(const double* sums, const float b[6], float delta[6], bool legacy) {
   const int lane = (int)(threadIdx.x & 63u);
   const int c = lane < 12 ? lane : 11;  // lanes >= 12 shadow lane 11
   float col[6];
@@ -289,7 +353,8 @@ __device__ inline bool solve_delta_wave(const double* sums, const float b[6], fl
     const int i = r < c ? r : c, j = r < c ? c : r;          // (min, max) of (r, c) for the A lanes
     const int idx = i * 6 - (i * (i - 1)) / 2 + (j - i);
     const float a_rc = (float)sums[c < 6 ? idx : 0];
-    col[r] = c < 6 ? a_rc : (r == c - 6 ? 1.f : 0.f);
+    const float rhs = legacy ? (r == c - 6 ? 1.f : 0.f) : b[r];   // X = I (legacy) or the right-hand side itself
+    col[r] = c < 6 ? a_rc : rhs;
   }
   const float eps = 1.1920929e-07f * 10;
   bool singular = false;
@@ -333,6 +398,11 @@ __device__ inline bool solve_delta_wave(const double* sums, const float b[6], fl
 #pragma unroll
     for (int q = i + 1; q < 6; q++) sacc = sacc - U[i][q] * col[q];
     col[i] = sacc * U[i][i];
+  }
+  if (!legacy) {   // wave-uniform: lane 6 holds x = the back-substituted right-hand side (cv::solve's dst)
+#pragma unroll
+    for (int i = 0; i < 6; i++) delta[i] = lane_f(col[i], 6);
+    return true;
   }
   // delta = X * b, f64 accumulation in column order, rounded once (X[i][j] lives in lane 6 + j)
 #pragma unroll
