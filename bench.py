@@ -42,8 +42,24 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 ALG_BYTES_PER_PIXEL_ITER = 10          # I_ref 1 + gx 2 + gy 2 + z 4 + I_tgt 1
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0                  # MI355X_MICROARCH.md §Chip-level parameters: measured copy ceiling
-# Static facts about the dominant kernel that cannot be measured from inside this process; each names its source file.
-PROFILE_FACTS = os.path.join(ROOT, "profiles", "r03", "k_residual_facts.json")
+# Facts about the dominant kernel that cannot be measured from inside this process (counter passes, compiler resource usage),
+# per arithmetic set, each naming its source file, stamped with the sha256 of the libuwt_hip.so they were collected on
+# (tools/make_profile_facts.py).  They are quoted only while the library this process loaded is that library.
+PROFILE_FACTS = os.path.join(ROOT, "profiles", "r04", "k_residual_facts.json")
+
+
+def _quoted_facts(capi, arith):
+    """(facts of this arithmetic set or {}, note).  Empty when the loaded library is not the one the facts were collected on."""
+    import hashlib
+    if not os.path.exists(PROFILE_FACTS):
+        return {}, "no %s" % os.path.relpath(PROFILE_FACTS, ROOT)
+    allf = json.load(open(PROFILE_FACTS))
+    sha = hashlib.sha256(open(capi.LIB_PATH, "rb").read()).hexdigest()
+    if allf.get("library_sha256") != sha:
+        return {}, ("quoted counter / resource facts withheld: %s was collected on libuwt_hip.so sha256 %s..., this run loaded %s... "
+                    "(re-run tools/collect_profiles.sh + tools/publish_profiles.sh)"
+                    % (os.path.relpath(PROFILE_FACTS, ROOT), str(allf.get("library_sha256"))[:12], sha[:12]))
+    return dict(allf.get("sets", {}).get(arith, {})), "facts collected on this library (sha256 %s...)" % sha[:12]
 
 
 def parse_args(argv=None):
@@ -292,9 +308,11 @@ def main(args):
             dist.barrier()
             torch.cuda.synchronize()
 
+    t_w = time.perf_counter()
     for _ in range(args.warmup):
         step()
     fence()
+    warm_s = time.perf_counter() - t_w
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -315,6 +333,7 @@ def main(args):
     res_levels = []
     co_ms = 0.0
     clock_ghz = 0.0
+    t_p = time.perf_counter()
     if not args.no_profile:
         for _ in range(max(2, args.warmup)):
             step()
@@ -335,6 +354,7 @@ def main(args):
         ctx.profile_enable(0)
         step()                                              # leave the real poses behind
         fence()
+    prof_s = time.perf_counter() - t_p
     streaming = None
     # (not under a profiler: its launches carry the residual kernel's name and, running beside the copies, would blur the
     # per-kernel statistics that are compared with roofline.avg_launch_ms)
@@ -356,6 +376,10 @@ def main(args):
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4),
+        # where this process kept the GPU busy (seconds of wall time): a utilisation sampler with a period of seconds sees
+        # little of a run whose GPU work is a few tenths of a second between CPU legs (generation, the CPU baseline)
+        "gpu_active_s": {"warmup_steps": round(warm_s, 3), "timed_steps": round(dt, 3),
+                         "event_bracketed_and_compute_only_steps": round(prof_s, 3)},
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
@@ -395,9 +419,7 @@ def main(args):
         if latency:
             out["single_pair_latency"] = latency
         if res_launches:
-            facts = {}
-            if os.path.exists(PROFILE_FACTS):
-                facts = json.load(open(PROFILE_FACTS))
+            facts, facts_note = _quoted_facts(capi, args.arith)
             alg_bytes = ALG_BYTES_PER_PIXEL_ITER * res_pixels
             achieved = alg_bytes / (res_ms * 1e-3) / 1e9
             default_shape = (w, h, args.levels, has_depth) == (640, 480, 4, 1) and not args.reference_schedule
@@ -436,13 +458,11 @@ def main(args):
             if clock_ghz:
                 # SIMD cycles the chip spent per pixel-iteration: 1024 SIMDs x 64 lanes
                 valu["simd_cycles_per_pixel"] = round(res_ms * 1e-3 * clock_ghz * 1e9 * 1024 * 64 / res_pixels, 1)
-            for k in ("valu_instructions_per_pixel", "f64_fma_per_pixel", "instruction_mix_source"):
-                if k in facts:
-                    valu[k] = facts[k]
-            valu["waves_per_simd"] = 4
-            valu["occupancy_note"] = ("120 VGPRs (54 of them the 27 f64 accumulators) and 34.9 KB of LDS per block: four waves per SIMD; an "
-                                      "independent v_fmac_f64 stream takes a SIMD 1.16 ns per wave instruction at 4 waves, 1.00 at 6, 0.83 at 8 "
-                                      "(profiles/r03/ubench_exec_toggle.txt)")
+            # counter and compiler facts of the production instantiation, only for the workload they were collected on
+            for k in ("valu_instructions_per_pixel", "f64_fma_per_pixel", "instruction_mix_source", "vgprs", "waves_per_simd",
+                      "lds_bytes_per_block", "resource_source"):
+                valu[k] = facts.get(k) if default_shape and args.weights == "identity" and not args.bilinear and args.acc == "f64" else None
+            roof["facts_note"] = facts_note
             roof["valu"] = valu
             if args.reference_schedule:
                 # early exit: a launch is counted (and its level's pixels with it) whether or not its pairs have already left

@@ -96,3 +96,26 @@ def test_gpu_trajectory_scan_agrees_with_the_sequential_product():
         ref_seq = ctx.accumulate_trajectory(poses, start, 40.0, True)
         assert np.abs(ref - ref_seq).max() < 1e-3 * max(1.0, np.abs(ref_seq).max())
     ctx.close()
+
+
+def test_ground_truth_conventions_camera_to_world_against_tracker_pairs(synth):
+    """A ground-truth FILE holds camera-to-world poses G_k; the tracker's pose of pair k maps the previous camera's coordinates
+    to the current one's (X_{k+1} = T_k X_k, src/Tracker.cpp:595), i.e. T_k = G_{k+1}^-1 G_k — the INVERSE of G_k^-1 G_{k+1}.
+    With the synthetic camera's physical poses written as ground truth: pair_ground_truth recovers the scene's true per-pair
+    motion, camera_trajectory of the true pairs recovers G_0^-1 G_k, and the wrong (un-inverted) pairing is visibly wrong."""
+    T = importlib.import_module("uw-slam_amd.trajectory")
+    S = importlib.import_module("uw-slam_amd.sequence")
+    _, _, rel, absp = synth.render_sequence(64, 48, 64.0, 64.0, 31.5, 23.5, n=12, seed=3, margin=(32, 32))
+    c2w = synth.camera_to_world_poses(rel)
+    assert np.allclose(c2w[0], [0, 0, 0, 1, 0, 0, 0])
+    gt_pairs = T.pair_ground_truth(c2w)
+    assert np.allclose(gt_pairs, rel, atol=1e-9)                       # the tracker's convention
+    assert np.allclose(T.camera_trajectory(rel), T.from_first(c2w), atol=1e-9)
+    assert np.allclose(T.from_first(c2w), c2w[1:], atol=1e-9)          # (G_0 = identity here)
+    wrong = T.relative_poses(c2w)                                      # G_k^-1 G_{k+1}: the inverse motion
+    step = np.linalg.norm(rel[:, 4:], axis=1).mean()
+    assert S.rpe_translation(rel[:, 4:], wrong[:, 4:]) > 1.5 * step    # about twice the motion, as the advisor measured
+    assert np.allclose(T.invert(T.invert(rel)), rel, atol=1e-12)
+    # the Visualizer-style accumulation (previous * SE3(q, t)) is a different trajectory: compose_from(rel) = absp, not c2w
+    assert np.allclose(T.compose_from(rel), absp[1:], atol=1e-9)
+    assert not np.allclose(T.compose_from(rel)[:, 4:], c2w[1:, 4:], atol=1e-4)

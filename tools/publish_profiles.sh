@@ -1,9 +1,14 @@
 #!/bin/bash
 # copy the summaries of a tools/collect_profiles.sh run into profiles/<round>/ under the names the README there lists
-#   tools/publish_profiles.sh <gpurun_out subdir> <round dir, e.g. r03>
+#   tools/publish_profiles.sh <gpurun_out subdir> <round dir, e.g. r04>
+# Refuses when the library in the tree is not the one the counters were collected on (the facts are stamped with its hash).
 set -e
 src=gpurun_out/$1; dst=profiles/$2
 mkdir -p $dst
+if [ -f $src/library_sha256.txt ]; then
+  want=$(cut -d' ' -f1 $src/library_sha256.txt); have=$(sha256sum uw-slam_amd/libuwt_hip.so | cut -d' ' -f1)
+  if [ "$want" != "$have" ]; then echo "library changed since the collection ($want vs $have): collect again" >&2; exit 1; fi
+fi
 for d in $src/stats_*; do
   n=$(basename $d | sed 's/^stats_//')
   f=$(find $d -name "*kernel_stats.csv" | head -1)
@@ -11,7 +16,10 @@ for d in $src/stats_*; do
   [ -f $src/bench_$n.json ] && cp $src/bench_$n.json $dst/bench_$n.json
   [ -f $src/bench_${n}_no_profiler.json ] && cp $src/bench_${n}_no_profiler.json $dst/bench_${n}_no_profiler.json
 done
-cp $src/pmc_fetch.csv $dst/pmc_fetch_bench_default_p1024.csv
-cp $src/pmc_write.csv $dst/pmc_write_bench_default_p1024.csv
+for a in opencv legacy; do
+  cp $src/pmc_fetch_$a.csv $dst/pmc_fetch_${a}_bench_default_p1024.csv
+  cp $src/pmc_write_$a.csv $dst/pmc_write_${a}_bench_default_p1024.csv
+done
 cp $src/sq_counters_*.csv $dst/
+[ -s $src/per_level_launch_table_trace.md ] && cp $src/per_level_launch_table_trace.md $dst/
 python3 tools/make_profile_facts.py $dst

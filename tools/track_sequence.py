@@ -62,13 +62,16 @@ def main():
         ts, gtp = (T.read_groundtruth_euroc if a.euroc else T.read_groundtruth_tum)(a.groundtruth)
         idx_all = np.clip(T.ground_truth_indices(len(gtp), len(names), a.start, euroc=a.euroc), 0, len(gtp) - 1)
         gt = gtp[idx_all[1:]]
-        # ATE: accumulated estimate against the ground-truth poses of the same frames, relative to the first frame's, after
-        # a rigid alignment; RPE: per-pair relative translation against the ground truth's G_{k-1}^-1 G_k
-        g_rel = T.relative_poses(gtp[idx_all])
-        g_abs = T.compose_from(g_rel)
-        metrics["ate_rmse_m"] = S.ate_rmse(traj[:, 4:], g_abs[:, 4:])
-        metrics["rpe_trans_rmse_m"] = S.rpe_translation(poses[:, 4:], g_rel[:, 4:])
-        metrics["rpe_rot_rmse_rad"] = T.rpe_rotation(poses, g_rel)
+        # The files hold camera-to-world poses G_k; the tracker's pose of pair k maps the previous camera's coordinates to
+        # the current one's, T_k = G_{k+1}^-1 G_k.  RPE: per-pair estimate against that; ATE: the camera trajectory the
+        # estimates imply, C_{k+1} = C_k T_k^-1, against G_0^-1 G_k after a rigid alignment.  (The Visualizer-style
+        # accumulation previous * SE3(q, t) stays a separate output: <out>_tum.txt / <out>_reference.csv.)
+        g_pair = T.pair_ground_truth(gtp[idx_all])
+        cam = T.camera_trajectory(poses)
+        metrics["ate_rmse_m"] = S.ate_rmse(cam[:, 4:], T.from_first(gtp[idx_all])[:, 4:])
+        metrics["rpe_trans_rmse_m"] = S.rpe_translation(poses[:, 4:], g_pair[:, 4:])
+        metrics["rpe_rot_rmse_rad"] = T.rpe_rotation(poses, g_pair)
+        np.savetxt(a.out + "_camera_tum.txt", np.concatenate([np.arange(1, len(cam) + 1)[:, None], cam[:, 4:], cam[:, :4]], axis=1), fmt="%.9g")
         print("ATE RMSE %.4f m, RPE %.5f m / %.5f rad over %d poses"
               % (metrics["ate_rmse_m"], metrics["rpe_trans_rmse_m"], metrics["rpe_rot_rmse_rad"], len(traj)))
     T.write_reference_csv(a.out + "_reference.csv", ref, gt)

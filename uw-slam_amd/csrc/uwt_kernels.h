@@ -687,10 +687,11 @@ __device__ __forceinline__ void pixel_warp(const LevelK& L, const WarpK& K, F xf
 // exact in double (a gradient has 14 bits), so the second step is one fma; columns 0 and 1 have a structural zero in Jw
 // and reduce to the f32 product (the exact product rounded once).  A zero row entry is +0 there (the sum starts from +0);
 // SIGNED_ZEROS reproduces that for the per-stage dumps, the sums cannot see it.
-template <int AR, bool UNIT_FACTORS, bool SQUARE = false, bool SIGNED_ZEROS = false, typename F = float>
-__device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf_, float af_, F x2, F y2, F iz, F g0, F g1, F J[6]) {
-  const F fx = bc<F>(L.fx), fy = bc<F>(L.fy), one = bc<F>(1.0f), zero = bc<F>(0.0f);
-  F a0, a2, a3, a5, b1, b2, b4, b5;
+// the non-zero entries of Jw (src/Tracker.cpp:455-467): row 0 = (a0, 0, a2, a3, a4, a5), row 1 = (0, b1, b2, b3, b4, b5)
+template <bool UNIT_FACTORS, bool SQUARE, typename F>
+__device__ __forceinline__ void jw_terms(const LevelK& L, float zf_, float af_, F x2, F y2, F iz, F& a0, F& b1, F a[4], F b[4]) {
+  const F fx = bc<F>(L.fx), fy = bc<F>(L.fy), one = bc<F>(1.0f);
+  F a2, a3, a5, b2, b4, b5;
   if constexpr (SQUARE) {
     const F fx2 = fx * x2, fy2 = fx * y2;
     a0 = fx * iz;
@@ -719,6 +720,16 @@ __device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf_, float
     a2 = a2 * zf; a3 = a3 * af; a4 = a4 * af; a5 = a5 * af;
     b2 = b2 * zf; b3 = b3 * af; b4 = b4 * af; b5 = b5 * af;
   }
+  a[0] = a2; a[1] = a3; a[2] = a4; a[3] = a5;
+  b[0] = b2; b[1] = b3; b[2] = b4; b[3] = b5;
+}
+
+template <int AR, bool UNIT_FACTORS, bool SQUARE = false, bool SIGNED_ZEROS = false, typename F = float>
+__device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf_, float af_, F x2, F y2, F iz, F g0, F g1, F J[6]) {
+  const F zero = bc<F>(0.0f);
+  F a0, b1, av[4], bv[4];
+  jw_terms<UNIT_FACTORS, SQUARE, F>(L, zf_, af_, x2, y2, iz, a0, b1, av, bv);
+  const F a2 = av[0], a3 = av[1], a4 = av[2], a5 = av[3], b2 = bv[0], b3 = bv[1], b4 = bv[2], b5 = bv[3];
   if constexpr (AR == kArithOpenCV) {
     if constexpr (SIGNED_ZEROS) {   // (0 + p0) + p1 in double: a zero result is +0
       J[0] = (g0 * a0) + zero;
@@ -752,6 +763,22 @@ __device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf_, float
     J[3] = fma_(g1, b3, g0 * a3);
     J[4] = fma_(g1, b4, g0 * a4);
     J[5] = fma_(g1, b5, g0 * a5);
+  }
+}
+
+// The kArithOpenCV row of one pixel pair handed to the f64 sums as doubles (the identity path of residual_core): column k >= 2
+// is (double)(float)(g0 * Jw0k + g1 * Jw1k) with the sum formed in double, columns 0 and 1 the widened f32 products.
+// (j0 = g0 * a0, j1 = g1 * b1: the packed f32 products; av, bv: jw_terms' columns 2..5; c: the pixel of the pair)
+template <typename F>
+__device__ __forceinline__ void jacobian_row_f64(F g0, F g1, F j0, F j1, const F av[4], const F bv[4], int c, double Jd[6]) {
+  const double g0d = (double)get(g0, c), g1d = (double)get(g1, c);
+  Jd[0] = (double)get(j0, c);
+  Jd[1] = (double)get(j1, c);
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    double p = g0d * (double)get(av[k], c);
+    p = __builtin_fma(g1d, (double)get(bv[k], c), p);
+    Jd[2 + k] = (double)(float)p;
   }
 }
 
@@ -1257,7 +1284,26 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   // MASKED: f64 sums added under an EXEC mask of the valid lanes (masked_sums_*), nothing of an invalid pixel sanitised
   constexpr bool MASKED = std::is_same<AccT, double>::value && !DUMP;
   WarpK K;
-  warp_setup<AR>(pose, K);   // the rigid matrix is block-uniform: scalar registers
+  // kArithOpenCV: the rigid matrix as doubles lives in LDS and is read back at the head of every step of the loop (TD_LDS).  As
+  // scalar registers the 12 doubles do not fit beside the kernel's ~95 (the compiler then keeps them in 24 vector registers
+  // for the whole loop: 151 registers, three waves per SIMD); read per step they are live through the warp phase only,
+  // where the pressure is lowest.  6 ds_read_b128 per 4 pixels, no vector-ALU instruction.
+#ifdef UWT_EXP_NO_TD_LDS
+  constexpr bool TD_LDS = false;
+#else
+  constexpr bool TD_LDS = AR == kArithOpenCV && !DUMP;
+#endif
+  __shared__ __attribute__((aligned(16))) double s_td[TD_LDS ? 12 : 2];
+  if constexpr (TD_LDS) {
+    warp_setup<kArithLegacy>(pose, K);   // T in scalar registers (the hand-over of the block's pose); Td goes through LDS
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) s_td[i] = (double)K.T[i];
+    }
+    __syncthreads();
+  } else {
+    warp_setup<AR>(pose, K);   // the rigid matrix is block-uniform: scalar registers
+  }
   const LevelK L = a.L;
   if (ref_slot < 0) {   // the pair list in memory (batches); k_iterate hands the slots over
     ref_slot = a.ref_slots[pair];
@@ -1325,6 +1371,13 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   auto body = [&](RefGroup<VEC>& rg, const int ahead) __attribute__((always_inline)) {
     const bool active = g < g_end;
     const unsigned long long active_mask = __builtin_amdgcn_sicmp(g, g_end, kIcmpSLT);
+    if constexpr (TD_LDS) {
+      unsigned off = 0;
+      asm volatile("" : "+v"(off));   // an offset the compiler cannot see through: the reads stay inside the loop
+      const double* tdp = reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(s_td) + off);
+#pragma unroll
+      for (int i = 0; i < 12; i++) K.Td[i] = tdp[i];
+    }
     const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
     uint8_t i1[VEC];
 #pragma unroll
@@ -1395,6 +1448,34 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     __builtin_amdgcn_sched_barrier(0);
     load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, I1, GX, GY, DP, (uint32_t)min(g + ahead * kBlock, n_groups - 1) * VEC);
     __builtin_amdgcn_sched_barrier(0);
+    // kArithOpenCV, identity path: a unit's row is formed in double and goes straight into the sums, one unit at a time (no f32
+    // rows of all four pixels held across the phase: the doubles of the small products take their registers)
+#ifdef UWT_EXP_NO_DIRECT
+    constexpr bool DIRECT = false;
+#else
+    constexpr bool DIRECT = AR == kArithOpenCV && MASKED && !GENERAL;
+#endif
+    if constexpr (DIRECT) {
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+        F a0, b1, av[4], bv[4];
+        jw_terms<UNIT_FACTORS, SQUARE, F>(L, a.zf, a.af, x2[u], y2[u], iz[u], a0, b1, av, bv);
+        const F j0 = g0[u] * a0, j1 = g1[u] * b1;
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+          const int j = u * N + c;
+          double Jd[6];
+          jacobian_row_f64<F>(g0[u], g1[u], j0, j1, av, bv, c, Jd);
+          const int ri = i2[j] - (int)i1[j];
+          masked_sums_lo(acc, Jd, okm[j]);
+          masked_sums_hi<0>(acc, r2d, Jd, (double)ri, 0.0, okm[j]);
+          n_valid_wave += (uint32_t)__builtin_popcountll(okm[j]);  // scalar
+#ifndef UWT_EXP_NO_UNIT_FENCE
+          __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+      }
+    } else {
     // phase 3: Jacobians (cover the gather latency)
     F J[NU][6];
 #pragma unroll
@@ -1493,6 +1574,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
       }
     }
     }
+    }   // !DIRECT
     xf0 += step_xf;
     yf += step_yf;
     const bool wrap = xf0 >= wf;

@@ -138,6 +138,25 @@ def render_sequence(w, h, fx, fy, cx, cy, n, seed, z=1.0, step_t=0.006, step_deg
     return frames, depths, rel, absp
 
 
+def camera_to_world_poses(rel):
+    """The physical camera-to-world poses G_0 .. G_n of render_sequence's camera (world = the first camera's frame) from its
+    true per-pair transformations rel[k] (X_{k+1} = rel[k] X_k): G_0 = I, G_{k+1} = G_k * rel[k]^-1.  What a motion-capture
+    ground-truth file of the sequence would hold (TUM groundtruth.txt, EUROC state estimate)."""
+    rel = np.asarray(rel, np.float64).reshape(-1, 7)
+    out = np.zeros((len(rel) + 1, 7)); out[:, 3] = 1.0
+    G = np.eye(4)
+    for k, r in enumerate(rel):
+        x, y, z, w = r[:4] / np.linalg.norm(r[:4])
+        T = np.eye(4)
+        T[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+        T[:3, 3] = r[4:]
+        G = G @ np.linalg.inv(T)
+        out[k + 1] = np.concatenate([_quat_from_R(G[:3, :3]), G[:3, 3]])
+    return out
+
+
 def write_tum_layout(root, frames, depths, abs_poses, gt_per_frame=4):
     """A directory in the layout launch/uw_slamTUM.launch:5-8 points the reference at: rgb/<stamp>.png, depth/<stamp>.png and
     groundtruth.txt — 3 comment lines, then 'timestamp tx ty tz qx qy qz qw' (src/Visualizer.cpp:449-477), `gt_per_frame`

@@ -86,8 +86,10 @@ def _qrot(q, v):
 
 
 def relative_poses(abs_poses):
-    """rel[k] = abs[k]^-1 * abs[k+1] (float64) for n absolute poses in the library layout: the per-pair ground truth that
-    Visualizer::UpdateMessages' accumulation final = previous * SE3(q, t) (src/Visualizer.cpp:313) turns back into abs."""
+    """rel[k] = abs[k]^-1 * abs[k+1] (float64) for n absolute poses in the library layout — the inverse of compose_from: the
+    per-step factors of a trajectory that was ACCUMULATED the way Visualizer::UpdateMessages does it, final = previous *
+    SE3(q, t) (src/Visualizer.cpp:313).  NOT the tracker's per-pair pose of a camera-to-world ground-truth file — that is
+    pair_ground_truth (the inverse)."""
     P = np.asarray(abs_poses, np.float64).reshape(-1, 7)
     out = np.zeros((max(len(P) - 1, 0), 7))
     for k in range(len(P) - 1):
@@ -97,6 +99,37 @@ def relative_poses(abs_poses):
         out[k, :4] = _qmul(qi, qb)
         out[k, 4:] = _qrot(qi, P[k + 1, 4:] - P[k, 4:])
     return out
+
+
+def invert(poses):
+    """Inverse of each SE(3) pose (n x 7, library layout), float64."""
+    P = np.asarray(poses, np.float64).reshape(-1, 7)
+    out = np.zeros_like(P)
+    for k, p in enumerate(P):
+        qi = p[:4] / np.linalg.norm(p[:4]) * [-1, -1, -1, 1]
+        out[k, :4] = qi
+        out[k, 4:] = -_qrot(qi, p[4:])
+    return out
+
+
+def pair_ground_truth(cam_to_world):
+    """Per-pair ground truth in the TRACKER's convention from a camera-to-world trajectory G_0 .. G_{n-1} (what TUM's
+    groundtruth.txt and EUROC's state estimate hold): previous_frame->rigid_transformation_ maps the previous camera's
+    coordinates to the current camera's, X_{k+1} = T_k X_k (src/Tracker.cpp:595, the warp of :1450), so
+    T_k = G_{k+1}^-1 * G_k — the inverse of relative_poses(G)[k]."""
+    return invert(relative_poses(cam_to_world))
+
+
+def camera_trajectory(pair_poses, start=None):
+    """Camera-to-world poses C_1 .. C_n from the tracker's per-pair poses T_0 .. T_{n-1} (X_{k+1} = T_k X_k):
+    C_{k+1} = C_k * T_k^-1, C_0 = start (identity: the first camera's frame is the world).  Comparable with a camera-to-world
+    ground truth expressed relative to its first pose, from_first(G)."""
+    return compose_from(invert(pair_poses), start)
+
+
+def from_first(cam_to_world):
+    """G_0^-1 * G_k for k = 1 .. n-1: a camera-to-world trajectory expressed in its first camera's frame."""
+    return compose_from(relative_poses(cam_to_world))
 
 
 def compose_from(rel, start=None):
