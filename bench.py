@@ -234,6 +234,9 @@ def main(args):
     if args.reference_schedule:
         over.update(n_levels=5, first_level=4, last_level=1, max_iters=50, early_exit=1)
     params = capi.default_params(w, h, *intr, max_frames=2 * P, max_pairs=P, device=local_rank, **over)
+    # (before the context: nothing may start a child process once the GPU is initialised — under rocprofv3 a child would
+    # inherit the profiler's preloaded library; _cpp_generator builds the generator, if it has to, with that environment stripped)
+    gen = _cpp_generator() if args.generator == "cpp" else None
     if _under_profiler():
         # per-kernel statistics are to describe whole-batch launches, one at a time: the two-halves-on-two-streams form of a
         # batch overlaps launches of half the size, whose durations a trace cannot tell apart from waiting
@@ -242,7 +245,6 @@ def main(args):
 
     U = min(args.unique, P)
     refs, tgts, deps = [], [], []
-    gen = _cpp_generator() if args.generator == "cpp" else None
     for u in range(U):
         gid = int(my_pairs[u])
         if gen is not None:                                 # same pair ids -> same inputs as tools/uwt_bench
@@ -273,33 +275,14 @@ def main(args):
     # step waits (on the device) for the gather that last read the set it is about to overwrite.  (Measured with a world of one:
     # the gather itself costs a step 0.07-0.1 ms; what cost 0.3 ms more was the communicator's streams crowding the hardware
     # queues, see GPU_MAX_HW_QUEUES at the top.)
-    n_buf = 2 if use_dist else 1
-    poses_buf = [torch.empty((P, 7), dtype=torch.float32, device=dev) for _ in range(n_buf)]
-    ctx_stream = torch.cuda.ExternalStream(ctx.stream(), device=dev) if use_dist else None
-    gather_stream = torch.cuda.Stream(device=dev) if use_dist else None
-    gatherers = [distm.PoseGatherer(total, dev) for _ in range(n_buf)] if use_dist else None
-    gatherer = gatherers[0] if use_dist else None
-    align_done = [torch.cuda.Event() for _ in range(n_buf)] if use_dist else None
-    gather_done = [torch.cuda.Event() for _ in range(n_buf)] if use_dist else None
-    gather_pending = [False] * n_buf
-    gathered = [None]
-    step_no = [0]
-    last_buf = [0]
+    pipe = distm.GatherPipeline(total, P, dev, ctx.stream()) if use_dist else None
+    single_buf = None if use_dist else torch.empty((P, 7), dtype=torch.float32, device=dev)
 
     def step():
-        b = step_no[0] % n_buf
-        step_no[0] += 1
-        last_buf[0] = b
-        if use_dist and gather_pending[b]:
-            ctx_stream.wait_event(gather_done[b])          # the gather of two steps ago has read poses_buf[b]
-        ctx.track_batch_async(0, 2 * P, ref_slots, tgt_slots, poses_buf[b].data_ptr())
         if use_dist:
-            align_done[b].record(ctx_stream)
-            with torch.cuda.stream(gather_stream):
-                gather_stream.wait_event(align_done[b])
-                gathered[0] = gatherers[b].gather(poses_buf[b])   # RCCL all_gather over xGMI + permutation to global order
-                gather_done[b].record(gather_stream)
-            gather_pending[b] = True
+            pipe.step(lambda buf: ctx.track_batch_async(0, 2 * P, ref_slots, tgt_slots, buf.data_ptr()))
+        else:
+            ctx.track_batch_async(0, 2 * P, ref_slots, tgt_slots, single_buf.data_ptr())
 
     def fence():
         ctx.sync()
@@ -322,8 +305,8 @@ def main(args):
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    gpu_poses = poses_buf[last_buf[0]].cpu().numpy()
-    all_poses = gathered[0].cpu().numpy() if use_dist else gpu_poses
+    gpu_poses = (pipe.last_local() if use_dist else single_buf).cpu().numpy()
+    all_poses = pipe.gathered.cpu().numpy() if use_dist else gpu_poses
 
     # ---- after the timed region: one step with HIP events around every residual launch (each event pair drains the
     # stream, so it is kept out of `value`), then one step of the kernel's compute-only twin (its instruction-issue
@@ -408,7 +391,7 @@ def main(args):
             assert all_poses.shape == (total, 7)
             assert np.array_equal(all_poses[rank::world], gpu_poses), "gathered poses of rank 0 differ from its own"
             assert np.isfinite(all_poses).all() and (np.abs(np.linalg.norm(all_poses[:, :4], axis=1) - 1.0) < 1e-3).all()
-            out["config"]["gather"] = {"collective_ran": bool(gatherer.collective), "world": world,
+            out["config"]["gather"] = {"collective_ran": bool(pipe.collective), "world": world,
                                        "rank0_block_bitwise_equal_to_its_own_poses": True}
         # SURVEY §8(d) secondary figure: the same step with the batch's frames crossing PCIe first (never `value`)
         out["h2d_inclusive"] = {"value": round(P / (upload_s + dt / args.steps), 2), "unit": "alignments/s per GPU",
@@ -528,7 +511,10 @@ def _cpp_generator():
     import ctypes as C
     path = os.path.join(ROOT, "tools", "libuwt_gen.so")
     if not os.path.exists(path):
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "libuwt_gen.so"])
+        # normally built by __graft_entry__.build() / make -C tools.  Built here only from a process that has not touched the
+        # GPU yet (run_rank calls this before it creates its context), and without the profiler's preload in the child.
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF", "ROCTRACER"))}
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools"), "libuwt_gen.so"], env=env)
     lib = C.CDLL(path)
     lib.uwt_gen_pair.restype = C.c_int
     lib.uwt_gen_pair.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p,

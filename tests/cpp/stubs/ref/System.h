@@ -18,7 +18,9 @@ class Mat {
   size_t elemSize() const { return 1; }
   template <typename T> const T& at(int r, int c) const { return reinterpret_cast<const T*>(data)[(size_t)r * cols + c]; }
   double dot(const Mat&) const { return 0.0; }
+  Mat inv() const { return *this; }
 };
+inline Mat operator*(const Mat& a, const Mat&) { return a; }
 template <typename T>
 struct Mat_ : Mat {
   Mat_(int, int) {}
@@ -39,8 +41,12 @@ struct Vector {
 };
 struct Quat { float x() const { return 0; } float y() const { return 0; } float z() const { return 0; } float w() const { return 1; } };
 struct Vec3 { float operator()(int) const { return 0; } };
+struct EigenQuat { EigenQuat(float, float, float, float) {} };
+struct EigenVec3 { static EigenVec3 Zero() { return EigenVec3(); } };
 struct SE3f {
   static const int DoF = 6;
+  SE3f() {}
+  SE3f(const EigenQuat&, const EigenVec3&) {}
   static SE3f exp(const Vector<float, 6>&) { return SE3f(); }
   Quat unit_quaternion() const { return Quat(); }
   Vec3 translation() const { return Vec3(); }
@@ -49,6 +55,8 @@ struct SE3f {
 
 namespace uw {
 typedef Sophus::SE3f SE3;
+typedef Sophus::EigenQuat Quaternion;   // include/Options.h:135 (Eigen::Quaternion<float>: w, x, y, z)
+typedef Sophus::EigenVec3 Mat31f;       // include/Options.h:144
 extern const int PYRAMID_LEVELS;
 class Frame {
  public:

@@ -62,3 +62,52 @@ def test_shard_partition_properties():
         assert np.array_equal(allid, np.arange(n))
         assert d.shard_sizes(n, g) == [len(x) for x in ids]
         assert all((x % g == r).all() for r, x in enumerate(ids))
+
+
+def _pipeline_worker(rank, world, port, n_pairs, steps, q):
+    """bench.py's rank logic with a CPU stand-in for the context: shard -> `align` stamps every pose of the shard with its
+    global pair id and the step number -> GatherPipeline (the double-buffered exchange bench.py runs per step)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    d = importlib.import_module("uw-slam_amd.dist")
+    mine = d.shard_round_robin(n_pairs, world, rank)                 # bench.py: my_pairs
+    pipe = d.GatherPipeline(n_pairs, len(mine), torch.device("cpu"))
+    assert pipe.collective and pipe.gatherers[0].world == world
+    seen = []
+    bufs = set()
+    for k in range(steps):
+        def align(buf, k=k):
+            bufs.add(buf.data_ptr())
+            for j, gid in enumerate(mine):
+                buf[j] = torch.arange(7, dtype=torch.float32) + 10.0 * float(gid) + 1000.0 * k
+        glob = pipe.step(align)
+        seen.append(glob.clone().numpy())
+        assert np.array_equal(pipe.last_local().numpy()[:, 0], 10.0 * mine + 1000.0 * k)
+    assert len(bufs) == min(2, steps)                                # the two pose buffers take turns
+    dist.barrier()
+    if rank == 0:
+        q.put(np.stack(seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [8, 7])
+def test_bench_step_pipeline_world2_double_buffered_gather(n_pairs):
+    """The step loop bench.py runs per rank (uw-slam_amd/dist.py GatherPipeline: two pose buffers, a gatherer each, the
+    exchange behind the alignment) executed at world size 2 over gloo for five steps: every step's gathered block is that
+    step's poses of ALL pairs in global pair order — even and uneven shards."""
+    world, steps = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, n_pairs, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    seen = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    for k in range(steps):
+        expect = np.arange(7, dtype=np.float32)[None, :] + 10.0 * np.arange(n_pairs, dtype=np.float32)[:, None] + 1000.0 * k
+        assert np.array_equal(seen[k], expect), k

@@ -42,6 +42,84 @@ def _pose_distance(a, b):
     return 2.0 * np.arccos(dot), float(np.linalg.norm(a[4:] - b[4:]))
 
 
+PICK_X = np.array([-0.5, -0.5, -0.5, 0.5, 0, 0, 0], np.float32)   # R = [[0,1,0],[0,0,1],[1,0,0]]: row 2 of the rigid product picks X
+PICK_Y = np.array([0.5, 0.5, 0.5, 0.5, 0, 0, 0], np.float32)      # the transpose: row 2 picks Y
+
+
+def _under_both_sets(O, fn):
+    """fn() evaluated with the oracle's per-stage switch at either arithmetic set: {"opencv": value, "legacy": value}."""
+    out = {}
+    prev = O.set_arith(O.ARITH_OPENCV)
+    try:
+        for name, a in (("opencv", O.ARITH_OPENCV), ("legacy", O.ARITH_LEGACY)):
+            O.set_arith(a)
+            out[name] = fn()
+    finally:
+        O.set_arith(prev)
+    return out
+
+
+def _verdict(ulps):
+    """which arithmetic set a reference record equals bit for bit: 'opencv', 'legacy', 'both' or 'neither (<ulps>)'"""
+    hit = [k for k in ("opencv", "legacy") if ulps[k] == 0]
+    return "both" if len(hit) == 2 else hit[0] if hit else "neither (opencv %d ulps, legacy %d ulps)" % (ulps["opencv"], ulps["legacy"])
+
+
+def diagnose_arithmetic(O, ref, pair, p):
+    """The records that separate the two arithmetic sets (uwt_oracle.h G1-G3 against S1, S3, S4), each compared with the oracle
+    under BOTH sets — what a maintainer's first real dump says about the OpenCV build it came from:
+      unproject   column 2 of WarpFunction at the axis permutations = X * z, Y * z of Tracker.cpp:1439-1444
+                  (G3: x * invfx + beta  /  legacy: (x - cx) * invfx)
+      rigid_row   column 2 of WarpFunction at the generic test pose = one row of rigid * points.t() before the divide (:1450)
+                  (G1: double accumulation  /  S1: f32 FMA chain) — meaningful once `unproject` is settled
+      delta       "A.inv() * b" from the reference's A and b (:564)   (G2: cv::solve  /  S3 + S4: inverse, then product)
+      delta_unfolded   the same through two statements: must be the inverse-then-product whatever the build folds
+    Returns {record: verdict string}; asserts nothing."""
+    h, w = pair["ref"].shape
+    depth = pair["depth"] if "depth" in pair.files else None
+    rep = {}
+    img, dep = pair["ref"], depth
+    un, rr = {"opencv": 0, "legacy": 0}, {"opencv": 0, "legacy": 0}
+    seen_un = seen_rr = False
+    for l in range(p.n_levels):
+        if l:
+            img = O.halve_u8(img)
+            dep = O.halve_u16(dep) if dep is not None else None
+        pts = O.dense_points(dep, img.shape[1], img.shape[0], l)
+        L = O.level_intrinsics(p, l)
+        for key, pose in (("stage_unpx%d" % l, PICK_X), ("stage_unpy%d" % l, PICK_Y)):
+            if key in ref.files:
+                seen_un = True
+                mine = _under_both_sets(O, lambda: O.warp(pts, pose, L)[:, 2])
+                for k in un:
+                    un[k] = max(un[k], int(_ulps(ref[key].reshape(-1, 4)[:, 2], mine[k]).max()))
+        if "stage_warp%d" % l in ref.files and "testpose" in ref.files:
+            seen_rr = True
+            mine = _under_both_sets(O, lambda: O.warp(pts, ref["testpose"], L)[:, 2])
+            for k in rr:
+                rr[k] = max(rr[k], int(_ulps(ref["stage_warp%d" % l].reshape(-1, 4)[:, 2], mine[k]).max()))
+    if seen_un:
+        rep["unproject"] = _verdict(un)
+    if seen_rr:
+        rep["rigid_row"] = _verdict(rr)
+    upd = [i for i in range(len(ref["level"])) if int(ref["updated"][i])]
+    if upd:
+        dl = {"opencv": 0, "legacy": 0}
+        for i in upd:
+            mine = _under_both_sets(O, lambda: O.solve_delta(ref["A"][i].reshape(36), ref["b"][i]))
+            for k in dl:
+                dl[k] = max(dl[k], int(_ulps(ref["delta"][i], mine[k]).max()))
+        rep["delta"] = _verdict(dl)
+        if "delta_unfolded" in ref.files:
+            prev = O.set_arith(O.ARITH_LEGACY)
+            try:
+                u = max(int(_ulps(ref["delta_unfolded"][i], O.solve_delta(ref["A"][i].reshape(36), ref["b"][i])).max()) for i in upd)
+            finally:
+                O.set_arith(prev)
+            rep["delta_unfolded_vs_inverse_then_product_ulps"] = u
+    return rep
+
+
 def compare_with_oracle(O, ref, pair):
     """ref: a loaded ref_<case>.npz; pair: the tests/golden/pair_<case>.npz it was dumped from.  Integer stages and counts
     must be identical; float records are reported in ulps; the final pose must meet the north-star tolerance
@@ -87,6 +165,7 @@ def compare_with_oracle(O, ref, pair):
     rep["error_ulps"] = int(_ulps(ref["error"], np.array([t["error"] for t in tr], np.float32)).max())
     rep["final_rot_rad"], rep["final_trans_m"] = _pose_distance(ref["final"], pose)
     rep["final_bitwise"] = bool(np.array_equal(np.asarray(ref["final"], np.float32).view(np.uint32), pose.view(np.uint32)))
+    rep["arithmetic"] = diagnose_arithmetic(O, ref, pair, p)
     assert rep["final_rot_rad"] <= 1e-4 and rep["final_trans_m"] <= 1e-4, rep
     return rep
 
@@ -110,6 +189,8 @@ def fabricate_dump(O, pair, name, out_dir):
         gx.tofile(pre + "gx%d.i16" % l); gy.tofile(pre + "gy%d.i16" % l)
         pts.tofile(pre + "pts%d.f32" % l)
         O.warp(pts, testpose, O.level_intrinsics(p, l)).tofile(pre + "warp%d.f32" % l)
+        O.warp(pts, PICK_X, O.level_intrinsics(p, l)).tofile(pre + "unpx%d.f32" % l)
+        O.warp(pts, PICK_Y, O.level_intrinsics(p, l)).tofile(pre + "unpy%d.f32" % l)
         if dep is not None:
             dep.tofile(pre + "dep%d.u16" % l)
     st, pose, tr = O.align_pair(p, pair["ref"], pair["tgt"], depth, want_trace=True)
@@ -121,7 +202,10 @@ def fabricate_dump(O, pair, name, out_dir):
             if t["exited"]:
                 f.write("exit\n")
             else:
-                f.write("solve A %s b %s delta %s\npose %s\n" % (hx(t["A"]), hx(t["b"]), hx(t["delta"]), hx(t["pose"])))
+                prev = O.set_arith(O.ARITH_LEGACY)   # "Mat Ai = A.inv(); Mat d = Ai * b;": the inverse formed, then multiplied
+                d2 = O.solve_delta(t["A"], t["b"])
+                O.set_arith(prev)
+                f.write("solve A %s b %s delta %s\nsolve2 delta %s\npose %s\n" % (hx(t["A"]), hx(t["b"]), hx(t["delta"]), hx(d2), hx(t["pose"])))
         f.write("final %s\n" % hx(pose))
     return pose
 
@@ -170,7 +254,28 @@ def test_input_export_round_trips(tmp_path):
             assert dp.dtype == np.uint16 and np.array_equal(dp, d["depth"])
 
 
-def test_dump_loader_and_comparison_on_a_fabricated_dump(tmp_path, O):
+def test_axis_permutation_poses_expose_the_unprojection_exactly(O, arith):
+    """WarpFunction at q = (-+1/2, -+1/2, -+1/2, 1/2): the rigid matrix has entries 0 and 1 only, so row 2 of rigid * points.t()
+    is X * z (resp. Y * z) whatever the gemm accumulates in — the two sets differ there only through the unprojection."""
+    assert np.array_equal(O.se3_matrix(PICK_X)[:3, :3], np.array([[0, 1, 0], [0, 0, 1], [1, 0, 0]], np.float32))
+    assert np.array_equal(O.se3_matrix(PICK_Y)[:3, :3], np.array([[0, 0, 1], [1, 0, 0], [0, 1, 0]], np.float32))
+    p = O.default_params(160, 96, 131.25, 131.25, 79.5, 47.5)
+    rng = np.random.default_rng(5)
+    dep = rng.integers(1, 20000, (48, 80)).astype(np.uint16)
+    pts = O.dense_points(dep, 80, 48, 1)
+    L = O.level_intrinsics(p, 1)
+    x, y, z = pts[:, 0], pts[:, 1], pts[:, 2]
+    if arith == "opencv":
+        X = x * np.float32(L.invfx) + np.float32(-np.float64(L.cx) * np.float64(L.invfx))
+        Y = y * np.float32(L.invfy) + np.float32(-np.float64(L.cy) * np.float64(L.invfy))
+    else:
+        X = (x - np.float32(L.cx)) * np.float32(L.invfx)
+        Y = (y - np.float32(L.cy)) * np.float32(L.invfy)
+    assert np.array_equal(O.warp(pts, PICK_X, L)[:, 2], (X * z).astype(np.float32))
+    assert np.array_equal(O.warp(pts, PICK_Y, L)[:, 2], (Y * z).astype(np.float32))
+
+
+def test_dump_loader_and_comparison_on_a_fabricated_dump(tmp_path, O, arith):
     """The pipeline a real dump goes through, fed with the oracle's own numbers in the reference-side format: every
     comparison must come out exact (0 ulps), which checks the formats, the loader and the comparison — not parity."""
     load = _tool("load_dump")
@@ -188,6 +293,10 @@ def test_dump_loader_and_comparison_on_a_fabricated_dump(tmp_path, O):
         ref = np.load(gold / ("ref_" + name + ".npz"))
         rep = compare_with_oracle(O, ref, np.load(os.path.join(GOLDEN, name + ".npz")))
         assert rep["final_bitwise"] and all(v == 0 for k, v in rep.items() if k.endswith("_ulps")), rep
+        # the diagnosis names the set the (fabricated) dump was made under, record by record
+        ar = rep["arithmetic"]
+        assert ar["unproject"] in (arith, "both") and ar["rigid_row"] == arith and ar["delta"] in (arith, "both"), ar
+        assert ar["delta_unfolded_vs_inverse_then_product_ulps"] == 0, ar
     # a perturbed record is caught: one more valid point in one evaluation
     bad = dict(np.load(gold / "ref_pair_160x96_ref5.npz"))
     bad["n_valid"] = bad["n_valid"].copy(); bad["n_valid"][1] += 1

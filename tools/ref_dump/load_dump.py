@@ -5,8 +5,9 @@ tests/test_ref_vectors.py consumes (it skips while none exists).
     python tools/ref_dump/load_dump.py <out_dir of ref_dump> [golden_dir]
 
 Per case: the per-evaluation records of Tracker::EstimatePose (level, iter, n_valid, sum_r2, error, exited, and — where the
-evaluation was followed by an update — A, b, delta, pose), the final pose, the test pose WarpFunction was called with, and
-the stage arrays per level (img, tgt, dep, gx, gy, pts, warp).
+evaluation was followed by an update — A, b, delta, pose, and delta_unfolded = the same solve through two statements), the
+final pose, the test pose WarpFunction was called with, and the stage arrays per level (img, tgt, dep, gx, gy, pts, warp,
+unpx / unpy = WarpFunction at the two axis permutations, whose column 2 is the unprojected X * z / Y * z).
 """
 import glob
 import os
@@ -38,13 +39,17 @@ def parse_dump(path):
             elif t[0] == "eval":
                 cur["rows"].append(dict(level=int(t[1]), iter=int(t[2]), n_valid=int(t[3]), sum_r2=int(round(float(t[4]))),
                                         error=hexf(t[5:6])[0], exited=0, A=np.zeros(36, np.float32), b=np.zeros(6, np.float32),
-                                        delta=np.zeros(6, np.float32), pose=np.zeros(7, np.float32), updated=0))
+                                        delta=np.zeros(6, np.float32), pose=np.zeros(7, np.float32), updated=0,
+                                        delta_unfolded=np.zeros(6, np.float32)))
             elif t[0] == "exit":
                 cur["rows"][-1]["exited"] = 1
             elif t[0] == "solve":
                 assert t[1] == "A" and t[38] == "b" and t[45] == "delta", line[:80]
                 r = cur["rows"][-1]
                 r["A"], r["b"], r["delta"], r["updated"] = hexf(t[2:38]), hexf(t[39:45]), hexf(t[46:52]), 1
+            elif t[0] == "solve2":
+                assert t[1] == "delta", line[:80]
+                cur["rows"][-1]["delta_unfolded"] = hexf(t[2:8])
             elif t[0] == "pose":
                 cur["rows"][-1]["pose"] = hexf(t[1:8])
             elif t[0] == "final":
@@ -53,7 +58,7 @@ def parse_dump(path):
     for name, c in cases.items():
         rows = c["rows"]
         d = {k: np.array([r[k] for r in rows]) for k in ("level", "iter", "n_valid", "sum_r2", "error", "exited", "updated")}
-        for k in ("A", "b", "delta", "pose"):
+        for k in ("A", "b", "delta", "pose", "delta_unfolded"):
             d[k] = np.stack([r[k] for r in rows]) if rows else np.zeros((0,), np.float32)
         d["A"] = d["A"].reshape(-1, 6, 6) if rows else d["A"]
         d["final"] = c["final"]

@@ -9,6 +9,10 @@
 //   Tracker::ApplyGradient                       (src/Tracker.cpp:1127-1176)   -> <case>_gx<l>.i16, <case>_gy<l>.i16
 //   Tracker::ObtainAllPoints                     (src/Tracker.cpp:1259-1310)   -> <case>_pts<l>.f32 (N x 4)
 //   Tracker::WarpFunction at a fixed test pose   (src/Tracker.cpp:1417-1471)   -> <case>_warp<l>.f32 (N x 4)
+//   Tracker::WarpFunction at the two cyclic axis permutations q = (-+1/2, -+1/2, -+1/2, 1/2), t = 0: every entry of the rigid
+//   matrix is exactly 0 or 1, so whatever cv::gemm accumulates in, column 2 of the result IS the unprojected X * z (resp.
+//   Y * z) of Tracker.cpp:1439-1444, bit for bit: the quantity that tells the folded scaled convert x * invfx + beta from
+//   (x - cx) * invfx                                                              -> <case>_unpx<l>.f32, <case>_unpy<l>.f32
 //   Tracker::EstimatePose                        (src/Tracker.cpp:362-597)     -> dump.txt records (ref_dump_hooks.h) written
 //                                                                                 by the instrumented Tracker_refdump.cpp
 // Usage:  ref_dump <inputs_dir> <out_dir>
@@ -68,6 +72,10 @@ int main(int argc, char** argv) {
     Sophus::Vector<float, SE3::DoF> xi;
     xi << 0.01f, -0.02f, 0.015f, 0.004f, -0.003f, 0.002f;
     const SE3 test_pose = SE3::exp(xi);
+    // rotations by 120 degrees about (1,1,1) and back: R = [[0,1,0],[0,0,1],[1,0,0]] (row 2 picks X) and its transpose
+    // (row 2 picks Y); unit quaternions with exactly representable coefficients (Eigen order: w, x, y, z)
+    const SE3 pick_x(Quaternion(0.5f, -0.5f, -0.5f, -0.5f), Mat31f::Zero());
+    const SE3 pick_y(Quaternion(0.5f, 0.5f, 0.5f, 0.5f), Mat31f::Zero());
     for (int l = 0; l < PYRAMID_LEVELS; l++) {
       const std::string s = std::to_string(l);
       write_raw(pre + "_img" + s + ".u8", prev->images_[l]);
@@ -77,6 +85,8 @@ int main(int argc, char** argv) {
       write_raw(pre + "_gy" + s + ".i16", prev->gradientY_[l]);
       write_raw(pre + "_pts" + s + ".f32", prev->candidatePoints_[l]);
       write_raw(pre + "_warp" + s + ".f32", tracker->WarpFunction(prev->candidatePoints_[l], test_pose, l));
+      write_raw(pre + "_unpx" + s + ".f32", tracker->WarpFunction(prev->candidatePoints_[l], pick_x, l));
+      write_raw(pre + "_unpy" + s + ".f32", tracker->WarpFunction(prev->candidatePoints_[l], pick_y, l));
     }
     uw_ref_dump::begin_case(name.c_str());
     uw_ref_dump::pose_line("testpose", test_pose);

@@ -6,7 +6,10 @@
 //   case <name>
 //   eval <lvl> <k> <num_valid> <sum_r2> <error>          Tracker.cpp:493-502 (raw residuals, before the x50 gain)
 //   exit                                                  the termination test fired at this evaluation (:508)
-//   solve A <36> b <6> delta <6>                          :560-564 (row-major A)
+//   solve A <36> b <6> delta <6>                          :560-564 (row-major A); delta is the reference's own "A.inv() * b"
+//   solve2 delta <6>                                      the same A and b through TWO statements, "Mat Ai = A.inv(); Mat d = Ai * b;"
+//                                                         — the inverse is formed and multiplied, the MatExpr algebra cannot fold it
+//                                                         into cv::solve: next to `solve` it shows which of the two the build runs
 //   pose <qx qy qz qw tx ty tz>                           :574, after the update
 //   final <qx qy qz qw tx ty tz>                          :595, previous_frame->rigid_transformation_
 #pragma once
@@ -34,6 +37,10 @@ inline void solve(const cv::Mat& A, const cv::Mat& b, const cv::Mat& delta) {
   std::fprintf(out(), "solve A"); floats(A);
   std::fprintf(out(), " b"); floats(b);
   std::fprintf(out(), " delta"); floats(delta);
+  std::fprintf(out(), "\n");
+  cv::Mat Ai = A.inv();        // (evaluated: cv::invert, DECOMP_LU)
+  cv::Mat d2 = Ai * b;         // (a plain gemm)
+  std::fprintf(out(), "solve2 delta"); floats(d2);
   std::fprintf(out(), "\n");
 }
 template <typename SE3T>

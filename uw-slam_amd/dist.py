@@ -63,3 +63,61 @@ class PoseGatherer:
 def gather_poses(local_poses, n_pairs, group=None):
     """One-off form of PoseGatherer.gather (allocates; a loop should keep a PoseGatherer)."""
     return PoseGatherer(n_pairs, local_poses.device, local_poses.dtype, group).gather(local_poses)
+
+
+class GatherPipeline:
+    """The step loop of the sharded batched mode (bench.py): every step enqueues this rank's alignment into one of two pose
+    buffers and, behind it, the exchange (PoseGatherer.gather) on a stream of its own — no host synchronisation per step:
+
+      step k:  [wait: the gather that last read poses[k % 2] has finished]  ->  align(poses[k % 2]) on the context's stream
+               -> event align_done  ->  on the gather stream: wait align_done, all_gather + un-shuffle into the gatherer's
+               own output buffer, event gather_done
+
+    so the next step's kernels never queue behind the collective, and a pose buffer is not overwritten while its gather may
+    still read it.  On a CPU device (the gloo tests) there are no streams: the same calls run synchronously in this order.
+    `align(buf)` must enqueue (CUDA) or perform (CPU) the alignment that fills `buf` ([n_local, 7]) in shard order."""
+
+    N_BUF = 2
+
+    def __init__(self, n_pairs, n_local, device, ctx_stream_handle=None, group=None, dtype=None):
+        import torch
+        self.torch = torch
+        self.cuda = torch.device(device).type == "cuda"
+        dtype = dtype or torch.float32
+        self.poses = [torch.empty((n_local, 7), dtype=dtype, device=device) for _ in range(self.N_BUF)]
+        self.gatherers = [PoseGatherer(n_pairs, device, dtype, group) for _ in range(self.N_BUF)]
+        self.pending = [False] * self.N_BUF
+        self.step_no = 0
+        self.last = 0
+        self.gathered = None
+        if self.cuda:
+            self.ctx_stream = torch.cuda.ExternalStream(ctx_stream_handle, device=device)
+            self.gather_stream = torch.cuda.Stream(device=device)
+            self.align_done = [torch.cuda.Event() for _ in range(self.N_BUF)]
+            self.gather_done = [torch.cuda.Event() for _ in range(self.N_BUF)]
+
+    @property
+    def collective(self):
+        return self.gatherers[0].collective
+
+    def step(self, align):
+        b = self.step_no % self.N_BUF
+        self.step_no += 1
+        self.last = b
+        if self.cuda:
+            if self.pending[b]:
+                self.ctx_stream.wait_event(self.gather_done[b])      # the gather of two steps ago has read poses[b]
+            align(self.poses[b])
+            self.align_done[b].record(self.ctx_stream)
+            with self.torch.cuda.stream(self.gather_stream):
+                self.gather_stream.wait_event(self.align_done[b])
+                self.gathered = self.gatherers[b].gather(self.poses[b])   # RCCL all_gather over xGMI + permutation to global order
+                self.gather_done[b].record(self.gather_stream)
+        else:
+            align(self.poses[b])
+            self.gathered = self.gatherers[b].gather(self.poses[b])
+        self.pending[b] = True
+        return self.gathered
+
+    def last_local(self):
+        return self.poses[self.last]
