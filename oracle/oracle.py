@@ -247,6 +247,13 @@ def set_arith(arith):
     return lib().uwo_set_arith(int(arith))
 
 
+def set_gemm_fold(fold):
+    """Fold of GEMMSingleMul's four partial sums in the 4-term rigid product and the short 1-wide sums: 0 (default, the
+    source's "s0 += s1 + s2 + s3": s0 + ((s1 + s2) + s3)) or 1 (((s0 + s1) + s2) + s3, diagnosis only: the HIP kernels
+    implement fold 0).  Returns the previous one."""
+    return lib().uwo_set_gemm_fold(int(fold))
+
+
 def solve6(A, b):
     """cv::solve(A, b, x, DECOMP_LU): (x, ok)."""
     A = np.ascontiguousarray(A, np.float32).reshape(36)

@@ -304,6 +304,25 @@ int uwo_set_arith(int arith) {
   return prev;
 }
 
+/* How GEMMSingleMul's "A * Bt" branch folds its four partial sums.  matmul.cpp writes "s0 += s1 + s2 + s3;" ahead of the
+ * store "d_data[j] = T(s0*alpha)": C++ evaluates the right-hand side first, so the stored sum is s0 + ((s1 + s2) + s3) —
+ * fold 0, the default.  Fold 1, ((s0 + s1) + s2) + s3, is what a left-to-right reading of "(s0+s1+s2+s3)" gives; kept
+ * selectable so that a dump of a real build (tools/ref_dump) can say which of the two it follows.  The two differ only where
+ * the double-precision sums round differently AND the float rounding of the result falls between them: about one stored
+ * value in 10^9. */
+static int g_gemm_fold = 0;
+int uwo_set_gemm_fold(int fold) {
+  int prev = g_gemm_fold;
+  g_gemm_fold = fold ? 1 : 0;
+  return prev;
+}
+static inline double fold4(double s0, double s1, double s2, double s3) {
+  if (g_gemm_fold) return ((s0 + s1) + s2) + s3;
+  double t = s1 + s2;
+  t = t + s3;
+  return s0 + t;
+}
+
 /* "(col - c) * inv" of Tracker.cpp:1439 / :1443 on one element.
  * G3: operator-(Mat, Scalar) makes MatOp_AddEx(a, alpha = 1, s = -(double)c); operator*(MatExpr, double) is
  * MatOp_AddEx::multiply: alpha *= inv, s *= inv — both in double; Mat::operator=(MatExpr) runs MatOp_AddEx::assign:
@@ -336,10 +355,11 @@ void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, 
     for (int k = 0; k < 4; k++) {  /* :1450 rigid * P^T */
       if (g_arith != UWO_ARITH_LEGACY) {
         /* G1: gemm(rigid, P, 1, GEMM_2_T) -> GEMMSingleMul<float,double>, "A * Bt" branch, n = 4: the unrolled loop
-         * runs once, s0 = a0*b0, s1 = a1*b1, s2 = a2*b2, s3 = a3*b3 (exact in double), d = T((s0+s1+s2+s3)*alpha), alpha = 1 */
+         * runs once, s0 = a0*b0, s1 = a1*b1, s2 = a2*b2, s3 = a3*b3 (exact in double), "s0 += s1 + s2 + s3" (fold4),
+         * d = T(s0*alpha), alpha = 1 */
         double s0 = (double)T[4 * k] * (double)X, s1 = (double)T[4 * k + 1] * (double)Y;
         double s2 = (double)T[4 * k + 2] * (double)z, s3 = (double)T[4 * k + 3] * (double)w;
-        o[k] = (float)(((s0 + s1) + s2) + s3);
+        o[k] = (float)fold4(s0, s1, s2, s3);
         continue;
       }
       float s = T[4 * k] * X;
@@ -539,7 +559,7 @@ void uwo_huber_weights(const float* r, int n, float* w) {
  * GEMM_2_T, so both code paths below run their "A * Bt" branch.  `rows` = d_size.height (6 for Jᵀr, 1 for rᵀr).
  *  - single pass ("(d_size.height <= 64 || d_size.width <= 64) && len <= 10000"): GEMMSingleMul<float,double>, four partial
  *    sums over k, k+1, k+2, k+3 (CV_ENABLE_UNROLLED is 1 outside ICC / CV_DISABLE_OPTIMIZATION), the tail into s0, then
- *    (s0+s1+s2+s3) * alpha;
+ *    "s0 += s1 + s2 + s3" (fold4), s0 * alpha;
  *  - otherwise the block algorithm: dm0 = min(128, rows), dn0 = 1, dk0 = min(16384 / dm0, 16384 / dn0, len); per block
  *    [k, k + dk): GEMMBlockMul<float,double>: s0 = (first block ? 0 : d_buf), s1 = 0, pairs into s0 / s1, an odd last term
  *    into s0, d_buf = s0 + s1; a block absorbs the remainder when "k + dk >= len || 8*(k + dk) + dk > 8*len";
@@ -561,7 +581,7 @@ static double gemm_dot_width1(const float* a, size_t sa, const float* b, int n, 
       s3 += (double)a[sa * (size_t)(k + 3)] * (double)b[k + 3];
     }
     for (; k < n; k++) s0 += (double)a[sa * (size_t)k] * (double)b[k];
-    return (s0 + s1 + s2 + s3) * alpha;
+    return fold4(s0, s1, s2, s3) * alpha;
   }
   const int block_size = 128 * 128;
   int dm0 = rows < 128 ? rows : 128;

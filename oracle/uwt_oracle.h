@@ -21,13 +21,14 @@
  *  G1  every cv::gemm on CV_32F runs GEMMSingleMul<float,double> / GEMMBlockMul<float,double>: operands widened to
  *      double, products exact, partial sums in double, ONE rounding to float on store:
  *      - rigid * points.t() (Tracker.cpp:1450; GEMM_2_T, len 4): s0..s3 take one product each, stored value
- *        (float)(((T0*X + T1*Y) + T2*Z) + T3*w);
+ *        (float)(T0*X + ((T1*Y + T2*Z) + T3*w)) — the source folds the partial sums with "s0 += s1 + s2 + s3;", whose
+ *        right-hand side is evaluated first (uwo_set_gemm_fold(1) selects the left-to-right fold ((s0+s1)+s2)+s3 instead);
  *      - Jl * Jw (:479; flags 0, len 2, 1x6 result — the inline len-2 case needs len == d_size.width|height, so the
  *        generic branch runs): (float)((0 + g0*Jw0k) + g1*Jw1k);
  *      - Jacobians.t() * Jacobians (:560; GEMM_1_T, 6x6, len N): one sequential double sum per entry (also through
  *        the block algorithm for N > 10000, whose d_buf carries the sum from block to block);
  *      - 1-wide results (-Jacobians.t() * Residuals.mul(W) :561, inv_n * Residuals.t() * ResidualsW :501): gemmImpl
- *        turns them into A*Bt with b_step 0; N <= 10000: four interleaved partial sums ((s0+s1)+s2)+s3 (CV_ENABLE_UNROLLED);
+ *        turns them into A*Bt with b_step 0; N <= 10000: four interleaved partial sums folded the same way (CV_ENABLE_UNROLLED);
  *        N > 10000: blocks of dk0 = min(16384/rows, N) terms, two interleaved partial sums per block, the total carried
  *        in double across blocks; alpha (-1, inv_n) applied in double before the store.
  *  G2  A.inv() * b (:564) is MatOp_Invert::matmul -> MatOp_Solve -> cv::solve(A, b, x, DECOMP_LU) -> hal::LU32f(A, 6, b, 1):
@@ -144,6 +145,8 @@ void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, 
 /* Process-wide arithmetic set of the per-stage functions (uwo_warp, uwo_residual_jacobian*, uwo_normal_equations,
  * uwo_error, uwo_solve_delta); uwo_estimate_pose* set it from uwo_params::arith on entry.  Returns the previous one. */
 int uwo_set_arith(int arith);
+/* fold of GEMMSingleMul's four partial sums: 0 (default) s0 + ((s1 + s2) + s3), 1 ((s0 + s1) + s2) + s3; returns the previous */
+int uwo_set_gemm_fold(int fold);
 
 /* per-point loop of Tracker::EstimatePose, Tracker.cpp:432-490.
  * J (n x 6) and r (n) receive the valid rows compacted; idx (n, optional) their point index. */

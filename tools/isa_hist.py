@@ -5,7 +5,8 @@ import collections
 import re
 import sys
 
-path = "uw-slam_amd/csrc/uwt_capi.gfx950.s"
+import os
+path = os.environ.get("ISA_FILE", "uw-slam_amd/csrc/uwt_capi.gfx950.s")
 key = sys.argv[1]
 lines = open(path).read().splitlines()
 start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3uwt") and ":" in l and key in l.split(":")[0])

@@ -535,21 +535,20 @@ __device__ __forceinline__ F div_by(F n, F d, F r) {
 }
 
 // One row of rigid * points.t() (src/Tracker.cpp:1450) as cv::gemm computes it on CV_32F (GEMMSingleMul<float,double>,
-// GEMM_2_T, len 4: s0 = a0*b0, s1 = a1*b1, s2 = a2*b2, s3 = a3*b3 in double — exact — then T((s0+s1+s2+s3)*alpha)).
-// A product of two widened floats is exact in double, so fma(a, b, s) = RN(s + a*b) is the separate add.
+// GEMM_2_T, len 4: s0 = a0*b0, s1 = a1*b1, s2 = a2*b2, s3 = a3*b3 in double — exact — then "s0 += s1 + s2 + s3;", whose
+// right-hand side C++ evaluates first: T((s0 + ((s1 + s2) + s3)) * alpha)).  A product of two widened floats is exact in
+// double, so fma(a, b, s) = RN(s + a*b) is the separate add.
 __device__ __forceinline__ float rigid_row_f64(const double* Td, double Xd, double Yd, double zd) {   // w = 1
-  double s = Td[0] * Xd;
-  s = __builtin_fma(Td[1], Yd, s);
-  s = __builtin_fma(Td[2], zd, s);
-  s = s + Td[3];
-  return (float)s;
+  double t = Td[1] * Yd;
+  t = __builtin_fma(Td[2], zd, t);
+  t = t + Td[3];
+  return (float)__builtin_fma(Td[0], Xd, t);
 }
 __device__ __forceinline__ float rigid_row_f64(const double* Td, double Xd, double Yd, double zd, double wd) {
-  double s = Td[0] * Xd;
-  s = __builtin_fma(Td[1], Yd, s);
-  s = __builtin_fma(Td[2], zd, s);
-  s = __builtin_fma(Td[3], wd, s);
-  return (float)s;
+  double t = Td[1] * Yd;
+  t = __builtin_fma(Td[2], zd, t);
+  t = __builtin_fma(Td[3], wd, t);
+  return (float)__builtin_fma(Td[0], Xd, t);
 }
 
 template <int AR, typename F>
@@ -769,15 +768,22 @@ __device__ __forceinline__ void pixel_jacobian(const LevelK& L, float zf_, float
 // The kArithOpenCV row of one pixel pair handed to the f64 sums as doubles (the identity path of residual_core): column k >= 2
 // is (double)(float)(g0 * Jw0k + g1 * Jw1k) with the sum formed in double, columns 0 and 1 the widened f32 products.
 // (j0 = g0 * a0, j1 = g1 * b1: the packed f32 products; av, bv: jw_terms' columns 2..5; c: the pixel of the pair)
-template <typename F>
+// SQUARE: jw_terms made a3 = -b4 (av[1] = -bv[2]), so its widening is the other's with the sign flipped: one conversion less.
+template <bool SQUARE, typename F>
 __device__ __forceinline__ void jacobian_row_f64(F g0, F g1, F j0, F j1, const F av[4], const F bv[4], int c, double Jd[6]) {
   const double g0d = (double)get(g0, c), g1d = (double)get(g1, c);
   Jd[0] = (double)get(j0, c);
   Jd[1] = (double)get(j1, c);
+  double b4d = 0.0;
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    double p = g0d * (double)get(av[k], c);
-    p = __builtin_fma(g1d, (double)get(bv[k], c), p);
+  for (int i = 0; i < 4; i++) {
+    constexpr int order[4] = {0, 2, 1, 3};   // column 4 (k = 2) ahead of column 3 (k = 1), which reuses its widened b4
+    const int k = order[i];
+    const double bd = (double)get(bv[k], c);
+    if (k == 2) b4d = bd;
+    const double ad = (SQUARE && k == 1) ? -b4d : (double)get(av[k], c);
+    double p = g0d * ad;
+    p = __builtin_fma(g1d, bd, p);
     Jd[2 + k] = (double)(float)p;
   }
 }
@@ -1208,6 +1214,14 @@ struct ResidualArgs {
   TailUpdate tail;
 };
 
+// What a caller that evaluates a level inside its own launch (k_coarse) changes of a level's ResidualArgs — handed over beside
+// the arguments instead of in a modified copy: the copy (200 bytes, no longer backed by the kernel-argument segment) would have
+// to live in registers for the whole launch.
+struct CoreOverride {
+  int groups_per_block, slices;
+  uint32_t* partials;
+};
+
 // reference planes of one group of VEC pixels, as loaded (one vector load per plane)
 template <int VEC>
 struct RefGroup {
@@ -1248,7 +1262,7 @@ template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename Ac
           bool COMPUTE_ONLY = false, int EXT_LDS = 0>   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first = nullptr, int ref_slot = -1,
-                                              int tgt_slot = -1);
+                                              int tgt_slot = -1, const CoreOverride* ov = nullptr);
 
 // the reference planes of the first group of (pair, slice) for this thread: what residual_core loads before anything else
 template <int VEC, bool DEPTH, bool COMPUTE_ONLY>
@@ -1280,7 +1294,12 @@ __device__ __forceinline__ bool residual_block(const ResidualArgs& a, const int 
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
           int EXT_LDS>
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
-                                              unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot) {
+                                              unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot,
+                                              const CoreOverride* ov) {
+  const int a_groups_per_block = ov ? ov->groups_per_block : a.groups_per_block;
+  const int a_slices = ov ? ov->slices : a.slices;
+  uint32_t* const a_partials = ov ? ov->partials : a.partials;
+  const bool a_probe = ov ? false : a.probe != 0;
   // MASKED: f64 sums added under an EXEC mask of the valid lanes (masked_sums_*), nothing of an invalid pixel sanitised
   constexpr bool MASKED = std::is_same<AccT, double>::value && !DUMP;
   WarpK K;
@@ -1317,7 +1336,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
 
   unsigned long long clk0 = 0, rt0 = 0;
-  if (a.probe) {
+  if (a_probe) {
     clk0 = __builtin_amdgcn_s_memtime();
     rt0 = __builtin_amdgcn_s_memrealtime();
   }
@@ -1341,8 +1360,8 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   }
 
   const int n_groups = L.n / VEC;
-  const int g_begin = slice * a.groups_per_block;
-  const int g_end = min(g_begin + a.groups_per_block, n_groups);
+  const int g_begin = slice * a_groups_per_block;
+  const int g_end = min(g_begin + a_groups_per_block, n_groups);
   const int iters = (g_end - g_begin + kBlock - 1) / kBlock;  // block-uniform trip count
 
   // Software pipeline over groups.  `rg` holds the reference planes of the group being processed and is re-requested IN
@@ -1434,8 +1453,16 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       if constexpr (MASKED) {
-        put(g0[j / N], j % N, (float)rg.gx[j]);
-        put(g1[j / N], j % N, (float)rg.gy[j]);
+        float gxf = (float)rg.gx[j], gyf = (float)rg.gy[j];
+        if constexpr (AR == kArithOpenCV) {
+          // the gradient is needed as f32 (columns 0, 1) and as f64 (columns 2..5).  Opaque here, so that the double is widened
+          // from the float (one conversion with the 16-bit extraction folded in — SDWA — and one widening) instead of being
+          // converted from the integer a second time, which costs a separate sign extension per value.
+          asm("" : "+v"(gxf));
+          asm("" : "+v"(gyf));
+        }
+        put(g0[j / N], j % N, gxf);
+        put(g1[j / N], j % N, gyf);
       } else {
         put(g0[j / N], j % N, keep_f((float)rg.gx[j], okm[j]));
         put(g1[j / N], j % N, keep_f((float)rg.gy[j], okm[j]));
@@ -1465,7 +1492,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
         for (int c = 0; c < N; c++) {
           const int j = u * N + c;
           double Jd[6];
-          jacobian_row_f64<F>(g0[u], g1[u], j0, j1, av, bv, c, Jd);
+          jacobian_row_f64<SQUARE, F>(g0[u], g1[u], j0, j1, av, bv, c, Jd);
           const int ri = i2[j] - (int)i1[j];
           masked_sums_lo(acc, Jd, okm[j]);
           masked_sums_hi<0>(acc, r2d, Jd, (double)ri, 0.0, okm[j]);
@@ -1597,12 +1624,12 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   for (int it = 0; it < iters; it++, g += kBlock) body(rg, 1);
 #endif
   const uint32_t n_valid = (threadIdx.x & 63) == 0 ? n_valid_wave : 0u;
-  uint32_t* out_rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
+  uint32_t* out_rec = a_partials + ((size_t)pair * a_slices + slice) * kRecWords;
 #ifdef UWT_EXP_STAMPS
   if (threadIdx.x == 0) out_rec[62] = (uint32_t)__builtin_amdgcn_s_memrealtime();
 #endif
   constexpr bool R2D = MASKED && !GENERAL;   // the identity path's sum of r^2 is the f64 one
-  const bool coherent = a.tail.on != 0;   // the record is read in this launch (tail_update_wave)
+  const bool coherent = !ov && a.tail.on != 0;   // the record is read in this launch (tail_update_wave)
   if constexpr (EXT_LDS != 0 && R2D) block_reduce_store_at<AccT, false, EXT_LDS, double>(lds, acc, r2d, n_valid, out_rec, err);   // the caller's bytes: k_iterate
   else if constexpr (EXT_LDS != 0) block_reduce_store_at<AccT, GENERAL, EXT_LDS>(lds, acc, sum_r2, n_valid, out_rec, err);
   else if constexpr (TABLE) {
@@ -1610,8 +1637,8 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     block_reduce_store_at<AccT, true>(tlds, acc, sum_r2, n_valid, out_rec, err, coherent);
   } else if constexpr (R2D) block_reduce_store<AccT, false, double>(acc, r2d, n_valid, out_rec, err, coherent);
   else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err, coherent);
-  if (a.probe && threadIdx.x == 0) {
-    uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
+  if (a_probe && threadIdx.x == 0) {
+    uint32_t* rec = a_partials + ((size_t)pair * a_slices + slice) * kRecWords;
     rec[60] = (uint32_t)(__builtin_amdgcn_s_memtime() - clk0);
     rec[61] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt0);
   }
@@ -2417,11 +2444,11 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
 #pragma unroll
   for (int li = 0; li < NLEV; li++) {
     if (li >= ca.n_levels) break;   // block-uniform
-    ResidualArgs a = ca.lv[li];
-    a.slices = 1;
-    a.groups_per_block = ((a.L.n / 4 + kBlock - 1) / kBlock) * kBlock;   // the whole level
-    a.partials = rec - (size_t)pair * kRecWords;                          // residual_core writes record (pair, slice 0)
-    a.probe = 0;
+    const ResidualArgs& a = ca.lv[li];   // read in place (the kernel-argument segment); what differs travels in `ov`
+    CoreOverride ov;
+    ov.slices = 1;
+    ov.groups_per_block = ((a.L.n / 4 + kBlock - 1) / kBlock) * kBlock;   // the whole level
+    ov.partials = rec - (size_t)pair * kRecWords;                          // residual_core writes record (pair, slice 0)
     UpdateArgs u = ca.u;
     u.slices = 1;
     u.active = nullptr;
@@ -2429,7 +2456,7 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
       for (int k = 0; k < u.max_iters; k++) {
         __syncthreads();   // every thread has taken the state out of the update's LDS bytes: they become the reduction's
         if (threadIdx.x == 0) *cur = st;
-        residual_core<AR, 4, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot);
+        residual_core<AR, 4, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
         __syncthreads();   // the record and the state are in LDS; the reduction's image is free
         u.k = k;
         st = update_compute(u, rec, cur, lds, false);   // ends with a barrier: every thread has the new state
