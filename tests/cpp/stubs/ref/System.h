@@ -43,8 +43,10 @@ struct Quat { float x() const { return 0; } float y() const { return 0; } float 
 struct Vec3 { float operator()(int) const { return 0; } };
 struct EigenQuat { EigenQuat(float, float, float, float) {} };
 struct EigenVec3 { static EigenVec3 Zero() { return EigenVec3(); } };
+struct Mat4 { float operator()(int, int) const { return 0; } };
 struct SE3f {
   static const int DoF = 6;
+  Mat4 matrix() const { return Mat4(); }
   SE3f() {}
   SE3f(const EigenQuat&, const EigenVec3&) {}
   static SE3f exp(const Vector<float, 6>&) { return SE3f(); }
@@ -57,6 +59,7 @@ namespace uw {
 typedef Sophus::SE3f SE3;
 typedef Sophus::EigenQuat Quaternion;   // include/Options.h:135 (Eigen::Quaternion<float>: w, x, y, z)
 typedef Sophus::EigenVec3 Mat31f;       // include/Options.h:144
+typedef Sophus::Mat4 Mat44f;            // include/Options.h (Eigen::Matrix<float,4,4>)
 extern const int PYRAMID_LEVELS;
 class Frame {
  public:

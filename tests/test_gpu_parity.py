@@ -255,6 +255,23 @@ def test_warp_table_bit_exact(capi, O):
         assert np.array_equal(a.view(np.uint32), b.view(np.uint32))  # bitwise, NaNs included
 
 
+@pytest.mark.one_arith
+def test_warp_folds_the_rigid_product_as_the_oracle_does(capi, O):
+    # the one-point vector of tests/test_oracle.py that separates "s0 += s1 + s2 + s3" from the left-to-right fold
+    from test_oracle import gemm_fold_vector
+    pose, pts, L, lo, hi = gemm_fold_vector(O)
+    ctx = make_ctx(capi, 64, 64, (1.0, 1.0, 0.0, 0.0))
+    a = ctx.warp(0, pts, pose)
+    assert a[0][2] == lo and a[0][2] != hi
+    assert np.array_equal(a.view(np.uint32), O.warp(pts, pose, L).view(np.uint32))
+    # and the probe tools/ref_dump builds for a generic pose (what a reference build is asked)
+    from test_ref_vectors import fold_probe
+    pose = O.se3_exp(np.array([0.01, -0.02, 0.015, 0.004, -0.003, 0.002], np.float32))
+    fp = fold_probe(O.se3_matrix(pose).reshape(4, 4)[2, :3])
+    a = ctx.warp(0, np.array([[fp[0], fp[1], fp[2], 0.0]], np.float32), pose)
+    assert a[0][2] == fp[3]
+
+
 def _load_pair(ctx, ref, tgt, depth=None):
     d = None if depth is None else np.stack([depth, depth])
     ctx.upload_frames(0, np.stack([ref, tgt]), d)

@@ -383,3 +383,40 @@ def test_arithmetic_set_sensitivity(O, synth):
 def test_oracle_params_reject_unknown_fields(O):
     with pytest.raises(AttributeError):
         O.default_params(64, 48, 64.0, 64.0, 31.5, 23.5, small_products_f64=1)
+
+
+# ---------------------------------------------------------------- the fold of GEMMSingleMul's partial sums (G1)
+
+def gemm_fold_vector(O):
+    """One point whose warped z separates the two folds of the 4-term rigid product (src/Tracker.cpp:1450).
+    Row 2 of the rigid matrix of q = (0, 1/4, 1/4, w) is (-w/2, 1/8, 7/8), exactly.  With z = 8 m / 7, m = (2^24 + 13) 2^-24
+    — a midpoint of two floats whose lower neighbour is even — the term s2 = (7/8) z is m itself; x and y put s0 = 0.49 and
+    s1 = 0.29 units of m's last double place beside it.  "s0 += s1 + s2 + s3" adds s1 to m first (m again), then s0 (m again):
+    the tie rounds to the even float.  ((s0 + s1) + s2) + s3 adds the two small terms first (0.78 units), m moves up one
+    place and the float rounds up."""
+    from fractions import Fraction
+    pose = np.array([0, .25, .25, np.float32(np.sqrt(3) / 2), 0, 0, 0], np.float32)
+    M = 2 ** 24 + 13
+    z = np.float32(Fraction(M, 7) / 2 ** 21)
+    assert Fraction(float(z)) * 7 / 8 == Fraction(M, 2 ** 24)
+    pts = np.array([[-2.0 ** -52, 2.0 ** -51, z, 1.0]], np.float32)
+    L = O.Level()
+    L.w = L.h = 64
+    L.fx = L.fy = L.invfx = L.invfy = 1.0
+    L.cx = L.cy = 0.0
+    lo = np.float32(Fraction(M - 1, 2 ** 24))
+    return pose, pts, L, lo, np.nextafter(lo, np.float32(2))
+
+
+@pytest.mark.one_arith
+def test_gemm_fold_follows_the_published_statement(O):
+    pose, pts, L, lo, hi = gemm_fold_vector(O)
+    T = O.se3_matrix(pose).reshape(4, 4)
+    assert tuple(T[2, 1:]) == (0.125, 0.875, 0.0)
+    assert O.warp(pts, pose, L)[0][2] == lo            # default: s0 + ((s1 + s2) + s3)
+    prev = O.set_gemm_fold(1)
+    try:
+        assert O.warp(pts, pose, L)[0][2] == hi        # ((s0 + s1) + s2) + s3
+    finally:
+        O.set_gemm_fold(prev)
+    assert O.warp(pts, pose, L)[0][2] == lo

@@ -65,6 +65,40 @@ def _verdict(ulps):
     return "both" if len(hit) == 2 else hit[0] if hit else "neither (opencv %d ulps, legacy %d ulps)" % (ulps["opencv"], ulps["legacy"])
 
 
+UNIT_CAMERA = dict(w=64, h=64, fx=1.0, fy=1.0, cx=0.0, cy=0.0, invfx=1.0, invfy=1.0)
+
+
+def unit_level(O):
+    L = O.Level()
+    for k, v in UNIT_CAMERA.items():
+        setattr(L, k, v)
+    return L
+
+
+def fold_verdict(O, ref):
+    """The `foldprobe` record (tools/ref_dump/fold_probe.h): how the build's gemm folds the four partial sums of the rigid product.
+    'published' = "s0 += s1 + s2 + s3" (the oracle's and the kernels' fold 0), 'left_to_right' = ((s0 + s1) + s2) + s3;
+    'matrix differs' when row 2 of the build's rigid matrix is not the oracle's (S6 comes first then); 'neither' otherwise."""
+    r, pt, lo, hi, out = ref["foldprobe"][:3], ref["foldprobe"][3:6], ref["foldprobe"][6], ref["foldprobe"][7], ref["foldprobe"][8]
+    T = O.se3_matrix(ref["testpose"]).reshape(4, 4)
+    if not np.array_equal(T[2, :3].view(np.uint32), np.asarray(r, np.float32).view(np.uint32)):
+        return "matrix differs (S6: the quaternion-to-matrix arithmetic), fold undetermined"
+    pts = np.array([[pt[0], pt[1], pt[2], 0.0]], np.float32)
+    mine = {}
+    prev_a = O.set_arith(O.ARITH_OPENCV)
+    try:
+        for fold in (0, 1):
+            prev = O.set_gemm_fold(fold)
+            try:
+                mine[fold] = O.warp(pts, ref["testpose"], unit_level(O))[0][2]
+            finally:
+                O.set_gemm_fold(prev)
+    finally:
+        O.set_arith(prev_a)
+    assert mine[0] == lo and mine[1] == hi, (mine, lo, hi)   # the construction itself, re-checked against the oracle
+    return "published" if out == lo else "left_to_right" if out == hi else "neither (%s)" % float(out).hex()
+
+
 def diagnose_arithmetic(O, ref, pair, p):
     """The records that separate the two arithmetic sets (uwt_oracle.h G1-G3 against S1, S3, S4), each compared with the oracle
     under BOTH sets — what a maintainer's first real dump says about the OpenCV build it came from:
@@ -74,6 +108,7 @@ def diagnose_arithmetic(O, ref, pair, p):
                   (G1: double accumulation  /  S1: f32 FMA chain) — meaningful once `unproject` is settled
       delta       "A.inv() * b" from the reference's A and b (:564)   (G2: cv::solve  /  S3 + S4: inverse, then product)
       delta_unfolded   the same through two statements: must be the inverse-then-product whatever the build folds
+      rigid_fold  the one-point fold probe (fold_verdict)
     Returns {record: verdict string}; asserts nothing."""
     h, w = pair["ref"].shape
     depth = pair["depth"] if "depth" in pair.files else None
@@ -98,6 +133,8 @@ def diagnose_arithmetic(O, ref, pair, p):
             mine = _under_both_sets(O, lambda: O.warp(pts, ref["testpose"], L)[:, 2])
             for k in rr:
                 rr[k] = max(rr[k], int(_ulps(ref["stage_warp%d" % l].reshape(-1, 4)[:, 2], mine[k]).max()))
+    if "foldprobe" in ref.files and ref["foldprobe"].shape == (9,):
+        rep["rigid_fold"] = fold_verdict(O, ref)
     if seen_un:
         rep["unproject"] = _verdict(un)
     if seen_rr:
@@ -170,6 +207,23 @@ def compare_with_oracle(O, ref, pair):
     return rep
 
 
+_PROBE_CLI = None
+
+
+def fold_probe(row):
+    """tools/ref_dump/fold_probe.h run on one matrix row through tests/cpp/fold_probe_cli.cpp: (x, y, z, lo, hi) or None"""
+    global _PROBE_CLI
+    import subprocess
+    import tempfile
+    if _PROBE_CLI is None:
+        exe = os.path.join(tempfile.mkdtemp(prefix="uwt_probe_"), "fold_probe_cli")
+        subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-Wall", "-Werror", "-I", os.path.join(ROOT, "tools", "ref_dump"),
+                               os.path.join(ROOT, "tests", "cpp", "fold_probe_cli.cpp"), "-o", exe])
+        _PROBE_CLI = exe
+    t = subprocess.run([_PROBE_CLI] + [float(v).hex() for v in np.asarray(row, np.float32)], capture_output=True, text=True, check=True).stdout.split()
+    return np.array([float.fromhex(v) for v in t[1:]], np.float32) if int(t[0]) else None
+
+
 def fabricate_dump(O, pair, name, out_dir):
     """The oracle's own results written in the reference-side formats (ref_dump_hooks.h records + raw stage files)."""
     h, w = pair["ref"].shape
@@ -197,6 +251,10 @@ def fabricate_dump(O, pair, name, out_dir):
     hx = lambda v: " ".join(float(x).hex() for x in np.asarray(v, np.float32).ravel())
     with open(os.path.join(out_dir, "dump.txt"), "a") as f:
         f.write("case %s\ntestpose %s\n" % (name, hx(testpose)))
+        fp = fold_probe(O.se3_matrix(testpose).reshape(4, 4)[2, :3])
+        if fp is not None:   # what the driver writes: the probe built for the matrix, and the (here: the oracle's) warped z
+            z = O.warp(np.array([[fp[0], fp[1], fp[2], 0.0]], np.float32), testpose, unit_level(O))[0][2]
+            f.write("foldprobe row %s pt %s lo %s hi %s out %s\n" % (hx(O.se3_matrix(testpose).reshape(4, 4)[2, :3]), hx(fp[:3]), hx(fp[3:4]), hx(fp[4:5]), hx([z])))
         for t in tr:
             f.write("eval %d %d %d %.17g %s\n" % (t["level"], t["iter"], t["n_valid"], float(t["sum_r2"]), hx([t["error"]])))
             if t["exited"]:
@@ -297,12 +355,34 @@ def test_dump_loader_and_comparison_on_a_fabricated_dump(tmp_path, O, arith):
         ar = rep["arithmetic"]
         assert ar["unproject"] in (arith, "both") and ar["rigid_row"] == arith and ar["delta"] in (arith, "both"), ar
         assert ar["delta_unfolded_vs_inverse_then_product_ulps"] == 0, ar
+        # (the legacy set has no partial sums: its f32 FMA chain lands on the probe's upper value)
+        assert ar["rigid_fold"] == ("published" if arith == "opencv" else "left_to_right"), ar
     # a perturbed record is caught: one more valid point in one evaluation
     bad = dict(np.load(gold / "ref_pair_160x96_ref5.npz"))
     bad["n_valid"] = bad["n_valid"].copy(); bad["n_valid"][1] += 1
     np.savez(tmp_path / "bad.npz", **bad)
     with pytest.raises(AssertionError):
         compare_with_oracle(O, np.load(tmp_path / "bad.npz"), np.load(os.path.join(GOLDEN, "pair_160x96_ref5.npz")))
+
+
+@pytest.mark.one_arith
+def test_fold_probe_separates_the_two_folds(O):
+    """fold_probe.h builds, for the rigid matrix of a generic pose, a point whose warped z is `lo` under the published fold and
+    `hi` = the next float under the left-to-right one — checked here against the oracle for a few poses."""
+    rng = np.random.default_rng(5)
+    for i in range(4):
+        xi = np.array([0.01, -0.02, 0.015, 0.004, -0.003, 0.002], np.float32) if i == 0 else rng.normal(0, 0.05, 6).astype(np.float32)
+        pose = O.se3_exp(xi)
+        fp = fold_probe(O.se3_matrix(pose).reshape(4, 4)[2, :3])
+        assert fp is not None
+        assert fp[4] == np.nextafter(fp[3], np.float32(4))
+        pts = np.array([[fp[0], fp[1], fp[2], 0.0]], np.float32)
+        for fold, want in ((0, fp[3]), (1, fp[4])):
+            prev = O.set_gemm_fold(fold)
+            try:
+                assert O.warp(pts, pose, unit_level(O))[0][2] == want
+            finally:
+                O.set_gemm_fold(prev)
 
 
 REF_FILES = sorted(glob.glob(os.path.join(GOLDEN, "ref_*.npz")))

@@ -6,7 +6,7 @@ tests/test_ref_vectors.py consumes (it skips while none exists).
 
 Per case: the per-evaluation records of Tracker::EstimatePose (level, iter, n_valid, sum_r2, error, exited, and — where the
 evaluation was followed by an update — A, b, delta, pose, and delta_unfolded = the same solve through two statements), the
-final pose, the test pose WarpFunction was called with, and the stage arrays per level (img, tgt, dep, gx, gy, pts, warp,
+final pose, the test pose WarpFunction was called with, the fold probe (foldprobe = r20 r21 r22 x y z lo hi out), and the stage arrays per level (img, tgt, dep, gx, gy, pts, warp,
 unpx / unpy = WarpFunction at the two axis permutations, whose column 2 is the unprojected X * z / Y * z).
 """
 import glob
@@ -32,10 +32,13 @@ def parse_dump(path):
             if not t:
                 continue
             if t[0] == "case":
-                cur = dict(rows=[], final=None, testpose=None)
+                cur = dict(rows=[], final=None, testpose=None, foldprobe=None)
                 cases[t[1]] = cur
             elif t[0] == "testpose":
                 cur["testpose"] = hexf(t[1:8])
+            elif t[0] == "foldprobe":
+                assert t[1] == "row" and t[5] == "pt" and t[9] == "lo" and t[11] == "hi" and t[13] == "out", line[:80]
+                cur["foldprobe"] = hexf(t[2:5] + t[6:9] + [t[10], t[12], t[14]])   # r20 r21 r22 x y z lo hi out
             elif t[0] == "eval":
                 cur["rows"].append(dict(level=int(t[1]), iter=int(t[2]), n_valid=int(t[3]), sum_r2=int(round(float(t[4]))),
                                         error=hexf(t[5:6])[0], exited=0, A=np.zeros(36, np.float32), b=np.zeros(6, np.float32),
@@ -63,6 +66,7 @@ def parse_dump(path):
         d["A"] = d["A"].reshape(-1, 6, 6) if rows else d["A"]
         d["final"] = c["final"]
         d["testpose"] = c["testpose"]
+        d["foldprobe"] = c["foldprobe"]
         out[name] = d
     return out
 

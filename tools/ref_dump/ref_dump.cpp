@@ -13,6 +13,9 @@
 //   matrix is exactly 0 or 1, so whatever cv::gemm accumulates in, column 2 of the result IS the unprojected X * z (resp.
 //   Y * z) of Tracker.cpp:1439-1444, bit for bit: the quantity that tells the folded scaled convert x * invfx + beta from
 //   (x - cx) * invfx                                                              -> <case>_unpx<l>.f32, <case>_unpy<l>.f32
+//   Tracker::WarpFunction on ONE constructed point (fold_probe.h) through a second Tracker with fx = fy = 1, cx = cy = 0: its
+//   warped z says how this build's gemm folds the four partial sums of the rigid product ("s0 += s1 + s2 + s3" against a
+//   left-to-right sum) — one value in 10^9 differs, so the dense tables above cannot tell     -> dump.txt record `foldprobe`
 //   Tracker::EstimatePose                        (src/Tracker.cpp:362-597)     -> dump.txt records (ref_dump_hooks.h) written
 //                                                                                 by the instrumented Tracker_refdump.cpp
 // Usage:  ref_dump <inputs_dir> <out_dir>
@@ -23,6 +26,7 @@
 
 #include "System.h"           // the reference's: uw::Frame (include/System.h:63-103), PYRAMID_LEVELS
 #include "Tracker.h"          // the reference's: uw::Tracker (include/Tracker.h:97-235)
+#include "fold_probe.h"
 #include "ref_dump_hooks.h"
 
 using namespace uw;
@@ -90,6 +94,19 @@ int main(int argc, char** argv) {
     }
     uw_ref_dump::begin_case(name.c_str());
     uw_ref_dump::pose_line("testpose", test_pose);
+    {  // the fold probe: built from the matrix WarpFunction itself will see (SE3::matrix(), src/Tracker.cpp:1423)
+      const Mat44f Tm = test_pose.matrix();
+      const uw_ref_dump::FoldProbe fp = uw_ref_dump::find_fold_probe(Tm(2, 0), Tm(2, 1), Tm(2, 2));
+      if (fp.found) {
+        Tracker* unit = new Tracker(false);
+        cv::Mat K1 = (cv::Mat_<float>(3, 3) << 1, 0, 0, 0, 1, 0, 0, 0, 1);
+        unit->InitializePyramid(64, 64, K1);
+        cv::Mat P = (cv::Mat_<float>(1, 4) << fp.x, fp.y, fp.z, 0.f);
+        const cv::Mat Wp = unit->WarpFunction(P, test_pose, 0);
+        uw_ref_dump::fold_probe_line(Tm(2, 0), Tm(2, 1), Tm(2, 2), fp, Wp.at<float>(0, 2));
+        delete unit;
+      }
+    }
     tracker->EstimatePose(prev, cur);                                              // src/System.cpp:214-223
     delete tracker;
   }

@@ -10,6 +10,10 @@
 //   solve2 delta <6>                                      the same A and b through TWO statements, "Mat Ai = A.inv(); Mat d = Ai * b;"
 //                                                         — the inverse is formed and multiplied, the MatExpr algebra cannot fold it
 //                                                         into cv::solve: next to `solve` it shows which of the two the build runs
+//   foldprobe row <r20 r21 r22> pt <x y z> lo <f> hi <f> out <f>   (written by the driver, once per case) row 2 of the test pose's
+//                                                         rigid matrix as the build computed it, the point fold_probe.h built for
+//                                                         it, and WarpFunction's z for that point: `lo` = "s0 += s1 + s2 + s3",
+//                                                         `hi` = a left-to-right sum of the four partial sums
 //   pose <qx qy qz qw tx ty tz>                           :574, after the update
 //   final <qx qy qz qw tx ty tz>                          :595, previous_frame->rigid_transformation_
 #pragma once
@@ -42,6 +46,12 @@ inline void solve(const cv::Mat& A, const cv::Mat& b, const cv::Mat& delta) {
   cv::Mat d2 = Ai * b;         // (a plain gemm)
   std::fprintf(out(), "solve2 delta"); floats(d2);
   std::fprintf(out(), "\n");
+}
+template <typename ProbeT>
+inline void fold_probe_line(float r0, float r1, float r2, const ProbeT& fp, float out_z) {
+  if (!out()) return;
+  std::fprintf(out(), "foldprobe row %a %a %a pt %a %a %a lo %a hi %a out %a\n", (double)r0, (double)r1, (double)r2, (double)fp.x,
+               (double)fp.y, (double)fp.z, (double)fp.lo, (double)fp.hi, (double)out_z);
 }
 template <typename SE3T>
 inline void pose_line(const char* tag, const SE3T& T) {
