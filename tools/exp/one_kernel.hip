@@ -12,3 +12,8 @@ template __global__ void k_residual<kArithOpenCV, 4, true, true, false, double, 
 template __global__ void k_coarse<kArithOpenCV, true, true, double, true, 14, 1>(const CoarseArgs);
 #endif
 }
+#ifdef ONE_KERNEL_W4
+namespace uwt {
+template __global__ void k_coarse_w4<kArithOpenCV, true, true, double, true, 14, 1>(const CoarseArgs);
+}
+#endif

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Instruction histogram of one kernel's main loop in uw-slam_amd/csrc/uwt_capi.gfx950.s (`make -C uw-slam_amd/csrc asm`).
-usage: isa_hist.py <mangled-name-substring> [--loop]   (--loop: only the largest backward-branch loop body)"""
+usage: isa_hist.py <mangled-name-substring> [--loop | --f64loop]   (--loop: only the largest backward-branch loop body; --f64loop: the innermost loop with the f64 sums)"""
 import collections
 import re
 import sys
@@ -12,14 +12,18 @@ lines = open(path).read().splitlines()
 start = next(i for i, l in enumerate(lines) if l.startswith("_ZN3uwt") and ":" in l and key in l.split(":")[0])
 end = next(i for i in range(start, len(lines)) if lines[i].strip().startswith("s_endpgm"))
 body = lines[start:end + 1]
-if "--loop" in sys.argv:
+if "--loop" in sys.argv or "--f64loop" in sys.argv:
     labels = {re.match(r"^(\.LBB\d+_\d+):", l).group(1): i for i, l in enumerate(body) if re.match(r"^\.LBB\d+_\d+:", l)}
     best = None
     for i, l in enumerate(body):
-        m = re.match(r"\s+s_cbranch_\w+ (\.LBB\d+_\d+)", l)
+        m = re.match(r"\s+s_c?branch\w* (\.LBB\d+_\d+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             span = (labels[m.group(1)], i)
-            if best is None or span[1] - span[0] > best[1] - best[0]:
+            if "--f64loop" in sys.argv:   # the innermost loop that holds the f64 sums (kernels with other large loops around)
+                n = sum("v_fmac_f64" in x for x in body[span[0]:span[1]])
+                if n >= 100 and (best is None or span[1] - span[0] < best[1] - best[0]):
+                    best = span
+            elif best is None or span[1] - span[0] > best[1] - best[0]:
                 best = span
     body = body[best[0]:best[1] + 1]
     print("loop: %d lines" % len(body))

@@ -721,8 +721,13 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         if (st) return st;
       }
       UWT_WITH_ARITH(c,
+#ifdef UWT_EXP_NO_W4
         if (p.has_depth) hipLaunchKernelGGL((k_coarse<AR, true, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
         else hipLaunchKernelGGL((k_coarse<AR, false, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca));
+#else
+        if (p.has_depth) hipLaunchKernelGGL((k_coarse_w4<AR, true, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
+        else hipLaunchKernelGGL((k_coarse_w4<AR, false, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca));
+#endif
       HIPCHK(c, hipGetLastError());
       if (c->profiling) {   // (fixed schedules only: the level runs max_iters evaluations; the launch stands for that many)
         HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], s));

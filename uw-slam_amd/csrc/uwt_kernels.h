@@ -974,7 +974,7 @@ __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict_
   AccT(*red)[kBlock] = reinterpret_cast<AccT(*)[kBlock]>(lds);
   double(*cnt2)[kBlock] = reinterpret_cast<double(*)[kBlock]>(lds + kPass * kBlock * 8);
   double(*seg_f)[8] = reinterpret_cast<double(*)[8]>(lds + kPass * kBlock * 8 + 2 * kBlock * 8);
-  const int tid = threadIdx.x;
+  const int tid = (int)thread_here();   // (opaque: see thread_here)
   const int v = tid >> 3, seg = tid & 7;
   EXP_STAMP(11);
   cnt2[0][tid] = (double)n_valid;
@@ -2216,7 +2216,7 @@ __device__ __forceinline__ void tail_update_wave(const ResidualArgs& a, int pair
 
 __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const uint32_t* __restrict__ recs, const PairState* __restrict__ st_in,
                                                     unsigned char* __restrict__ lds, bool count_active) {
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = (int)thread_here(), lane = tid & 63;   // (opaque: see thread_here)
   double(*part_f)[32] = reinterpret_cast<double(*)[32]>(lds);                              // [8][32] part sums, f64 reading
   long long(*part_i)[32] = reinterpret_cast<long long(*)[32]>(lds + 8 * 32 * 8);            // [8][32] part sums, integer reading
   double* sums = reinterpret_cast<double*>(lds + 2 * 8 * 32 * 8);                           // [kAccFloats + 1]
@@ -2418,6 +2418,17 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca);
 
 template <int AR, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS = kIteratePass, int NLEV = kCoarseMaxLevels>
 __global__ UWT_RESIDUAL_BOUNDS void k_coarse(const CoarseArgs ca) {
+  coarse_body<AR, DEPTH, UNIT_FACTORS, AccT, SQUARE, PASS, NLEV>(ca);
+}
+// The batch form (one block per pair of a whole batch, PASS 14, one level per launch) held to four waves per SIMD: all blocks
+// of a 1024-pair batch are resident at once, and while one block's wave 0 runs its update the other three blocks of the CU
+// evaluate.  Two things made that possible (round 4; before, the kernel took ~210 registers and spilled inside the loop when
+// capped): the library is built without machine-level loop-invariant code motion (the f64 sine / cosine polynomials of the
+// update had their ~40 constant registers hoisted above the iteration loop, live through the residual loop), and the thread
+// index behind the update's and the reduction's lane roles is opaque (thread_here).  What remains above 128 is parked in
+// scratch outside the residual loop (40 bytes per lane).
+template <int AR, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS = 14, int NLEV = 1>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_coarse_w4(const CoarseArgs ca) {
   coarse_body<AR, DEPTH, UNIT_FACTORS, AccT, SQUARE, PASS, NLEV>(ca);
 }
 template <int AR, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS, int NLEV>

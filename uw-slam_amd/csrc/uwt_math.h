@@ -147,6 +147,16 @@ __device__ inline void se3_exp(const float xi[6], Pose& out) {
   se3_exp_with(xi, theta_sq, theta, sh, ch, st, ct, out);
 }
 
+// threadIdx.x behind an opaque statement.  Whatever is derived from it (lane roles, LDS addresses of the reduction and of the
+// update) is then computed where it is used: read plainly, the compiler hoists those values out of a loop that encloses an
+// evaluation and its update (k_coarse), where they stay live through the residual loop — two dozen registers of the kernel's
+// budget for a few shifts per evaluation.
+__device__ __forceinline__ unsigned thread_here() {
+  unsigned t = threadIdx.x;
+  asm volatile("" : "+v"(t));
+  return t;
+}
+
 // The same on a full wave holding uniform values (the update's tail): the four transcendentals — the longest dependent
 // stretch of the tail — are taken in one pass, lane 0 on theta / 2 and lane 1 on theta, each by the sin and the cos of its
 // own argument, instead of four evaluations one after the other.  Same functions, same results.
@@ -154,7 +164,7 @@ __device__ inline void se3_exp_wave(const float xi[6], Pose& out) {
   const float theta_sq = xi[3] * xi[3] + xi[4] * xi[4] + xi[5] * xi[5];
   const float theta = sqrtf(theta_sq);
   const float half_theta = 0.5f * theta;
-  const int lane = (int)(threadIdx.x & 63u);
+  const int lane = (int)(thread_here() & 63u);
   const float arg = (lane & 1) ? theta : half_theta;
   const float s = sin_r(arg), c = cos_r(arg);
   const float sh = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(s), 0));
@@ -345,7 +355,7 @@ __device__ __forceinline__ float lane_f(float v, int lane) {
 
 // sums: the 21 upper-triangle entries of A in row-major order (as accumulated); returns false when singular (delta = 0)
 __device__ inline bool solve_delta_wave(const double* sums, const float b[6], float delta[6], bool legacy) {
-  const int lane = (int)(threadIdx.x & 63u);
+  const int lane = (int)(thread_here() & 63u);
   const int c = lane < 12 ? lane : 11;  // lanes >= 12 shadow lane 11
   float col[6];
 #pragma unroll
