@@ -17,3 +17,10 @@ namespace uwt {
 template __global__ void k_coarse_w4<kArithOpenCV, true, true, double, true, 14, 1>(const CoarseArgs);
 }
 #endif
+#ifdef ONE_KERNEL_RW4
+namespace uwt {
+template __global__ void k_residual_w4<kArithOpenCV, 4, true, true, false, double, true, 1, 2>(const ResidualArgs);
+template __global__ void k_residual_w4<kArithLegacy, 4, true, true, false, double, true, 1, 2>(const ResidualArgs);
+template __global__ void k_residual<kArithLegacy, 4, true, true, false, double, true, 1, 2>(const ResidualArgs);
+}
+#endif

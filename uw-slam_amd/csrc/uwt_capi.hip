@@ -369,7 +369,10 @@ void launch_general_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sam
         case 1: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 1>), grid, blk, 0, s, a); break;
         case 2: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 2>), grid, blk, 0, s, a); break;
         case 3: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 1, 0>), grid, blk, 0, s, a); break;
-        default: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 1, 2>), grid, blk, 0, s, a); break;
+        default:   // bilinear + Huber: 129 registers under the OpenCV set, held to 128 (one value parked in scratch outside the loop)
+          if constexpr (AR == kArithOpenCV) hipLaunchKernelGGL((k_residual_w4<AR, VEC, DEPTH, UNIT, false, double, true, 1, 2>), grid, blk, 0, s, a);
+          else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 1, 2>), grid, blk, 0, s, a);
+          break;
       }
       return;
     }

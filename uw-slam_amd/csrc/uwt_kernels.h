@@ -788,6 +788,27 @@ __device__ __forceinline__ void jacobian_row_f64(F g0, F g1, F j0, F j1, const F
   }
 }
 
+// The same row as the six floats the reference holds (pixel_jacobian's kArithOpenCV arithmetic for pixel c of a unit): what a
+// caller that still has to weight the row needs (w * J[k] is an f32 product of the stored float).
+template <bool SQUARE, typename F>
+__device__ __forceinline__ void jacobian_row_f32(F g0, F g1, F j0, F j1, const F av[4], const F bv[4], int c, float J[6]) {
+  const double g0d = (double)get(g0, c), g1d = (double)get(g1, c);
+  J[0] = get(j0, c);
+  J[1] = get(j1, c);
+  double b4d = 0.0;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    constexpr int order[4] = {0, 2, 1, 3};   // as jacobian_row_f64
+    const int k = order[i];
+    const double bd = (double)get(bv[k], c);
+    if (k == 2) b4d = bd;
+    const double ad = (SQUARE && k == 1) ? -b4d : (double)get(av[k], c);
+    double p = g0d * ad;
+    p = __builtin_fma(g1d, bd, p);
+    J[2 + k] = (float)p;
+  }
+}
+
 // Accumulator type: double reproduces the reference's double-accumulating gemm (src/Tracker.cpp:560-561) to the
 // last bit of the f32 result in practice (products of two f32 are exact in f64); float is the cheaper variant.
 __device__ __forceinline__ void accumulate(float acc[kAccFloats], const float J[6], int ri) {
@@ -1502,6 +1523,51 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 #endif
         }
       }
+    } else if constexpr (MASKED && GENERAL && !TABLE) {
+      // float residuals (bilinear sampler) and / or weights evaluated per pixel: the same one-unit-at-a-time form —
+      // a pixel's row is formed, weighted and added before the next one's is begun, so that no f32 rows of all four pixels sit
+      // beside the doubles of the small products (the instantiation with the most live values: bilinear + Huber)
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+        if constexpr (SAMPLER != 0) {
+          // every sample finished here, ahead of the Jacobian terms: four floats stay,
+          // not the sixteen bytes and eight fractions of interpolations the scheduler would otherwise leave pending into the sums
+          if (u == 0) {
+#pragma unroll
+            for (int j = 0; j < VEC; j++) asm volatile("" : "+v"(s2[j]));
+          }
+        }
+        F a0, b1, av[4], bv[4], j0, j1, Ju[6];
+        if constexpr (AR == kArithOpenCV) {
+          jw_terms<UNIT_FACTORS, SQUARE, F>(L, a.zf, a.af, x2[u], y2[u], iz[u], a0, b1, av, bv);
+          j0 = g0[u] * a0;
+          j1 = g1[u] * b1;
+        } else {
+          pixel_jacobian<AR, UNIT_FACTORS, SQUARE, false, F>(L, a.zf, a.af, x2[u], y2[u], iz[u], g0[u], g1[u], Ju);
+        }
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+          const int j = u * N + c;
+          float Jp[6];
+          if constexpr (AR == kArithOpenCV) jacobian_row_f32<SQUARE, F>(g0[u], g1[u], j0, j1, av, bv, c, Jp);
+          else {
+#pragma unroll
+            for (int k = 0; k < 6; k++) Jp[k] = get(Ju[k], c);
+          }
+          float rf;
+          if constexpr (SAMPLER == 0) rf = (float)(i2[j] - (int)i1[j]);
+          else rf = s2[j] - (float)i1[j];
+          const float w = robust_weight<true>(WEIGHTS, rf, inv_mad);
+          double Jd[6];
+#pragma unroll
+          for (int k = 0; k < 6; k++) Jd[k] = (double)(w * Jp[k]);
+          const double e = (double)rf * (double)(rf * w);
+          masked_sums_lo(acc, Jd, okm[j]);
+          masked_sums_hi<1>(acc, err, Jd, (double)((rf * a.gain) * w), e, okm[j]);
+          n_valid_wave += (uint32_t)__builtin_popcountll(okm[j]);  // scalar
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     } else {
     // phase 3: Jacobians (cover the gather latency)
     F J[NU][6];
@@ -1658,6 +1724,17 @@ __global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
   const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, (int)blockIdx.x);
   if constexpr (!COMPUTE_ONLY && !DUMP) {
     if (a.tail.on && live && threadIdx.x < 64) tail_update_wave(a, pair);   // wave 0 wrote the block's record
+  }
+}
+
+// The same kernel held to four waves per SIMD (128 registers), for the one instantiation whose allocation lands just above
+// (bilinear sampler + Huber: 129 — the 129th register holds scalar registers the compiler parks across the loop).
+template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_residual_w4(const ResidualArgs a) {
+  const int pair = (int)blockIdx.y + a.pair_base;
+  const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, false>(a, pair, (int)blockIdx.x);
+  if constexpr (!DUMP) {
+    if (a.tail.on && live && threadIdx.x < 64) tail_update_wave(a, pair);
   }
 }
 
