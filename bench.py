@@ -43,23 +43,23 @@ ALG_BYTES_PER_PIXEL_ITER = 10          # I_ref 1 + gx 2 + gy 2
 HBM_PEAK_GBS = 8000.0                  # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_COPY_GBS = 6290.0                  # MI355X_MICROARCH.md §Chip-level parameters: measured copy ceiling
 # Facts about the dominant kernel that cannot be measured from inside this process (counter passes, compiler resource usage),
-# per arithmetic set, each naming its source file, stamped with the sha256 of the libuwt_hip.so they were collected on
-# (tools/make_profile_facts.py).  They are quoted only while the library this process loaded is that library.
+# per arithmetic set, each naming its source file, stamped with the source id (uwt_source_id(): sha256 of sources + flags) of the
+# libuwt_hip.so they were collected on (tools/make_profile_facts.py).  They are quoted only while the library this process
+# loaded reports that id — hipcc's output is not byte-reproducible, so the binary's own hash would not survive a rebuild.
 PROFILE_FACTS = os.path.join(ROOT, "profiles", "r04", "k_residual_facts.json")
 
 
 def _quoted_facts(capi, arith):
-    """(facts of this arithmetic set or {}, note).  Empty when the loaded library is not the one the facts were collected on."""
-    import hashlib
+    """(facts of this arithmetic set or {}, note).  Empty when the loaded library is not built from the sources the facts were collected on."""
     if not os.path.exists(PROFILE_FACTS):
         return {}, "no %s" % os.path.relpath(PROFILE_FACTS, ROOT)
     allf = json.load(open(PROFILE_FACTS))
-    sha = hashlib.sha256(open(capi.LIB_PATH, "rb").read()).hexdigest()
-    if allf.get("library_sha256") != sha:
-        return {}, ("quoted counter / resource facts withheld: %s was collected on libuwt_hip.so sha256 %s..., this run loaded %s... "
-                    "(re-run tools/collect_profiles.sh + tools/publish_profiles.sh)"
-                    % (os.path.relpath(PROFILE_FACTS, ROOT), str(allf.get("library_sha256"))[:12], sha[:12]))
-    return dict(allf.get("sets", {}).get(arith, {})), "facts collected on this library (sha256 %s...)" % sha[:12]
+    sid = capi.source_id()
+    if allf.get("library_source_id") != sid:
+        return {}, ("quoted counter / resource facts withheld: %s was collected on a libuwt_hip.so built from sources %s..., this run "
+                    "loaded one built from %s... (re-run tools/collect_profiles.sh + tools/publish_profiles.sh)"
+                    % (os.path.relpath(PROFILE_FACTS, ROOT), str(allf.get("library_source_id"))[:12], sid[:12]))
+    return dict(allf.get("sets", {}).get(arith, {})), "facts collected on a library built from these sources (uwt_source_id %s...)" % sid[:12]
 
 
 def parse_args(argv=None):

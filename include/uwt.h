@@ -122,6 +122,10 @@ int uwt_level_info(const uwt_ctx* ctx, int32_t lvl, uwt_level* out);
 const char* uwt_status_string(int status);
 const char* uwt_last_error(const uwt_ctx* ctx);
 int uwt_abi_version(void);
+/* sha256 (hex) of the sources and compiler flags this library was built from (csrc/Makefile puts it in at build time; hipcc's
+ * output is not byte-reproducible, the sources are).  No reference counterpart: measurement hygiene — bench.py quotes the
+ * counter-derived facts under profiles/ only while the loaded library reports the id they were collected on. */
+const char* uwt_source_id(void);
 
 /* ---- frames (the Frame data the tracker borrows: images_, depths_, gradientX_, gradientY_; include/System.h:85-89) */
 

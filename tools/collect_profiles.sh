@@ -46,7 +46,7 @@ bash tools/exp/r3_sq.sh ${1:-prof_r04}/sq_huber k_resid_hist_v --pairs 256 --uni
 python3 tools/sq_summary.py $out/sq_huber k_resid_hist_v $((256*640*480)) $out/sq_counters_k_resid_hist_v_level0_p256_huber.csv
 python3 tools/sq_summary.py $out/sq_huber "k_residual<" $((256*640*480)) $out/sq_counters_k_residual_weighted_level0_p256_huber.csv
 python3 tools/per_level_table.py $(find $out/stats_default_p1024 -name "*kernel_trace.csv" | head -1) > $out/per_level_launch_table_trace.md 2>/dev/null
-sha256sum uw-slam_amd/libuwt_hip.so > $out/library_sha256.txt
+python3 -c "import ctypes; h = ctypes.CDLL('uw-slam_amd/libuwt_hip.so'); h.uwt_source_id.restype = ctypes.c_char_p; print(h.uwt_source_id().decode())" > $out/library_source_id.txt
 # keep what travels back small: the statistics tables, not the raw traces
 find $out -name "*kernel_trace.csv" -size +20M -delete
 find $out -name "*counter_collection.csv" -size +20M -delete

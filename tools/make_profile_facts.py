@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """profiles/<round>/k_residual_facts.json from the round's counter summaries and the compiler's resource table: the facts about
-the dominant kernel that bench.py quotes with their source, per arithmetic set (opencv / legacy), stamped with the sha256 of
-the libuwt_hip.so they were collected on — bench.py quotes them only while it has loaded that very library.
+the dominant kernel that bench.py quotes with their source, per arithmetic set (opencv / legacy), stamped with the source id
+(uwt_source_id(): sha256 of sources + flags) of the libuwt_hip.so they were collected on — bench.py quotes them only while the
+library it loaded reports the same id (the binary itself is not byte-reproducible).
 
   HBM bytes per pixel-iteration   pmc_fetch_<set>_bench_default_p1024.csv + pmc_write_… (2 x FETCH_SIZE + WRITE_SIZE, KiB)
   instruction mix                 sq_counters_k_residual_<set>_level0_p1024.csv (SQ_INSTS_VALU, SQ_INSTS_VALU_FMA_F64 per pixel)
@@ -66,7 +67,10 @@ def set_facts(d, name):
 
 
 def main(d, lib):
-    out = {"library_sha256": hashlib.sha256(open(lib, "rb").read()).hexdigest(),
+    import ctypes
+    h = ctypes.CDLL(lib)
+    h.uwt_source_id.restype = ctypes.c_char_p
+    out = {"library_source_id": h.uwt_source_id().decode(),   # sha256 of the sources + flags the library was built from
            "library": os.path.relpath(lib, ROOT),
            "sets": {name: set_facts(d, name) for name in ("opencv", "legacy")}}
     json.dump(out, open(os.path.join(d, "k_residual_facts.json"), "w"), indent=1)

@@ -1,13 +1,14 @@
 #!/bin/bash
 # copy the summaries of a tools/collect_profiles.sh run into profiles/<round>/ under the names the README there lists
 #   tools/publish_profiles.sh <gpurun_out subdir> <round dir, e.g. r04>
-# Refuses when the library in the tree is not the one the counters were collected on (the facts are stamped with its hash).
+# Refuses when the library in the tree is not the one the counters were collected on (the facts are stamped with its source id).
 set -e
 src=gpurun_out/$1; dst=profiles/$2
 mkdir -p $dst
-if [ -f $src/library_sha256.txt ]; then
-  want=$(cut -d' ' -f1 $src/library_sha256.txt); have=$(sha256sum uw-slam_amd/libuwt_hip.so | cut -d' ' -f1)
-  if [ "$want" != "$have" ]; then echo "library changed since the collection ($want vs $have): collect again" >&2; exit 1; fi
+if [ -f $src/library_source_id.txt ]; then
+  want=$(cat $src/library_source_id.txt)
+  have=$(python3 -c "import ctypes; h = ctypes.CDLL('uw-slam_amd/libuwt_hip.so'); h.uwt_source_id.restype = ctypes.c_char_p; print(h.uwt_source_id().decode())")
+  if [ "$want" != "$have" ]; then echo "library sources changed since the collection ($want vs $have): collect again" >&2; exit 1; fi
 fi
 for d in $src/stats_*; do
   n=$(basename $d | sed 's/^stats_//')

@@ -45,7 +45,7 @@ class Accum(C.Structure):
 
 # every symbol include/uwt.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "uwt_abi_version", "uwt_status_string", "uwt_last_error", "uwt_default_params", "uwt_create", "uwt_destroy",
+    "uwt_abi_version", "uwt_source_id", "uwt_status_string", "uwt_last_error", "uwt_default_params", "uwt_create", "uwt_destroy",
     "uwt_level_info", "uwt_set_frame", "uwt_upload_frames", "uwt_upload_frames_async", "uwt_host_alloc", "uwt_host_free", "uwt_plane_device_ptr", "uwt_get_plane",
     "uwt_build_pyramids", "uwt_apply_gradient", "uwt_estimate_pose_batch", "uwt_track_batch_async", "uwt_track_batch_host_async", "uwt_wait_ticket", "uwt_sync", "uwt_set_deferred",
     "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_profile_read_levels", "uwt_profile_clock", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
@@ -92,8 +92,15 @@ def lib():
         _lib = C.CDLL(LIB_PATH)
         _lib.uwt_status_string.restype = C.c_char_p
         _lib.uwt_last_error.restype = C.c_char_p
+        _lib.uwt_source_id.restype = C.c_char_p
+        _lib.uwt_source_id.argtypes = []
         _lib.uwt_last_error.argtypes = [C.c_void_p]
     return _lib
+
+
+def source_id():
+    """uwt_source_id(): sha256 of the sources and flags the loaded library was built from"""
+    return lib().uwt_source_id().decode()
 
 
 def _p(a, t):
