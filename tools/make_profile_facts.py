@@ -36,9 +36,10 @@ def set_facts(d, name):
         # KiB per dispatch, weighted by dispatch count = bytes of all residual launches of the run
         kib = sum(2.0 * m * n for _, m, n in fetch) + sum(m * n for _, m, n in write)   # x2: gfx950 FETCH_SIZE correction
         launches = sum(n for _, _, n in fetch)
-        # the coarsest level of a batch runs in k_coarse; k_residual launches cover levels 0..2, all at one grid size
-        grids = sorted({g for g, _, _ in fetch})
-        n_lv = 4 if len(grids) > 1 else 3
+        # the coarsest level of a batch runs in k_coarse when that kernel appears in the trace: k_residual launches then cover
+        # levels 0..2 (an equal number of launches each, whatever their grid sizes), else 0..3
+        coarse = any("k_coarse" in r["kernel"] for r in csv.DictReader(open(f_fetch)))
+        n_lv = 3 if coarse else 4
         pixels = 1024 * sum((640 >> l) * (480 >> l) for l in range(n_lv)) * launches / float(n_lv)
         facts["hbm_bytes_per_pixel_iteration"] = round(kib * 1024.0 / pixels, 3)
         facts["hbm_bytes_source"] = ("%s/pmc_fetch_%s_bench_default_p1024.csv + pmc_write_%s_bench_default_p1024.csv (2 x FETCH_SIZE + "
