@@ -37,8 +37,9 @@ enum uwt_plane { UWT_PLANE_IMAGE = 0, UWT_PLANE_DEPTH = 1, UWT_PLANE_GRADX = 2, 
 /* Arithmetic of the OpenCV steps on the path (the reference pins no OpenCV build; "3.2", README.md:15).
  * UWT_ARITH_OPENCV: what OpenCV 3.x's generic (non-BLAS, non-IPP) code computes for the reference's expressions —
  *   - every cv::gemm on CV_32F accumulates in double and rounds to float once (matmul.cpp GEMMSingleMul<float,double>):
- *     rigid * points.t() (src/Tracker.cpp:1450) = (float)(((T0*X + T1*Y) + T2*Z) + T3*w), Jl * Jw (:479) =
- *     (float)(g0*Jw0k + g1*Jw1k), and the N-long JtJ / Jtr / rtr sums (:501, :560-561);
+ *     rigid * points.t() (src/Tracker.cpp:1450) = (float)(T0*X + ((T1*Y + T2*Z) + T3*w)) — the A*Bt branch folds its four
+ *     partial sums with "s0 += s1 + s2 + s3;" —, Jl * Jw (:479) = (float)((0 + g0*Jw0k) + g1*Jw1k), and the N-long JtJ / Jtr /
+ *     rtr sums (:501, :560-561);
  *   - "(col - cx) * invfx" (:1439, :1443) is folded by the MatExpr algebra (matop.cpp MatOp_AddEx::multiply) into one scaled
  *     convert: x * invfx + (float)(-(double)cx * invfx);
  *   - "A.inv() * b" (:564) is MatOp_Invert::matmul -> cv::solve(A, b, DECOMP_LU) = hal::LU32f(A, 6, b, 1): elimination on

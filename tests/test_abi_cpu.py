@@ -33,6 +33,23 @@ def test_library_exports_every_declared_symbol(capi):
     assert lib.uwt_abi_version() == 2   # 2: uwt_params::arith
 
 
+def test_source_id_is_the_hash_of_sources_and_flags(capi):
+    """uwt_source_id(): what bench.py compares with the id stamped on profiles/rNN/k_residual_facts.json.  The Makefile hashes
+    the four source files followed by its flags line; recomputed here from the same inputs."""
+    import hashlib
+    import subprocess
+    sid = capi.source_id()
+    assert re.fullmatch(r"[0-9a-f]{64}", sid), sid
+    csrc = os.path.join(ROOT, "uw-slam_amd", "csrc")
+    flags = subprocess.run(["make", "-s", "-C", csrc, "--eval", "print-flags: ; @echo '$(CXXFLAGS)'", "print-flags"],
+                           capture_output=True, text=True, check=True).stdout
+    h = hashlib.sha256()
+    for f in ("uwt_capi.hip", "uwt_kernels.h", "uwt_math.h", os.path.join("..", "..", "include", "uwt.h")):
+        h.update(open(os.path.join(csrc, f), "rb").read())
+    h.update(flags.encode())
+    assert h.hexdigest() == sid
+
+
 def test_struct_layouts_match_header(capi):
     import ctypes as C
     assert C.sizeof(capi.Params) == 26 * 4

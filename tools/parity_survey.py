@@ -18,7 +18,11 @@ ap.add_argument("--seed0", type=int, default=1000)
 ap.add_argument("--single", type=int, default=0, help="1: one pair per synchronous call (the chained k_iterate flow)")
 ap.add_argument("--weights", type=int, default=0, help="0 identity, 1 Tukey (reference medians), 2 Huber")
 ap.add_argument("--sampler", type=int, default=0, help="0 nearest, 1 bilinear")
+ap.add_argument("--arith", default="opencv", choices=["opencv", "legacy"], help="arithmetic set of both sides")
 a = ap.parse_args()
+ARITH = {"opencv": 0, "legacy": 1}[a.arith]
+capi.DEFAULT_ARITH = ARITH
+O.DEFAULT_ARITH = ARITH
 w, h = a.w, a.h
 f = 525.0 * w / 640.0
 intr = (f, f, w / 2 - 0.5, h / 2 - 0.5)
@@ -69,7 +73,7 @@ dr = np.array([rot_angle(poses[i][:4], cpu[i][1][:4]) for i in range(n)])
 dt = np.array([np.linalg.norm(poses[i][4:].astype(np.float64) - cpu[i][1][4:]) for i in range(n)])
 bit = sum(np.array_equal(poses[i].view(np.uint32), cpu[i][1].view(np.uint32)) for i in range(n))
 it_eq = sum(stats[i]["iterations"] == cpu[i][2] for i in range(n))
-print("mode %s%s weights=%d sampler=%d %dx%d depth=%d n=%d: bit-identical %d, iterations equal %d, status!=0 %d" % (a.mode, " (one pair per call)" if a.single else " (one batch)", a.weights, a.sampler, w, h, a.depth, n, bit, it_eq, sum(s["status"] != 0 for s in stats)))
+print("arith %s mode %s%s weights=%d sampler=%d %dx%d depth=%d n=%d: bit-identical %d, iterations equal %d, status!=0 %d" % (a.arith, a.mode, " (one pair per call)" if a.single else " (one batch)", a.weights, a.sampler, w, h, a.depth, n, bit, it_eq, sum(s["status"] != 0 for s in stats)))
 print("  rot  diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dr), np.percentile(dr, 90), dr.max(), (dr > 1e-4).sum()))
 print("  trans diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dt), np.percentile(dt, 90), dt.max(), (dt > 1e-4).sum()))
 print("  |t| median %.2e ; cpu time/pair %.3fs" % (np.median([np.linalg.norm(c[1][4:]) for c in cpu]), t_cpu / n))

@@ -1254,7 +1254,12 @@ struct RefGroup {
 template <int VEC, bool DEPTH, bool COMPUTE_ONLY = false>
 __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __restrict__ I1, const int16_t* __restrict__ GX,
                                            const int16_t* __restrict__ GY, const uint16_t* __restrict__ DP, uint32_t idx) {
-  if constexpr (COMPUTE_ONLY) {  // diagnostic instantiation: plane values made up from the index, no memory operation
+#ifdef UWT_EXP_TWIN_KEEP_PLANES
+  constexpr bool FAKE_PLANES = false;   // experiment: the twin keeps its plane loads (tools/exp/r4_twin_ab.sh)
+#else
+  constexpr bool FAKE_PLANES = COMPUTE_ONLY;
+#endif
+  if constexpr (FAKE_PLANES) {  // diagnostic instantiation: plane values made up from the index, no memory operation
 #pragma unroll
     for (int j = 0; j < VEC; j++) { r.i1[j] = (uint8_t)(idx + j); r.gx[j] = (int16_t)(idx * 3 + j); r.gy[j] = (int16_t)(idx * 5 - j); r.dp[j] = (uint16_t)(4000 + (idx & 255)); }
     return;
@@ -1356,10 +1361,12 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   const int16_t* __restrict__ GY = a.gy + ref_off;
   const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
 
-  unsigned long long clk0 = 0, rt0 = 0;
-  if (a_probe) {
-    clk0 = __builtin_amdgcn_s_memtime();
-    rt0 = __builtin_amdgcn_s_memrealtime();
+  // the probe's start stamps wait in LDS, not in four scalar registers through the loop (the kernels sit near the scalar-register
+  // limit, and what does not fit there is parked in a vector register)
+  __shared__ unsigned long long s_probe[2];
+  if (a_probe && threadIdx.x == 0) {
+    s_probe[0] = __builtin_amdgcn_s_memtime();
+    s_probe[1] = __builtin_amdgcn_s_memrealtime();
   }
   AccT acc[kAccFloats];
 #pragma unroll
@@ -1411,7 +1418,16 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   auto body = [&](RefGroup<VEC>& rg, const int ahead) __attribute__((always_inline)) {
     const bool active = g < g_end;
     const unsigned long long active_mask = __builtin_amdgcn_sicmp(g, g_end, kIcmpSLT);
-    if constexpr (TD_LDS) {
+#ifdef UWT_EXP_TWIN_NO_TD
+    constexpr bool TD_READ = TD_LDS && !COMPUTE_ONLY;   // experiment: the twin without the LDS reads of the rigid matrix
+    if constexpr (TD_LDS && COMPUTE_ONLY) {
+#pragma unroll
+      for (int i = 0; i < 12; i++) K.Td[i] = 0.5 + 0.25 * i;
+    }
+#else
+    constexpr bool TD_READ = TD_LDS;
+#endif
+    if constexpr (TD_READ) {
       unsigned off = 0;
       asm volatile("" : "+v"(off));   // an offset the compiler cannot see through: the reads stay inside the loop
       const double* tdp = reinterpret_cast<const double*>(reinterpret_cast<const unsigned char*>(s_td) + off);
@@ -1465,7 +1481,12 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     float s2[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-      if constexpr (COMPUTE_ONLY) i2[j] = (int)i1[j] + (int)(gidx[j] & 1);
+#ifdef UWT_EXP_TWIN_KEEP_GATHER
+      constexpr bool FAKE_GATHER = false;   // experiment: the twin keeps its gathers
+#else
+      constexpr bool FAKE_GATHER = COMPUTE_ONLY;
+#endif
+      if constexpr (FAKE_GATHER) i2[j] = (int)i1[j] + (int)(gidx[j] & 1);
       else if constexpr (SAMPLER == 0) i2[j] = I2[gidx[j]];   // nearest-neighbour gather of the target level (:472)
       else s2[j] = sample_bilinear(I2, L, get(x2[j / N], j % N), get(y2[j / N], j % N));  // EXTENSION; x2 = y2 = 0 for sanitised invalid pixels
     }
@@ -1705,8 +1726,8 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err, coherent);
   if (a_probe && threadIdx.x == 0) {
     uint32_t* rec = a_partials + ((size_t)pair * a_slices + slice) * kRecWords;
-    rec[60] = (uint32_t)(__builtin_amdgcn_s_memtime() - clk0);
-    rec[61] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - rt0);
+    rec[60] = (uint32_t)(__builtin_amdgcn_s_memtime() - s_probe[0]);
+    rec[61] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - s_probe[1]);
   }
 }
 
