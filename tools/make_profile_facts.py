@@ -18,8 +18,9 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PRODUCTION = {"opencv": "k_residual<0, 4, true, true, false, double, true, 0, 0, false>",
-              "legacy": "k_residual<1, 4, true, true, false, double, true, 0, 0, false>"}
+# (the last argument: the streamed twin — non-temporal plane loads — that a batch larger than the caches runs at its fine levels)
+PRODUCTION = {"opencv": "k_residual<0, 4, true, true, false, double, true, 0, 0, false, true>",
+              "legacy": "k_residual<1, 4, true, true, false, double, true, 0, 0, false, true>"}
 
 
 def per_dispatch(path, counter):

@@ -36,6 +36,7 @@ struct uwt_ctx {
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {};
   int split = 2;                        // parts a fixed-schedule batch is cut into (UWT_SPLIT; 1 = one stream)
   int split_min = 8;                    // pairs per part at least (UWT_SPLIT_MIN)
+  long long stream_bytes = 200LL << 20; // a level whose planes of the whole batch exceed this is read non-temporally (UWT_STREAM_MB)
   long long split_min_px = 32LL * 640 * 480;   // level-0 pixels of the batch at least: below, a launch is too short for a
                                         // second stream to pay (the host enqueues twice as many) (UWT_SPLIT_MIN_PX)
   hipEvent_t ev_pyramids = nullptr, ev_side_done = nullptr, ev_level[UWT_MAX_LEVELS] = {};
@@ -257,9 +258,10 @@ void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool a
       return;
     }
   }
-  if (acc64 && UNIT && VEC == 4 && !DUMP && a.L.fx == a.L.fy)
-    hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
-  else if (acc64)
+  if (acc64 && UNIT && VEC == 4 && !DUMP && a.L.fx == a.L.fy) {   // the production instantiation, and its streamed twin (load_group)
+    if (a.stream_planes) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, false, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+    else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+  } else if (acc64)
     hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
   else
     hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, float>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
@@ -365,6 +367,18 @@ void launch_general_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sam
   const int key = sampler * 3 + weights;
   if constexpr (VEC == 4 && UNIT) {
     if (a.L.fx == a.L.fy) {   // SQUARE: the Jacobian's coinciding products once (pixel_jacobian), as on the identity path
+      if (a.stream_planes) {   // the streamed twins (load_group)
+        switch (key) {
+          case 1: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 1, false, true>), grid, blk, 0, s, a); break;
+          case 2: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 2, false, true>), grid, blk, 0, s, a); break;
+          case 3: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 1, 0, false, true>), grid, blk, 0, s, a); break;
+          default:
+            if constexpr (AR == kArithOpenCV) hipLaunchKernelGGL((k_residual_w4<AR, VEC, DEPTH, UNIT, false, double, true, 1, 2, true>), grid, blk, 0, s, a);
+            else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 1, 2, false, true>), grid, blk, 0, s, a);
+            break;
+        }
+        return;
+      }
       switch (key) {
         case 1: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 1>), grid, blk, 0, s, a); break;
         case 2: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 2>), grid, blk, 0, s, a); break;
@@ -688,6 +702,12 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
     groups_per_block = gpt * kBlock;
     slices = (n_groups + groups_per_block - 1) / groups_per_block;
   };
+  // the accumulation kernels stream a level's reference planes past the caches (ResidualArgs::stream_planes) when the batch's
+  // planes of that level — u8 + 2 x i16 [+ u16] per reference pixel, the target's u8 — exceed what the 256 MB memory-side cache
+  // holds across an evaluation; a smaller batch finds them there again at the next evaluation (UWT_STREAM_MB: the threshold)
+  auto streams = [&](int lvl) -> int {
+    return (long long)n_pairs * c->lv[lvl].n * (p.has_depth ? 8 : 6) > c->stream_bytes ? 1 : 0;
+  };
   int smax = 1;
   for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
     int gpb, sl;
@@ -764,6 +784,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
       UpdateArgs ua = update_args(c, lvl);
       ra.pair_base = base;
       ua.pair_base = base;
+      ra.stream_planes = streams(lvl);
       slicing(lvl, ra.groups_per_block, ra.slices);
       ua.slices = ra.slices;
       // A pair's records sit at (pair * slices + slice): the place depends on the level's slice count, and the parts of a
@@ -882,6 +903,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
       q.ra = residual_args(c, lvl);
       q.ua = update_args(c, lvl);
       q.ra.pair_base = q.ua.pair_base = q.base;
+      q.ra.stream_planes = streams(lvl);
       slicing(lvl, q.ra.groups_per_block, q.ra.slices);
       q.ua.slices = q.ra.slices;
       // A pair's records sit at (pair * slices + slice): the place depends on the level's slice count, and the parts are at
@@ -1112,6 +1134,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   c->coarse_batch_px = kCoarseMaxPixels;   // e.g. level 3 of 640x480: +0.8 % on the default batch; larger levels lose (2 waves / SIMD)
   if (const char* e = std::getenv("UWT_COARSE_BATCH_PX")) c->coarse_batch_px = std::max(0, std::atoi(e));
   if (const char* e = std::getenv("UWT_SPLIT_MIN")) c->split_min = std::max(1, std::atoi(e));
+  if (const char* e = std::getenv("UWT_STREAM_MB")) c->stream_bytes = std::max(0LL, std::atoll(e)) << 20;
   if (const char* e = std::getenv("UWT_SPLIT_MIN_PX")) c->split_min_px = std::max(1LL, std::atoll(e));
   CREATE_CHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
   for (int i = 0; i < uwt_ctx::kDeps; i++) {

@@ -500,6 +500,7 @@ __device__ __forceinline__ void warp_setup(const Pose& pose, WarpK& K) {
 // Each component sees exactly the scalar IEEE operation (same rounding, no contraction), so results are bit-identical
 // to the one-pixel form, which the VEC = 1 fallback and the per-stage kernels still use (F = float).
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));   // (the type __builtin_nontemporal_load takes for an 8-byte load)
 
 template <typename F> struct lanes { static constexpr int n = 1; };
 template <> struct lanes<v2f> { static constexpr int n = 2; };
@@ -1230,6 +1231,7 @@ struct ResidualArgs {
   float* dumpR;
   uint8_t* dumpV;
   float* dumpW;             // per-pixel robust weights (general path only)
+  int stream_planes;        // 1: the launch takes the STREAM instantiation (load_group) where one exists: the batch's planes of this level exceed the caches
   int probe;                // 1: thread 0 of every block leaves its shader-clock / 100 MHz real-time deltas in words 60, 61
                             // of the block's record (uwt_profile_clock: the clock the chip holds under this kernel)
   TailUpdate tail;
@@ -1251,7 +1253,7 @@ struct RefGroup {
   uint16_t dp[VEC];
 };
 
-template <int VEC, bool DEPTH, bool COMPUTE_ONLY = false>
+template <int VEC, bool DEPTH, bool COMPUTE_ONLY = false, bool STREAM = false>
 __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __restrict__ I1, const int16_t* __restrict__ GX,
                                            const int16_t* __restrict__ GY, const uint16_t* __restrict__ DP, uint32_t idx) {
 #ifdef UWT_EXP_TWIN_KEEP_PLANES
@@ -1268,10 +1270,23 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
     // byte offsets in 32 bits (a level plane of one frame is < 2^31 bytes): uniform base + 32-bit lane offset addressing,
     // no 64-bit address arithmetic per load
     const uint32_t o2 = idx * 2u;
-    *reinterpret_cast<uint32_t*>(r.i1) = *reinterpret_cast<const uint32_t*>(I1 + idx);
-    *reinterpret_cast<uint2*>(r.gx) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(GX) + o2);
-    *reinterpret_cast<uint2*>(r.gy) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(GY) + o2);
-    if constexpr (DEPTH) *reinterpret_cast<uint2*>(r.dp) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(DP) + o2);
+    // STREAM: a batch whose planes of this level exceed the caches reads them exactly once per evaluation — streamed (nt), so
+    // that they do not displace the target level's lines, which the gathers of neighbouring lanes and steps do re-use, from the
+    // 32 KB L1 (a step of a CU's 16 waves streams 28 KB of planes).  Same-box A/B (round 4): default batch +0.9 %, Huber at 256
+    // pairs +3 %.  A batch that fits the 256 MB memory-side cache keeps the plain loads (its planes come back from there at the
+    // next evaluation; streamed: 64 pairs -3.6 %).  A template parameter, not a flag: the compiler merges the two sides of a
+    // run-time choice into plain loads.
+    if constexpr (STREAM) {
+      *reinterpret_cast<uint32_t*>(r.i1) = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(I1 + idx));
+      *reinterpret_cast<u2v*>(r.gx) = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(reinterpret_cast<const uint8_t*>(GX) + o2));
+      *reinterpret_cast<u2v*>(r.gy) = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(reinterpret_cast<const uint8_t*>(GY) + o2));
+      if constexpr (DEPTH) *reinterpret_cast<u2v*>(r.dp) = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(reinterpret_cast<const uint8_t*>(DP) + o2));
+    } else {
+      *reinterpret_cast<uint32_t*>(r.i1) = *reinterpret_cast<const uint32_t*>(I1 + idx);
+      *reinterpret_cast<uint2*>(r.gx) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(GX) + o2);
+      *reinterpret_cast<uint2*>(r.gy) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(GY) + o2);
+      if constexpr (DEPTH) *reinterpret_cast<uint2*>(r.dp) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(DP) + o2);
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
@@ -1285,7 +1300,7 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
 // by register arithmetic — results are meaningless, its duration is the kernel's own instruction-issue floor.
 // residual_core evaluates one slice of one pair at `pose`; `lds` (optional) is the caller's buffer for the block reduction.
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, int EXT_LDS = 0>   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's
+          bool COMPUTE_ONLY = false, int EXT_LDS = 0, bool STREAM = false>   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's; STREAM: load_group
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first = nullptr, int ref_slot = -1,
                                               int tgt_slot = -1, const CoreOverride* ov = nullptr);
@@ -1301,7 +1316,7 @@ __device__ __forceinline__ void load_first_group(RefGroup<VEC>& rg, const Residu
 }
 
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false>
+          bool COMPUTE_ONLY = false, bool STREAM = false>
 __device__ __forceinline__ bool residual_block(const ResidualArgs& a, const int pair, const int slice) {   // false: the pair is not iterating
   Pose pose;
   if constexpr (COMPUTE_ONLY) {
@@ -1313,12 +1328,12 @@ __device__ __forceinline__ bool residual_block(const ResidualArgs& a, const int 
   } else {
     pose = a.pose;
   }
-  residual_core<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, slice, pose, nullptr);
+  residual_core<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, 0, STREAM>(a, pair, slice, pose, nullptr);
   return true;
 }
 
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
-          int EXT_LDS>
+          int EXT_LDS, bool STREAM>
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot,
                                               const CoreOverride* ov) {
@@ -1400,7 +1415,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   RefGroup<VEC> rg;
   int g = g_begin + (int)threadIdx.x;
   if (first) rg = *first;   // requested by the caller ahead of the pose (k_iterate: before the update)
-  else load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
+  else load_group<VEC, DEPTH, COMPUTE_ONLY, STREAM>(rg, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
   // Pixel coordinates of the thread's group, as floats (small integers: exact).  One division up front, then each step
   // of kBlock groups moves (x, y) by the level's fixed (step mod w, step / w) with at most one wrap.  Lanes past the end
   // of the level run on with coordinates outside the image; they are inactive and every term of theirs is discarded.
@@ -1515,7 +1530,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     // behind the gathers.  The request is unconditional (the index is clamped): inside a branch, the compiler's wait for
     // the gathers would have to assume the branch not taken and count the plane loads in.
     __builtin_amdgcn_sched_barrier(0);
-    load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, I1, GX, GY, DP, (uint32_t)min(g + ahead * kBlock, n_groups - 1) * VEC);
+    load_group<VEC, DEPTH, COMPUTE_ONLY, STREAM>(rg, I1, GX, GY, DP, (uint32_t)min(g + ahead * kBlock, n_groups - 1) * VEC);
     __builtin_amdgcn_sched_barrier(0);
     // kArithOpenCV, identity path: a unit's row is formed in double and goes straight into the sums, one unit at a time (no f32
     // rows of all four pixels held across the phase: the doubles of the small products take their registers)
@@ -1739,10 +1754,10 @@ __device__ __forceinline__ void tail_update_wave(const ResidualArgs& a, int pair
 #define UWT_RESIDUAL_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(UWT_EXP_WAVES, UWT_EXP_WAVES)))
 #endif
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false>
+          bool COMPUTE_ONLY = false, bool STREAM = false>
 __global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
   const int pair = (int)blockIdx.y + a.pair_base;
-  const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY>(a, pair, (int)blockIdx.x);
+  const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, STREAM>(a, pair, (int)blockIdx.x);
   if constexpr (!COMPUTE_ONLY && !DUMP) {
     if (a.tail.on && live && threadIdx.x < 64) tail_update_wave(a, pair);   // wave 0 wrote the block's record
   }
@@ -1750,10 +1765,11 @@ __global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
 
 // The same kernel held to four waves per SIMD (128 registers), for the one instantiation whose allocation lands just above
 // (bilinear sampler + Huber: 129 — the 129th register holds scalar registers the compiler parks across the loop).
-template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0>
+template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
+          bool STREAM = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_residual_w4(const ResidualArgs a) {
   const int pair = (int)blockIdx.y + a.pair_base;
-  const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, false>(a, pair, (int)blockIdx.x);
+  const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, false, STREAM>(a, pair, (int)blockIdx.x);
   if constexpr (!DUMP) {
     if (a.tail.on && live && threadIdx.x < 64) tail_update_wave(a, pair);
   }
@@ -1980,7 +1996,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
   uint16_t dpn[VEC];
   auto load_planes = [&](int g) {
     const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
-    if constexpr (VEC == 4) {
+    if constexpr (VEC == 4) {   // (plain loads: the weighted pass reads the same planes next, and finds them cached — streamed here: -1.2 %)
       *reinterpret_cast<uint32_t*>(i1n) = *reinterpret_cast<const uint32_t*>(I1 + idx);
       if constexpr (DEPTH) *reinterpret_cast<uint2*>(dpn) = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(DP) + idx * 2u);
     } else {
