@@ -315,7 +315,7 @@ def main(args):
     res_ms = res_launches = res_pixels = 0
     res_levels = []
     co_ms = 0.0
-    clock_ghz = 0.0
+    clock_ghz = co_clock_ghz = 0.0
     t_p = time.perf_counter()
     if not args.no_profile:
         for _ in range(max(2, args.warmup)):
@@ -334,6 +334,7 @@ def main(args):
             step()                                          # poses of these steps are meaningless by construction
             fence()
             co_ms = ctx.profile_read()[0]
+            co_clock_ghz = ctx.profile_clock()              # the clock the chip holds under the twin (no memory traffic)
         ctx.profile_enable(0)
         step()                                              # leave the real poses behind
         fence()
@@ -436,6 +437,11 @@ def main(args):
                 # same launches, same instruction stream, no memory operation: what the VALU alone takes
                 valu["compute_only_avg_launch_ms"] = round(co_ms / res_launches, 5)
                 valu["valu_issue_frac"] = round(co_ms / res_ms, 4)
+                if co_clock_ghz:
+                    # the twin moves no data: if the chip clocks higher under it, part of valu_issue_frac is clock, not stalls
+                    valu["compute_only_shader_clock_GHz"] = round(co_clock_ghz, 3)
+                    if clock_ghz:
+                        valu["valu_issue_frac_in_cycles"] = round(co_ms * co_clock_ghz / (res_ms * clock_ghz), 4)
                 valu["note"] = ("valu_issue_frac = duration of the kernel's compute-only twin (every load of the loop replaced "
                                 "by register arithmetic) / duration of the kernel, measured back to back in this run")
             if clock_ghz:
