@@ -604,6 +604,37 @@ def test_batch_sizes_and_schedules_match_oracle(capi, O, synth, n, cfg):
         assert np.array_equal(poses[i], cpu[i][1]), (i, poses[i], cpu[i][1])
 
 
+@pytest.mark.parametrize("general", [dict(), dict(weights=2), dict(weights=1), dict(sampler=1), dict(sampler=1, weights=2)],
+                         ids=["identity", "huber", "tukey", "bilinear", "bilinear_huber"])
+def test_streamed_plane_loads_change_no_bit(capi, O, synth, monkeypatch, general):
+    """A batch whose planes exceed the caches runs the STREAM twins of the accumulation kernels (non-temporal plane loads,
+    load_group).  UWT_STREAM_MB=0 makes every level of a small batch take them; UWT_STREAM_MB=1000000 none: same poses, the
+    oracle's, bit for bit.  (The batch is split over two streams: the launch path the twins are dispatched from.)"""
+    w, h, n = 160, 96, 12
+    over = dict(n_levels=4, first_level=3, last_level=0, max_iters=5, early_exit=0, has_depth=1, **general)
+    p = O.default_params(w, h, *MID, **over)
+    frames, depths, cpu = [], [], []
+    for s in range(n):
+        ref, tgt, dep, _, _ = synth.render_pair(w, h, *MID, seed=7300 + s, with_depth=True)
+        frames += [ref, tgt]
+        depths += [dep, dep]
+        cpu.append(O.align_pair(p, ref, tgt, dep)[1])
+    monkeypatch.setenv("UWT_SPLIT_MIN_PX", "1")    # two parts on two streams even at this size
+    monkeypatch.setenv("UWT_SPLIT_MIN", "2")
+    got = {}
+    for mb in ("0", "1000000"):
+        monkeypatch.setenv("UWT_STREAM_MB", mb)
+        ctx = make_ctx(capi, w, h, MID, max_frames=2 * n, max_pairs=n, **over)
+        ctx.upload_frames(0, np.stack(frames), np.stack(depths))
+        ctx.build_pyramids(0, 2 * n)
+        ctx.apply_gradient(0, 2 * n)
+        got[mb], _ = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1, raise_on_pair_failure=True)
+        ctx.close()
+    assert np.array_equal(got["0"].view(np.uint32), got["1000000"].view(np.uint32))
+    for i in range(n):
+        assert np.array_equal(got["0"][i].view(np.uint32), cpu[i].view(np.uint32)), i
+
+
 def test_failing_pair_does_not_disturb_its_batch(capi, O, synth):
     """One pair with no valid depth gets UWT_ERR_NO_VALID_POINTS; the other pairs of the batch are untouched."""
     w, h, n = 64, 48, 6
