@@ -3,7 +3,7 @@
 //
 //   make -C tools            (g++ against include/uwt.h and uw-slam_amd/libuwt_hip.so; see tools/Makefile)
 //   tools/uwt_bench [--pairs 1024] [--unique 32] [--steps 10] [--warmup 3] [--width 640] [--height 480] [--levels 4]
-//                   [--iters 10] [--no-depth] [--reference-schedule] [--gpus N] [--rccl]
+//                   [--iters 10] [--no-depth] [--reference-schedule] [--legacy-arith] [--gpus N] [--rccl]
 //
 // --gpus N: the batched multi-GPU mode from a native host — one thread and one context per device, --pairs per device,
 // global pair i on device i mod N, one ncclAllGather (RCCL over xGMI) of the solved poses per step enqueued on each
@@ -78,7 +78,7 @@ struct Barrier {   // std::barrier is C++20
 
 struct Shared {
   int P, U, steps, warmup, w, h, levels, iters, n_dev;
-  bool depth, ref_sched, rccl;
+  bool depth, ref_sched, rccl, legacy;
   Barrier* bar;
   ncclComm_t* comms;
   double t_start = 0, t_end = 0;
@@ -104,6 +104,7 @@ int run_device(Shared& S, int dev) {
     p.n_levels = S.levels; p.first_level = S.levels - 1; p.last_level = 0; p.max_iters = S.iters; p.early_exit = 0;
   }
   p.has_depth = S.depth ? 1 : 0;
+  p.arith = S.legacy ? UWT_ARITH_LEGACY : UWT_ARITH_OPENCV;   // (the default: OpenCV's generic code paths, include/uwt.h)
   p.max_frames = 2 * P;
   p.max_pairs = P;
   p.device = dev;
@@ -177,6 +178,7 @@ int main(int argc, char** argv) {
   S.iters = arg_int(argc, argv, "--iters", 10);
   S.depth = !arg_flag(argc, argv, "--no-depth");
   S.ref_sched = arg_flag(argc, argv, "--reference-schedule");
+  S.legacy = arg_flag(argc, argv, "--legacy-arith");
   S.n_dev = arg_int(argc, argv, "--gpus", 1);
   S.rccl = S.n_dev > 1 || arg_flag(argc, argv, "--rccl");
   if (S.ref_sched) S.levels = 5;
@@ -240,12 +242,12 @@ int main(int argc, char** argv) {
   }
   std::printf("{\"metric\": \"frame-pair alignments/sec (%dx%d, %d pyr lvls)\", \"value\": %.2f, \"unit\": \"alignments/s\", "
               "\"n_gpus\": %d, \"steps\": %d, \"warmup\": %d, \"ms_per_step\": %.4f, \"scaling\": \"weak\", \"host\": \"C++ over the C ABI%s\", "
-              "\"config\": {\"workload\": \"%s, %d pairs resident per GPU (%d distinct)%s\"}, "
+              "\"config\": {\"workload\": \"%s, %d pairs resident per GPU (%d distinct)%s\", \"arithmetic\": \"%s\"}, "
               "\"poses_finite\": %s, \"tiled_pairs_identical\": %s, \"gathered_blocks_match\": %s, \"max_translation_m\": %.6f}\n",
               S.w, S.h, S.levels, (double)P * N * S.steps / sec, N, S.steps, S.warmup, sec * 1e3 / S.steps,
               S.rccl ? " + RCCL all-gather" : "",
               S.ref_sched ? "reference schedule (levels 4..1, <= 50 iterations, early exit)" : "fixed iterations, no early exit", P, U,
-              S.depth ? ", u16 depth plane" : "", finite ? "true" : "false", tiled_equal ? "true" : "false",
+              S.depth ? ", u16 depth plane" : "", S.legacy ? "legacy" : "opencv", finite ? "true" : "false", tiled_equal ? "true" : "false",
               !S.rccl ? "null" : (gather_ok ? "true" : "false"), tmax);
   return (finite && tiled_equal && gather_ok) ? 0 : 1;
 }
