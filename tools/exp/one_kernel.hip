@@ -24,3 +24,9 @@ template __global__ void k_residual_w4<kArithLegacy, 4, true, true, false, doubl
 template __global__ void k_residual<kArithLegacy, 4, true, true, false, double, true, 1, 2>(const ResidualArgs);
 }
 #endif
+#ifdef ONE_KERNEL_CW
+namespace uwt {
+template __global__ void k_coarse_weighted<kArithOpenCV, true, 2, 1>(const CoarseArgs);
+template __global__ void k_coarse_weighted<kArithOpenCV, true, 1, 3>(const CoarseArgs);
+}
+#endif

@@ -725,7 +725,10 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   int n_coarse = 0;
   {
     const LevelK& L0 = c->lv[p.first_level];
-    const bool plain = !general && c->vec == 4 && p.accumulate_f64 != 0 && p.z_factor == 1.0f && p.angle_factor == 1.0f && L0.fx == L0.fy;
+    const bool shape = c->vec == 4 && p.accumulate_f64 != 0 && p.z_factor == 1.0f && p.angle_factor == 1.0f && L0.fx == L0.fy;
+    // identity weights: k_coarse_w4; robust weights over the nearest sampler: k_coarse_weighted (histogram, scale, weighted
+    // sums and update of a whole level in one block).  The bilinear sampler stays on the launches.
+    const bool plain = shape && (!general || (p.sampler == 0 && p.weights != 0 && !std::getenv("UWT_NO_COARSE_WEIGHTED")));
     if (plain && c->coarse_batch_px > 0 && !c->compute_only && !(c->profiling && p.early_exit))
       while (n_coarse < kCoarseMaxLevels && p.first_level - n_coarse >= p.last_level &&
              c->lv[p.first_level - n_coarse].n <= c->coarse_batch_px) n_coarse++;
@@ -753,6 +756,15 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         if (st) return st;
       }
       UWT_WITH_ARITH(c,
+        if (general) {
+          if (p.weights == kWeightsTukeyRef) {
+            if (p.has_depth) hipLaunchKernelGGL((k_coarse_weighted<AR, true, kWeightsTukeyRef, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
+            else hipLaunchKernelGGL((k_coarse_weighted<AR, false, kWeightsTukeyRef, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
+          } else {
+            if (p.has_depth) hipLaunchKernelGGL((k_coarse_weighted<AR, true, kWeightsHuber, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
+            else hipLaunchKernelGGL((k_coarse_weighted<AR, false, kWeightsHuber, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
+          }
+        } else
 #ifdef UWT_EXP_NO_W4
         if (p.has_depth) hipLaunchKernelGGL((k_coarse<AR, true, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
         else hipLaunchKernelGGL((k_coarse<AR, false, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca));

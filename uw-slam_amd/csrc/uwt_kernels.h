@@ -1243,6 +1243,7 @@ struct ResidualArgs {
 struct CoreOverride {
   int groups_per_block, slices;
   uint32_t* partials;
+  const PairScale* scale = nullptr;   // robust-weight scale of the pair, indexed like ResidualArgs::scale (k_coarse_weighted: in LDS)
 };
 
 // reference planes of one group of VEC pixels, as loaded (one vector load per plane)
@@ -1391,7 +1392,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   constexpr bool GENERAL = SAMPLER != 0 || WEIGHTS != 0;  // float residuals and/or robust weights
   AccT err = (AccT)0;                                      // Σ r·(r·w), the error numerator on the general path
   float inv_mad = 1.f;
-  if constexpr (WEIGHTS != 0) inv_mad = a.scale[pair].inv_mad;
+  if constexpr (WEIGHTS != 0) inv_mad = (ov && ov->scale ? ov->scale : a.scale)[pair].inv_mad;
   // robust weights over integer residuals: the per-value table (see WeightEntry) in the bytes of the reduction's image
   constexpr bool TABLE = WEIGHTS != 0 && SAMPLER == 0;
   static_assert(!TABLE || EXT_LDS == 0, "the weighted path reduces in its own LDS");
@@ -1970,27 +1971,13 @@ __global__ __launch_bounds__(256) void k_scale_stage(const GeneralArgs ga, const
 constexpr int kHistRep = 8;
 constexpr int kHistTicketWord = kHistBins - 1;
 
+// The scale pass over groups [g_begin, g_end) of one pair's level at `pose`: every valid pixel's rounded residual counted in the
+// caller's LDS histogram (myh: bin 0 of this thread's replica).  Shared by k_resid_hist_v (one slice per block) and
+// k_coarse_weighted (a whole level per block).  The masked ds_add_u32 are the asm's own: the caller waits (lgkmcnt(0)).
 template <int AR, int VEC, bool DEPTH, int SAMPLER>
-__global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, unsigned int* __restrict__ hist, PairScale* __restrict__ scale_out,
-                                                         int weights) {
-  const int pair = blockIdx.y + a.pair_base;
-  const PairState st = a.state[pair];
-  if (st.level_done || st.status) return;
-  __shared__ unsigned int h[kHistBins * kHistRep];
-  __shared__ int s_last;
-  for (int i = threadIdx.x; i < kHistRep * kHistBins; i += kBlock) h[i] = 0;
-  __syncthreads();
-  WarpK K;
-  warp_setup<AR>(st.pose, K);
-  const LevelK L = a.L;
-  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
-  const uint8_t* __restrict__ I1 = a.img + ref_off;
-  const uint8_t* __restrict__ I2 = a.img + tgt_off;
-  const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
-  // bin q of this thread's replica: myh[q * kHistRep]
-  unsigned int* myh = h + 255 * kHistRep + (threadIdx.x & (kHistRep - 1));
-  const int n_groups = L.n / VEC;
-  const int g_begin = blockIdx.x * a.groups_per_block, g_end = min(g_begin + a.groups_per_block, n_groups);
+__device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2,
+                                            const uint16_t* __restrict__ DP, unsigned int* myh, const int g_begin, const int g_end,
+                                            const int n_groups) {
   // the planes of a thread's next group are requested behind this group's gathers, as in residual_core
   uint8_t i1n[VEC];
   uint16_t dpn[VEC];
@@ -2091,6 +2078,30 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
       }
     }
   }
+}
+
+template <int AR, int VEC, bool DEPTH, int SAMPLER>
+__global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, unsigned int* __restrict__ hist, PairScale* __restrict__ scale_out,
+                                                         int weights) {
+  const int pair = blockIdx.y + a.pair_base;
+  const PairState st = a.state[pair];
+  if (st.level_done || st.status) return;
+  __shared__ unsigned int h[kHistBins * kHistRep];
+  __shared__ int s_last;
+  for (int i = threadIdx.x; i < kHistRep * kHistBins; i += kBlock) h[i] = 0;
+  __syncthreads();
+  WarpK K;
+  warp_setup<AR>(st.pose, K);
+  const LevelK L = a.L;
+  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
+  const uint8_t* __restrict__ I1 = a.img + ref_off;
+  const uint8_t* __restrict__ I2 = a.img + tgt_off;
+  const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
+  // bin q of this thread's replica: myh[q * kHistRep]
+  unsigned int* myh = h + 255 * kHistRep + (threadIdx.x & (kHistRep - 1));
+  const int n_groups = L.n / VEC;
+  const int g_begin = blockIdx.x * a.groups_per_block, g_end = min(g_begin + a.groups_per_block, n_groups);
+  hist_groups<AR, VEC, DEPTH, SAMPLER>(L, K, I1, I2, DP, myh, g_begin, g_end, n_groups);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the masked ds_add_u32 above are the asm's own: the compiler does not count them
   __syncthreads();
   unsigned int* gh = hist + (size_t)pair * kHistBins;
@@ -2586,6 +2597,102 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
         u.k = k;
         st = update_compute(u, rec, cur, lds, false);   // ends with a barrier: every thread has the new state
         if (st.level_done || st.status) break;          // block-uniform (the exit test, src/Tracker.cpp:508)
+      }
+    }
+    // end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
+    if (st.status == 0 && ca.level_id[li] != 0) {
+      if (!se3_handoff(st.pose, ca.scale_t != 0)) st.status = 1;  // SOPHUS_ENSURE would abort
+    }
+    st.level_done = 0;
+    st.last_error = ca.initial_error;
+  }
+  if (threadIdx.x == 0) ca.state_out[pair] = st;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// k_coarse_weighted: what k_coarse is to the identity path, for robust weights over the nearest-neighbour sampler — a level of up
+// to kCoarseMaxPixels pixels of one pair evaluated by ONE block, every iteration of it in one launch: the residual histogram in
+// LDS (hist_groups), median and MAD from it (wave_scale), the weighted sums through the per-value weight table (residual_core),
+// the update on the record in LDS (update_compute), the exit test on the device.  Per evaluation that replaces the scale
+// launch, the weighted launch and the update (three dependent launches of a few blocks each, ~20 us for a lone pair) by ~8 us
+// of one resident block.  Same device functions as the launches it replaces: same bits.
+// ------------------------------------------------------------------------------------------------------------
+template <int AR, bool DEPTH, int WEIGHTS, int NLEV = kCoarseMaxLevels>
+__global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca) {
+  __shared__ unsigned int h[kHistBins * kHistRep];                                  // the residual histogram, kHistRep replicas per bin
+  __shared__ unsigned int h_scratch[kHistBins];                                     // wave_scale's working copy
+  __shared__ __attribute__((aligned(16))) unsigned char ulds[kUpdateLdsBytes];      // update_compute's staging
+  __shared__ __attribute__((aligned(16))) uint32_t rec[kRecWords];                  // the evaluation's record
+  __shared__ PairState cur;                                                         // the state update_compute reads
+  __shared__ PairScale s_scale;
+  const int lp = (int)blockIdx.x, pair = lp + ca.u.pair_base;
+  const int ref_slot = ca.inline_pairs ? (lp == 0 ? ca.pair_slots[0] : ca.pair_slots[2]) : ca.lv[0].ref_slots[pair];
+  const int tgt_slot = ca.inline_pairs ? (lp == 0 ? ca.pair_slots[1] : ca.pair_slots[3]) : ca.lv[0].tgt_slots[pair];
+  PairState st;
+  if (ca.resume) {
+    st = ca.state_out[pair];
+  } else {
+    pose_identity(st.pose);  // src/Tracker.cpp:385
+    st.last_error = ca.initial_error;
+    st.error = 0.f;
+    st.level_done = 0;
+    st.status = 0;
+    st.iters = 0;
+    st.n_valid = 0;
+  }
+#pragma unroll
+  for (int li = 0; li < NLEV; li++) {
+    if (li >= ca.n_levels) break;   // block-uniform
+    const ResidualArgs& a = ca.lv[li];
+    const LevelK L = a.L;
+    const int n_groups = L.n / 4;
+    CoreOverride ov;
+    ov.slices = 1;
+    ov.groups_per_block = ((n_groups + kBlock - 1) / kBlock) * kBlock;   // the whole level
+    ov.partials = rec - (size_t)pair * kRecWords;                         // residual_core writes record (pair, slice 0)
+    ov.scale = &s_scale - pair;
+    UpdateArgs u = ca.u;
+    u.slices = 1;
+    u.active = nullptr;
+    u.general = 1;
+    const size_t ref_off = (size_t)ref_slot * L.n, tgt_off = (size_t)tgt_slot * L.n;
+    if (st.status == 0) {
+      for (int k = 0; k < u.max_iters; k++) {
+        // the scale pass (MedianMat / MedianAbsoluteDeviation, src/Tracker.cpp:1571-1619) at this evaluation's pose
+        for (int i = threadIdx.x; i < kHistRep * kHistBins; i += kBlock) h[i] = 0;
+        __syncthreads();   // (also: every thread has taken the last state out of the update's bytes)
+        if (threadIdx.x == 0) cur = st;
+        {
+          WarpK K;
+          warp_setup<AR>(st.pose, K);
+          hist_groups<AR, 4, DEPTH, 0>(L, K, a.img + ref_off, a.img + tgt_off, DEPTH ? a.depth + ref_off : nullptr,
+                                       h + 255 * kHistRep + (threadIdx.x & (kHistRep - 1)), 0, n_groups, n_groups);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // hist_groups' masked ds_add_u32 are its asm's own
+        __syncthreads();
+        if (threadIdx.x < 64) {
+          const int lane = (int)threadIdx.x;
+          unsigned int mine[8];
+#pragma unroll
+          for (int q = 0; q < 8; q++) {
+            const int b = lane * 8 + q;
+            unsigned int t = 0;
+            if (b < 511) {
+              const uint4 lo = *reinterpret_cast<const uint4*>(&h[b * kHistRep]), hi = *reinterpret_cast<const uint4*>(&h[b * kHistRep + 4]);
+              t = lo.x + lo.y + lo.z + lo.w + hi.x + hi.y + hi.z + hi.w;
+            }
+            mine[q] = t;
+          }
+          const PairScale sc = wave_scale(mine, h_scratch, WEIGHTS == kWeightsTukeyRef, lane);
+          if (lane == 0) s_scale = sc;
+        }
+        __syncthreads();
+        // the weighted sums (src/Tracker.cpp:554-561) through the weight table; the record lands in LDS
+        residual_core<AR, 4, DEPTH, true, false, double, true, 0, WEIGHTS>(a, pair, 0, st.pose, nullptr, nullptr, ref_slot, tgt_slot, &ov);
+        __syncthreads();
+        u.k = k;
+        st = update_compute(u, rec, &cur, ulds, false);   // ends with a barrier: every thread has the new state
+        if (st.level_done || st.status) break;            // block-uniform (the exit test, src/Tracker.cpp:508)
       }
     }
     // end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
