@@ -635,6 +635,43 @@ def test_streamed_plane_loads_change_no_bit(capi, O, synth, monkeypatch, general
         assert np.array_equal(got["0"][i].view(np.uint32), cpu[i].view(np.uint32)), i
 
 
+@pytest.mark.parametrize("sched", ["fixed", "reference"])
+@pytest.mark.parametrize("weights", [1, 2], ids=["tukey", "huber"])
+def test_coarse_weighted_kernel_and_the_launches_agree(capi, O, synth, monkeypatch, weights, sched):
+    """Coarse levels of the robust-weight path run in k_coarse_weighted (one block per pair: histogram, scale, weighted sums and
+    update in LDS, a level's iterations in one launch); UWT_NO_COARSE_WEIGHTED=1 keeps them on the scale / accumulation / update
+    launches.  Same poses, same iteration counts, the oracle's — one pair per call and a batch, fixed and early-exit schedules."""
+    w, h, n = 160, 96, 5
+    over = dict(has_depth=1, weights=weights)
+    if sched == "fixed":
+        over.update(n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0)
+    p = O.default_params(w, h, *MID, **over)
+    frames, depths, cpu = [], [], []
+    for s in range(n):
+        ref, tgt, dep, _, _ = synth.render_pair(w, h, *MID, seed=7400 + s, with_depth=True)
+        frames += [ref, tgt]
+        depths += [dep, dep]
+        cpu.append(O.align_pair(p, ref, tgt, dep, want_trace=True))
+    got = {}
+    for mode in ("coarse", "launches"):
+        if mode == "launches":
+            monkeypatch.setenv("UWT_NO_COARSE_WEIGHTED", "1")
+        ctx = make_ctx(capi, w, h, MID, max_frames=2 * n, max_pairs=n, **over)
+        ctx.upload_frames(0, np.stack(frames), np.stack(depths))
+        ctx.build_pyramids(0, 2 * n)
+        ctx.apply_gradient(0, 2 * n)
+        batch, bstats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1, raise_on_pair_failure=True)
+        single, sstats = ctx.estimate_pose_batch([0], [1], raise_on_pair_failure=True)
+        got[mode] = (batch.copy(), [s["iterations"] for s in bstats], single[0].copy(), sstats[0]["iterations"])
+        ctx.close()
+    for mode in got:
+        batch, its, single, sit = got[mode]
+        for i in range(n):
+            assert np.array_equal(batch[i].view(np.uint32), cpu[i][1].view(np.uint32)), (mode, i)
+            assert its[i] == len(cpu[i][2]), (mode, i)
+        assert np.array_equal(single.view(np.uint32), cpu[0][1].view(np.uint32)) and sit == len(cpu[0][2]), mode
+
+
 def test_failing_pair_does_not_disturb_its_batch(capi, O, synth):
     """One pair with no valid depth gets UWT_ERR_NO_VALID_POINTS; the other pairs of the batch are untouched."""
     w, h, n = 64, 48, 6
