@@ -663,6 +663,30 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
   return UWT_OK;
 }
 
+// one coarse level of a batch (one block per pair, the level's iterations in one launch): identity weights k_coarse_w4, robust
+// weights over the nearest sampler k_coarse_weighted
+template <int AR>
+void launch_coarse_level(hipStream_t s, const CoarseArgs& ca, int cnt, bool depth, bool general, int weights) {
+  const dim3 grid(cnt), blk(kBlock);
+  if (general) {
+    if (weights == kWeightsTukeyRef) {
+      if (depth) hipLaunchKernelGGL((k_coarse_weighted<AR, true, kWeightsTukeyRef, 1>), grid, blk, 0, s, ca);
+      else hipLaunchKernelGGL((k_coarse_weighted<AR, false, kWeightsTukeyRef, 1>), grid, blk, 0, s, ca);
+    } else {
+      if (depth) hipLaunchKernelGGL((k_coarse_weighted<AR, true, kWeightsHuber, 1>), grid, blk, 0, s, ca);
+      else hipLaunchKernelGGL((k_coarse_weighted<AR, false, kWeightsHuber, 1>), grid, blk, 0, s, ca);
+    }
+    return;
+  }
+#ifdef UWT_EXP_NO_W4
+  if (depth) hipLaunchKernelGGL((k_coarse<AR, true, true, double, true, 14, 1>), grid, blk, 0, s, ca);
+  else hipLaunchKernelGGL((k_coarse<AR, false, true, double, true, 14, 1>), grid, blk, 0, s, ca);
+#else
+  if (depth) hipLaunchKernelGGL((k_coarse_w4<AR, true, true, double, true, 14, 1>), grid, blk, 0, s, ca);
+  else hipLaunchKernelGGL((k_coarse_w4<AR, false, true, double, true, 14, 1>), grid, blk, 0, s, ca);
+#endif
+}
+
 // Tracker::EstimatePose for a batch, enqueued on the context's stream (src/Tracker.cpp:362-597)
 // The chained flow pays where an alignment is bound by kernel boundaries and dependent round trips, not by arithmetic: a
 // few pairs on their own (the drop-in call).  In a batch every block would repeat its pair's update.  Measured at 640x480
@@ -755,23 +779,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         int st = prof_begin(c, &ev, lvl, p.max_iters);
         if (st) return st;
       }
-      UWT_WITH_ARITH(c,
-        if (general) {
-          if (p.weights == kWeightsTukeyRef) {
-            if (p.has_depth) hipLaunchKernelGGL((k_coarse_weighted<AR, true, kWeightsTukeyRef, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
-            else hipLaunchKernelGGL((k_coarse_weighted<AR, false, kWeightsTukeyRef, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
-          } else {
-            if (p.has_depth) hipLaunchKernelGGL((k_coarse_weighted<AR, true, kWeightsHuber, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
-            else hipLaunchKernelGGL((k_coarse_weighted<AR, false, kWeightsHuber, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
-          }
-        } else
-#ifdef UWT_EXP_NO_W4
-        if (p.has_depth) hipLaunchKernelGGL((k_coarse<AR, true, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
-        else hipLaunchKernelGGL((k_coarse<AR, false, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca));
-#else
-        if (p.has_depth) hipLaunchKernelGGL((k_coarse_w4<AR, true, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca);
-        else hipLaunchKernelGGL((k_coarse_w4<AR, false, true, double, true, 14, 1>), dim3(cnt), dim3(kBlock), 0, s, ca));
-#endif
+      UWT_WITH_ARITH(c, launch_coarse_level<AR>(s, ca, cnt, p.has_depth != 0, general, p.weights));
       HIPCHK(c, hipGetLastError());
       if (c->profiling) {   // (fixed schedules only: the level runs max_iters evaluations; the launch stands for that many)
         HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], s));
