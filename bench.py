@@ -237,11 +237,9 @@ def main(args):
     # (before the context: nothing may start a child process once the GPU is initialised — under rocprofv3 a child would
     # inherit the profiler's preloaded library; _cpp_generator builds the generator, if it has to, with that environment stripped)
     gen = _cpp_generator() if args.generator == "cpp" else None
-    if _under_profiler():
-        # per-kernel statistics are to describe whole-batch launches, one at a time: the two-halves-on-two-streams form of a
-        # batch overlaps launches of half the size, whose durations a trace cannot tell apart from waiting
-        os.environ.setdefault("UWT_SPLIT", "1")
-    ctx = capi.Context(params)
+    # under a profiler, per-kernel statistics are to describe whole-batch launches, one at a time: the two-halves-on-two-streams
+    # form of a batch overlaps launches of half the size, whose durations a trace cannot tell apart from waiting
+    ctx = capi.Context(params, tuning=dict(split=1) if _under_profiler() else None)
 
     U = min(args.unique, P)
     refs, tgts, deps = [], [], []

@@ -20,7 +20,7 @@ extern "C" {
 #endif
 
 #define UWT_MAX_LEVELS 8
-#define UWT_ABI_VERSION 2   /* 2: uwt_params::arith */
+#define UWT_ABI_VERSION 3   /* 2: uwt_params::arith; 3: uwt_tuning (no environment variables are read any more) */
 
 enum uwt_status_code {
   UWT_OK = 0,
@@ -102,6 +102,34 @@ typedef struct uwt_accum {
 
 typedef struct uwt_ctx uwt_ctx;
 
+/* Launch-shape switches of a context: HOW the same arithmetic is laid out in launches, never WHAT is computed — every
+ * setting gives the same poses bit for bit (tests/test_gpu_production.py runs the forms against each other).  The library reads
+ * no environment variable; a context starts with the defaults below (uwt_get_tuning returns them), and the parity suite and the
+ * A/B tools change them through uwt_set_tuning.  No reference counterpart (the reference has one form of everything). */
+typedef struct uwt_tuning {
+  int32_t split;             /* parts a large fixed-schedule batch is cut into, each on a stream of its own (1..4) [2]      */
+  int32_t split_min;         /* pairs per part at least [8]                                                                 */
+  int64_t split_min_px;      /* level-0 pixels of the whole batch from which the split pays [32 * 640 * 480]                */
+  int64_t stream_bytes;      /* a level whose planes over the whole batch exceed this is read non-temporally [200 MiB]      */
+  int32_t tail_update;       /* Gauss-Newton update in the tail of the evaluation's own launch: 0 never, 1 split batches,
+                                2 always [1]                                                                                */
+  int32_t target_blocks;     /* blocks per residual launch the batch-dependent slicing aims at; 0: automatic [0]            */
+  int32_t coarse;            /* a few pairs: the coarsest levels in one launch (k_coarse) [1]                               */
+  int32_t coarse_batch_px;   /* batches: levels of up to this many pixels run one block per pair, one launch per level;
+                                0: never [6144]                                                                             */
+  int32_t coarse_weighted;   /* the same for robust weights over the nearest sampler (k_coarse_weighted) [1]                */
+  int32_t overlap_gradients; /* uwt_track_batch_async: finer levels' gradients on a side stream beside the first, coarse
+                                iterations [1]                                                                              */
+  int32_t first_poll;        /* early-exit schedules: evaluations of a level before the host first looks [3]                */
+  int32_t chained;           /* -1: update chained into the next evaluation's launch for a few pairs; 1 / 0: always / never
+                                [-1]                                                                                        */
+  int32_t speculation;       /* one or two pairs, early exit: launch without read-backs, redo carefully if cut short [1]    */
+  int32_t fused_stages;      /* a few frames: whole pyramid / all gradient levels in one launch each [1]                    */
+  int32_t pyramid_batch;     /* batches: pyramid levels 1..3 in one pass over level 0 [1]                                   */
+  int32_t persistent;        /* one pair per call: the whole alignment in ONE launch (k_align_one) [1]                      */
+  int32_t reserved[4];
+} uwt_tuning;
+
 /* ---- lifecycle -------------------------------------------------------------------------------------------- */
 
 /* Fills the reference's EstimatePose constants (src/Tracker.cpp:364-372) for a w x h camera. */
@@ -116,6 +144,10 @@ int uwt_create(const uwt_params* p, uwt_ctx** out);
 int uwt_update_params(uwt_ctx* ctx, const uwt_params* p);
 /* the context's current parameters */
 int uwt_get_params(const uwt_ctx* ctx, uwt_params* out);
+/* the context's launch-shape switches (uwt_tuning); uwt_set_tuning waits for the context's work in flight, validates and
+ * clamps, and applies to every later call */
+int uwt_get_tuning(const uwt_ctx* ctx, uwt_tuning* out);
+int uwt_set_tuning(uwt_ctx* ctx, const uwt_tuning* t);
 /* Tracker::~Tracker (src/Tracker.cpp:280-293) */
 int uwt_destroy(uwt_ctx* ctx);
 /* reads back w_/h_/fx_/fy_/cx_/cy_/invfx_/invfy_[lvl] (include/Tracker.h:516-526) */

@@ -77,9 +77,9 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-# what default_params() fills in when the caller names no set: UWT_ARITH=legacy in the environment (the parity suite's child
-# processes; the HIP library's uwt_default_params reads the same variable), else OpenCV's; tests/conftest.py switches it per test
-DEFAULT_ARITH = ARITH_LEGACY if os.environ.get("UWT_ARITH") == "legacy" else ARITH_OPENCV
+# what default_params() fills in when the caller names no set: OpenCV's, like the HIP library's uwt_default_params (no
+# environment variable is read); tests/conftest.py switches it per test, child processes of tests set it from their arguments
+DEFAULT_ARITH = ARITH_OPENCV
 
 
 def default_params(width, height, fx, fy, cx, cy, **over):

@@ -29,19 +29,32 @@ def pytest_generate_tests(metafunc):
 @pytest.fixture(autouse=True)
 def arith(request, monkeypatch):
     """The arithmetic set of this test: the default both Python bindings put into fresh parameter blocks (oracle.oracle and
-    uw-slam_amd.capi default_params), the oracle's per-stage switch, and UWT_ARITH for child processes."""
+    uw-slam_amd.capi default_params) and the oracle's per-stage switch.  Neither library reads the environment: child processes
+    of tests are told the set explicitly (--arith / an argument), and the Python snippets tests run as children pick it up from
+    UWT_TEST_ARITH through child_arith_header() below."""
     name = request.param
     from oracle import oracle
     capi = importlib.import_module("uw-slam_amd.capi")
     monkeypatch.setattr(oracle, "DEFAULT_ARITH", ARITH_SETS[name])
     monkeypatch.setattr(capi, "DEFAULT_ARITH", ARITH_SETS[name])
-    monkeypatch.setenv("UWT_ARITH", name)
+    monkeypatch.setenv("UWT_TEST_ARITH", name)
     if os.path.exists(oracle._LIB_PATH):
         prev = oracle.set_arith(ARITH_SETS[name])
         yield name
         oracle.set_arith(prev)
     else:
         yield name
+
+
+# first lines of a Python snippet a test runs as a child process: both bindings' default set = the parent test's
+CHILD_ARITH_HEADER = r'''
+import importlib as _il, os as _os
+_ar = {"opencv": 0, "legacy": 1}[_os.environ.get("UWT_TEST_ARITH", "opencv")]
+_il.import_module("uw-slam_amd.capi").DEFAULT_ARITH = _ar
+from oracle import oracle as _O
+_O.DEFAULT_ARITH = _ar
+_O.set_arith(_ar)
+'''
 
 
 class GoldenView:

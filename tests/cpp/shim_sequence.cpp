@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <memory>
 #include <vector>
 
@@ -65,6 +66,7 @@ int main(int argc, char** argv) {
     const float K[9] = {fl, 0, w / 2 - 0.5f, 0, fl, h / 2 - 0.5f, 0, 0, 1};
     Tracker* tracker_ = new Tracker(false, /*max_frames=*/4);
     tracker_->InitializePyramid(w, h, K);
+    if (argc > 4 && !std::strcmp(argv[4], "legacy")) tracker_->params().arith = UWT_ARITH_LEGACY;   // the parity suite runs both sets
     tracker_->InitializeMasks();
     std::unique_ptr<Frame> previous_frame_(AddFrame(0, a, w, h, false)), current_frame_(AddFrame(1, b, w, h, false));
     if (previous_frame_->images_[2].rows != h / 4 || previous_frame_->images_[2].cols != w / 4) return 4;

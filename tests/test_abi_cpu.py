@@ -30,21 +30,24 @@ def test_library_exports_every_declared_symbol(capi):
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(capi.SYMBOLS) == declared
-    assert lib.uwt_abi_version() == 2   # 2: uwt_params::arith
+    assert lib.uwt_abi_version() == 3   # 3: uwt_tuning
 
 
 def test_source_id_is_the_hash_of_sources_and_flags(capi):
     """uwt_source_id(): what bench.py compares with the id stamped on profiles/rNN/k_residual_facts.json.  The Makefile hashes
-    the four source files followed by its flags line; recomputed here from the same inputs."""
+    its source files (every translation unit and header) followed by its flags line; recomputed here from the same inputs."""
     import hashlib
     import subprocess
     sid = capi.source_id()
     assert re.fullmatch(r"[0-9a-f]{64}", sid), sid
     csrc = os.path.join(ROOT, "uw-slam_amd", "csrc")
-    flags = subprocess.run(["make", "-s", "-C", csrc, "--eval", "print-flags: ; @echo '$(CXXFLAGS)'", "print-flags"],
-                           capture_output=True, text=True, check=True).stdout
+    def make_var(name):
+        return subprocess.run(["make", "-s", "-C", csrc, "--eval", "print-var: ; @echo '$(%s)'" % name, "print-var"],
+                              capture_output=True, text=True, check=True).stdout
+    flags, sources = make_var("CXXFLAGS"), make_var("SOURCES").split()
+    assert "uwt_capi.hip" in sources and "uwt_kernels.h" in sources and "../../include/uwt.h" in sources
     h = hashlib.sha256()
-    for f in ("uwt_capi.hip", "uwt_kernels.h", "uwt_math.h", os.path.join("..", "..", "include", "uwt.h")):
+    for f in sources:
         h.update(open(os.path.join(csrc, f), "rb").read())
     h.update(flags.encode())
     assert h.hexdigest() == sid
@@ -56,6 +59,18 @@ def test_struct_layouts_match_header(capi):
     assert C.sizeof(capi.Level) == 8 * 4
     assert C.sizeof(capi.Stats) == 16
     assert C.sizeof(capi.Accum) == 21 * 8 + 6 * 8 + 8 + 8
+    assert C.sizeof(capi.Tuning) == 2 * 4 + 2 * 8 + 12 * 4 + 4 * 4
+
+
+def test_library_reads_no_environment_and_carries_no_experiment_switches():
+    """The production surface: launch shapes are chosen through uwt_tuning, results through uwt_params — no getenv anywhere in
+    the library's sources, no UWT_EXP_* experiment branch in the kernels."""
+    csrc = os.path.join(ROOT, "uw-slam_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            txt = open(os.path.join(csrc, f)).read()
+            assert "getenv" not in txt, f
+            assert "UWT_EXP_" not in txt, f
 
 
 def test_default_params_are_the_reference_constants(capi):

@@ -38,14 +38,14 @@ def test_optional_opencv_and_eigen_branches_pass_a_syntax_check():
 
 
 @pytest.mark.gpu
-def test_shim_sequence_matches_oracle(O, synth, tmp_path):
+def test_shim_sequence_matches_oracle(O, synth, tmp_path, arith):
     exe = EXE if os.path.exists(EXE) else build_exe()
     w, h = 160, 96
     f = 525.0 * w / 640.0
     ref, tgt, _, _, _ = synth.render_pair(w, h, f, f, w / 2 - 0.5, h / 2 - 0.5, seed=77)
     raw = tmp_path / "pair.raw"
     raw.write_bytes(ref.tobytes() + tgt.tobytes())
-    out = subprocess.run([exe, str(raw), str(w), str(h)], capture_output=True, text=True, timeout=300)
+    out = subprocess.run([exe, str(raw), str(w), str(h), arith], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
     lines = {ln.split()[0]: ln.split()[1:] for ln in out.stdout.strip().splitlines()}
     vals = lines["POSE"]

@@ -68,7 +68,7 @@ def test_config2_sequential_640x480_no_depth_4x10_every_pose_is_the_oracles(synt
     trk.close()
 
 
-def test_euroc_layout_752x480_centre_crop_through_the_cli(tmp_path, synth, O):
+def test_euroc_layout_752x480_centre_crop_through_the_cli(tmp_path, synth, O, arith):
     S = importlib.import_module("uw-slam_amd.sequence")
     n, W, H, w, h = 12, 752, 480, 640, 480
     fx, fy, cx, cy = 458.654, 457.296, 367.215, 248.375           # calibration/calibrationEUROC.xml:16-21
@@ -76,7 +76,7 @@ def test_euroc_layout_752x480_centre_crop_through_the_cli(tmp_path, synth, O):
     img_dir, csv = synth.write_euroc_layout(str(tmp_path), frames, synth.camera_to_world_poses(rel))   # physical poses, as in data.csv
     out = str(tmp_path / "traj")
     text = _track_cli(["--images", img_dir, "--fx", str(fx), "--fy", str(fy), "--cx", str(cx), "--cy", str(cy),
-                       "--width", str(w), "--height", str(h), "--groundtruth", csv, "--euroc", "--out", out])
+                       "--width", str(w), "--height", str(h), "--groundtruth", csv, "--euroc", "--out", out, "--arith", arith])
     m = json.load(open(out + "_metrics.json"))
     assert m["pairs"] == n - 1 and m["failed"] == 0 and m["crop_offset"] == [56, 0] and "ATE RMSE" in text
     poses = np.load(out + "_poses.npy")
@@ -91,7 +91,7 @@ def test_euroc_layout_752x480_centre_crop_through_the_cli(tmp_path, synth, O):
     assert m["rpe_trans_rmse_m"] < 0.02 and np.isfinite(m["ate_rmse_m"]) and m["ate_rmse_m"] < 0.05
 
 
-def test_config5_tum_layout_depth_huber_through_the_cli_with_ate(tmp_path, synth, O):
+def test_config5_tum_layout_depth_huber_through_the_cli_with_ate(tmp_path, synth, O, arith):
     S = importlib.import_module("uw-slam_amd.sequence")
     T = importlib.import_module("uw-slam_amd.trajectory")
     w, h, n = 640, 480, 25
@@ -100,7 +100,7 @@ def test_config5_tum_layout_depth_huber_through_the_cli_with_ate(tmp_path, synth
     rgb, dep, gt = synth.write_tum_layout(str(tmp_path), frames, depths, c2w)
     out = str(tmp_path / "traj")
     text = _track_cli(["--images", rgb, "--depth", dep, "--fx", "525", "--fy", "525", "--cx", "319.5", "--cy", "239.5",
-                       "--weights", "huber", "--fixed-iters", "10", "--groundtruth", gt, "--tum", "--out", out])
+                       "--weights", "huber", "--fixed-iters", "10", "--groundtruth", gt, "--tum", "--out", out, "--arith", arith])
     m = json.load(open(out + "_metrics.json"))
     assert m["pairs"] == n - 1 and m["failed"] == 0 and m["iterations"] == [40] * (n - 1) and "ATE RMSE" in text
     poses = np.load(out + "_poses.npy")

@@ -140,15 +140,13 @@ def test_batched_pyramids_and_gradients_in_slots(capi, O, synth):
 @pytest.mark.parametrize("fused", [True, False])
 def test_one_launch_pyramid_and_gradient_forms(capi, O, synth, monkeypatch, shape, fused):
     """A frame or a few take their whole pyramid in one launch per plane (k_pyramid_all) and the gradients of every level in
-    one launch (k_scharr3_levels); larger sets take a launch per level (UWT_NO_FUSED_STAGES forces that form).  Same
+    one launch (k_scharr3_levels); larger sets take a launch per level (uwt_tuning::fused_stages = 0 forces that form).  Same
     integers either way: tile borders (sizes that are no multiple of 64 / 128), levels whose width is no multiple of 4
     (scalar gradient tile), 2 to 7 levels, frame ranges and the slot-list form used by the tracker."""
     w, h, levels = shape
-    if not fused:
-        monkeypatch.setenv("UWT_NO_FUSED_STAGES", "1")
     f = 525.0 * w / 640.0
     ctx = capi.Context(capi.default_params(w, h, f, f, w / 2 - 0.5, h / 2 - 0.5, n_levels=levels, first_level=levels - 1,
-                                           last_level=0, max_frames=4, max_pairs=2, has_depth=1))
+                                           last_level=0, max_frames=4, max_pairs=2, has_depth=1), tuning=dict(fused_stages=int(fused)))
     rng = np.random.default_rng(w + levels)
     frames = np.stack([synth.texture(w, h, seed=300 + s) for s in range(4)])
     frames[3] = rng.integers(0, 256, (h, w)).astype(np.uint8)       # white noise: every rounding case of the 2x2 mean
@@ -183,10 +181,9 @@ def test_batch_pyramids_in_one_pass(capi, O, monkeypatch, shape):
     frames = rng.integers(0, 256, (n, h, w)).astype(np.uint8)
     depth = rng.integers(0, 65536, (n, h, w)).astype(np.uint16)
     for switch in ("0", "1"):
-        if switch == "1":
-            monkeypatch.setenv("UWT_NO_PYRAMID_BATCH", "1")
         ctx = capi.Context(capi.default_params(w, h, f, f, w / 2 - 0.5, h / 2 - 0.5, n_levels=levels, first_level=levels - 1,
-                                               last_level=0, max_frames=n, max_pairs=2, has_depth=1))
+                                               last_level=0, max_frames=n, max_pairs=2, has_depth=1),
+                           tuning=dict(pyramid_batch=int(switch == "0")))
         ctx.upload_frames(0, frames, depth)
         ctx.build_pyramids(1, n - 1)
         for s in (1, 5, n - 1):
@@ -608,7 +605,7 @@ def test_batch_sizes_and_schedules_match_oracle(capi, O, synth, n, cfg):
                          ids=["identity", "huber", "tukey", "bilinear", "bilinear_huber"])
 def test_streamed_plane_loads_change_no_bit(capi, O, synth, monkeypatch, general):
     """A batch whose planes exceed the caches runs the STREAM twins of the accumulation kernels (non-temporal plane loads,
-    load_group).  UWT_STREAM_MB=0 makes every level of a small batch take them; UWT_STREAM_MB=1000000 none: same poses, the
+    load_group).  uwt_tuning::stream_bytes = 0 makes every level of a small batch take them; a huge value none: same poses, the
     oracle's, bit for bit.  (The batch is split over two streams: the launch path the twins are dispatched from.)"""
     w, h, n = 160, 96, 12
     over = dict(n_levels=4, first_level=3, last_level=0, max_iters=5, early_exit=0, has_depth=1, **general)
@@ -619,12 +616,10 @@ def test_streamed_plane_loads_change_no_bit(capi, O, synth, monkeypatch, general
         frames += [ref, tgt]
         depths += [dep, dep]
         cpu.append(O.align_pair(p, ref, tgt, dep)[1])
-    monkeypatch.setenv("UWT_SPLIT_MIN_PX", "1")    # two parts on two streams even at this size
-    monkeypatch.setenv("UWT_SPLIT_MIN", "2")
     got = {}
     for mb in ("0", "1000000"):
-        monkeypatch.setenv("UWT_STREAM_MB", mb)
         ctx = make_ctx(capi, w, h, MID, max_frames=2 * n, max_pairs=n, **over)
+        ctx.set_tuning(split_min_px=1, split_min=2, stream_bytes=int(mb) << 20)   # two parts on two streams even at this size
         ctx.upload_frames(0, np.stack(frames), np.stack(depths))
         ctx.build_pyramids(0, 2 * n)
         ctx.apply_gradient(0, 2 * n)
@@ -639,7 +634,7 @@ def test_streamed_plane_loads_change_no_bit(capi, O, synth, monkeypatch, general
 @pytest.mark.parametrize("weights", [1, 2], ids=["tukey", "huber"])
 def test_coarse_weighted_kernel_and_the_launches_agree(capi, O, synth, monkeypatch, weights, sched):
     """Coarse levels of the robust-weight path run in k_coarse_weighted (one block per pair: histogram, scale, weighted sums and
-    update in LDS, a level's iterations in one launch); UWT_NO_COARSE_WEIGHTED=1 keeps them on the scale / accumulation / update
+    update in LDS, a level's iterations in one launch); uwt_tuning::coarse_weighted = 0 keeps them on the scale / accumulation / update
     launches.  Same poses, same iteration counts, the oracle's — one pair per call and a batch, fixed and early-exit schedules."""
     w, h, n = 160, 96, 5
     over = dict(has_depth=1, weights=weights)
@@ -654,9 +649,8 @@ def test_coarse_weighted_kernel_and_the_launches_agree(capi, O, synth, monkeypat
         cpu.append(O.align_pair(p, ref, tgt, dep, want_trace=True))
     got = {}
     for mode in ("coarse", "launches"):
-        if mode == "launches":
-            monkeypatch.setenv("UWT_NO_COARSE_WEIGHTED", "1")
         ctx = make_ctx(capi, w, h, MID, max_frames=2 * n, max_pairs=n, **over)
+        ctx.set_tuning(coarse_weighted=int(mode == "coarse"))
         ctx.upload_frames(0, np.stack(frames), np.stack(depths))
         ctx.build_pyramids(0, 2 * n)
         ctx.apply_gradient(0, 2 * n)

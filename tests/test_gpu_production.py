@@ -170,9 +170,8 @@ def test_speculative_launching_redoes_a_cut_short_alignment(capi, O, synth, monk
     assert st == 0 and len(tr) > 8          # more than two evaluations on some level
     out = []
     for forced in (False, True):
-        if forced:
-            monkeypatch.setenv("UWT_FIRST_POLL", "1")
-        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, has_depth=1))
+        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, has_depth=1),
+                           tuning=dict(first_poll=1, persistent=0) if forced else dict(persistent=0))
         _upload_pair(ctx, ref, tgt, dep)
         poses, stats = ctx.estimate_pose_batch([0], [1], raise_on_pair_failure=True)
         out.append((poses[0].copy(), stats[0]["iterations"]))
@@ -256,7 +255,7 @@ def test_deferred_stage_calls_wait_once_per_frame(capi, O, synth):
 
 @pytest.mark.parametrize("mode", ["identity", "huber"])
 def test_split_batch_on_two_streams_gives_the_same_poses(capi, O, synth, monkeypatch, mode):
-    """Fixed-schedule batches of 16 pairs or more run as two parts on two streams (UWT_SPLIT=1: one stream).  21 pairs (an
+    """Fixed-schedule batches of 16 pairs or more run as two parts on two streams (uwt_tuning::split = 1: one stream).  21 pairs (an
     odd count: parts of 10 and 11), pyramids and gradients through uwt_track_batch_async: same poses bit for bit either way,
     and the oracle's on the pairs checked."""
     w, h, n, distinct = 320, 240, 21, 5
@@ -266,10 +265,8 @@ def test_split_batch_on_two_streams_gives_the_same_poses(capi, O, synth, monkeyp
         over["weights"] = 2
     pairs = [synth.render_pair(w, h, *intr, seed=6100 + s, max_t=0.012, max_deg=0.6, with_depth=True)[:3] for s in range(distinct)]
     results = []
-    monkeypatch.setenv("UWT_SPLIT_MIN_PX", "1")     # the test's batch is smaller than the size from which the split pays
-    for split in ("2", "1"):
-        monkeypatch.setenv("UWT_SPLIT", split)
-        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
+    for split in ("2", "1"):      # (split_min_px: the test's batch is smaller than the size from which the split pays)
+        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over), tuning=dict(split_min_px=1, split=int(split)))
         for i in range(n):
             ref, tgt, dep = pairs[i % distinct]
             ctx.upload_frames(2 * i, np.stack([ref, tgt]), np.stack([dep, dep]))
@@ -300,11 +297,9 @@ def test_split_batch_small_images_parts_at_different_levels(capi, synth, monkeyp
         frames += [ref, tgt]
     frames = np.stack(frames)
     ref_s = np.arange(n, dtype=np.int32) * 2
-    monkeypatch.setenv("UWT_SPLIT_MIN_PX", "1")
     out = {}
     for split in ("1", "2"):
-        monkeypatch.setenv("UWT_SPLIT", split)
-        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
+        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over), tuning=dict(split_min_px=1, split=int(split)))
         ctx.upload_frames(0, frames)
         runs = []
         for rep in range(1 if split == "1" else 6):
@@ -320,7 +315,7 @@ def test_split_batch_small_images_parts_at_different_levels(capi, synth, monkeyp
 @pytest.mark.parametrize("mode", ["reference", "fixed"])
 def test_coarse_levels_in_one_launch_match_the_per_launch_form(capi, O, synth, monkeypatch, mode):
     """The coarsest levels of a lone pair (those one block evaluates) run to their end in one launch, k_coarse — exit test
-    and hand-offs on the device; UWT_NO_COARSE=1 keeps a launch per evaluation.  Same poses and iteration counts, the
+    and hand-offs on the device; uwt_tuning::coarse = 0 keeps a launch per evaluation.  Same poses and iteration counts, the
     oracle's; 5 levels of 320x240: three coarse levels, then k_iterate; a pair of unrelated frames included (many
     evaluations per level, the level limit of 50 in reach)."""
     w, h = 320, 240
@@ -331,9 +326,7 @@ def test_coarse_levels_in_one_launch_match_the_per_launch_form(capi, O, synth, m
     po = O.default_params(w, h, *intr, **over)
     want = [O.align_pair(po, r, t, d, want_trace=True) for r, t, d in pairs]
     for no_coarse in (False, True):
-        if no_coarse:
-            monkeypatch.setenv("UWT_NO_COARSE", "1")
-        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, **over))
+        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, **over), tuning=dict(coarse=int(not no_coarse), persistent=0))
         for (r, t, d), (st, pose_cpu, tr) in zip(pairs, want):
             _upload_pair(ctx, r, t, d)
             poses, stats = ctx.estimate_pose_batch([0], [1])
@@ -441,21 +434,26 @@ print("ok")
 def test_update_launch_form_matches_the_tail_update():
     """Where a batch runs as two parts on two streams the Gauss-Newton update runs in the tail of the evaluation's own launch
     (tail_update_wave: the pair's last block folds the records and solves); elsewhere a k_gn_update launch follows every
-    evaluation.  UWT_TAIL_UPDATE=0 / 2 selects the launch form / the tail form everywhere.  Both forms
+    evaluation.  uwt_tuning::tail_update = 0 / 2 selects the launch form / the tail form everywhere.  Both forms
     add the records in the same order: a batch with several blocks per pair on every level — fixed schedule and the
     reference's early-exit schedule (whose polls count the pairs still iterating through the same code), identity and Huber
-    weights — gives the oracle's poses bit for bit in either form.  Child processes: the switch is read when a context is
-    created."""
+    weights — gives the oracle's poses bit for bit in either form.  (Child processes: a stalled ticket wait would otherwise
+    take the whole run with it.)"""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r'''
+    from conftest import CHILD_ARITH_HEADER
+    code = (r'''
 import importlib, sys, numpy as np
 sys.path.insert(0, %r)
+''' % root) + CHILD_ARITH_HEADER + r'''
 capi = importlib.import_module("uw-slam_amd.capi"); synth = importlib.import_module("uw-slam_amd.synth")
 from oracle import oracle as O
 import os
+tuning = dict(tail_update=int(os.environ["TEST_TAIL_UPDATE"]))
+if os.environ.get("TEST_FEW_LARGE"):
+    tuning.update(chained=0)
 if os.environ.get("TEST_FEW_LARGE"):   # two pairs of 640x480 off the chained flow: 150 records per pair at level 0 (five rounds of the tail's fold)
     w, h, intr, n = 640, 480, (525.0, 525.0, 319.5, 239.5), 2
 else:
@@ -466,7 +464,7 @@ out = []
 for over in (dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0, has_depth=1),
              dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0, has_depth=1, weights=2),
              dict(n_levels=5, first_level=4, last_level=1, max_iters=50, early_exit=1, has_depth=1)):
-    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
+    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over), tuning=tuning)
     ctx.upload_frames(0, frames, depth); ctx.build_pyramids(0, 2 * n); ctx.apply_gradient(0, 2 * n)
     for rep in range(3):
         poses, stats = ctx.estimate_pose_batch(np.arange(n) * 2, np.arange(n) * 2 + 1, raise_on_pair_failure=True)
@@ -477,8 +475,8 @@ for over in (dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_ex
             assert stats[i]["iterations"] == len(tr), (over, i)
     ctx.close()
 print("ok")
-''' % root
-    for switch, extra in (("0", {}), ("2", {}), ("2", dict(TEST_FEW_LARGE="1", UWT_CHAINED="0"))):
-        env = dict(os.environ, UWT_TAIL_UPDATE=switch, **extra)
+'''
+    for switch, extra in (("0", {}), ("2", {}), ("2", dict(TEST_FEW_LARGE="1"))):
+        env = dict(os.environ, TEST_TAIL_UPDATE=switch, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=540)
         assert r.returncode == 0 and b"ok" in r.stdout, (switch, extra, r.stderr.decode()[-2000:])

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--start", type=int, default=0); ap.add_argument("--count", type=int, default=0)
     ap.add_argument("--weights", choices=["identity", "tukey", "huber"], default="identity")
     ap.add_argument("--bilinear", action="store_true")
+    ap.add_argument("--arith", choices=["opencv", "legacy"], default="opencv", help="arithmetic set (include/uwt.h uwt_arith)")
     ap.add_argument("--fixed-iters", type=int, default=0, help="0: the reference schedule (levels 4..1, early exit)")
     ap.add_argument("--groundtruth"); ap.add_argument("--euroc", action="store_true"); ap.add_argument("--tum", action="store_true")
     ap.add_argument("--out", default="trajectory")
@@ -45,7 +46,7 @@ def main():
     _, x0, y0 = S.centre_crop(first, a.width, a.height)
     frames = [S.centre_crop(S.load_gray(n), a.width, a.height)[0] for n in names]
     depths = [S.centre_crop(S.load_depth(n), a.width, a.height)[0] for n in dnames] if dnames else None
-    over = dict(weights={"identity": 0, "tukey": 1, "huber": 2}[a.weights], sampler=int(a.bilinear))
+    over = dict(weights={"identity": 0, "tukey": 1, "huber": 2}[a.weights], sampler=int(a.bilinear), arith={"opencv": 0, "legacy": 1}[a.arith])
     if a.fixed_iters:
         over.update(n_levels=4, first_level=3, last_level=0, max_iters=a.fixed_iters, early_exit=0)
     trk = S.SequenceTracker(a.width, a.height, a.fx, a.fy, a.cx - x0, a.cy - y0, depth=bool(depths), **over)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 def build_native(force=False):
     """hipcc --offload-arch=gfx950 build of libuwt_hip.so (recipe: csrc/Makefile)."""
-    cmd = ["make", "-C", os.path.join(_HERE, "csrc")]
+    cmd = ["make", "-j%d" % max(1, min(8, os.cpu_count() or 1)), "-C", os.path.join(_HERE, "csrc")]
     if force:
         cmd.append("-B")
     subprocess.check_call(cmd)

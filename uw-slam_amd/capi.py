@@ -29,6 +29,17 @@ class Params(C.Structure):
     ]
 
 
+class Tuning(C.Structure):
+    """uwt_tuning: launch-shape switches of a context (never what is computed)."""
+    _fields_ = [
+        ("split", C.c_int32), ("split_min", C.c_int32), ("split_min_px", C.c_int64), ("stream_bytes", C.c_int64),
+        ("tail_update", C.c_int32), ("target_blocks", C.c_int32), ("coarse", C.c_int32), ("coarse_batch_px", C.c_int32),
+        ("coarse_weighted", C.c_int32), ("overlap_gradients", C.c_int32), ("first_poll", C.c_int32), ("chained", C.c_int32),
+        ("speculation", C.c_int32), ("fused_stages", C.c_int32), ("pyramid_batch", C.c_int32), ("persistent", C.c_int32),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
 class Level(C.Structure):
     _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
                 ("cx", C.c_float), ("cy", C.c_float), ("invfx", C.c_float), ("invfy", C.c_float)]
@@ -55,6 +66,7 @@ SYMBOLS = [
     "uwt_obtain_candidate_points", "uwt_obtain_candidate_points_batch", "uwt_obtain_patch_points", "uwt_add_patch_points",
     "uwt_ingest_create", "uwt_ingest_destroy", "uwt_ingest_maps", "uwt_ingest_undistort", "uwt_ingest_calculate_roi",
     "uwt_ingest_frame", "uwt_update_params", "uwt_get_params", "uwt_ls_accumulate_sse", "uwt_robust_weights",
+    "uwt_get_tuning", "uwt_set_tuning",
 ]
 
 _lib = None
@@ -166,13 +178,31 @@ def pinned_empty(shape, dtype):
 class Context:
     """Owns one uwt_ctx (device buffers + stream) — the state behind a reference `Tracker` instance."""
 
-    def __init__(self, params):
+    def __init__(self, params, tuning=None):
+        """tuning: dict of uwt_tuning fields to change from their defaults (launch shapes only; the A/B tools and the tests
+        that run one form against another use it)."""
         self.params = params
         self._h = C.c_void_p()
         st = lib().uwt_create(C.byref(params), C.byref(self._h))
         if st:
             raise UwtError(st, lib().uwt_status_string(st).decode())
         self.w, self.h = params.width, params.height
+        if tuning:
+            self.set_tuning(**tuning)
+
+    def get_tuning(self):
+        t = Tuning()
+        self._chk(lib().uwt_get_tuning(self._h, C.byref(t)))
+        return t
+
+    def set_tuning(self, **over):
+        """Change launch-shape switches of the live context (uwt_set_tuning)."""
+        t = self.get_tuning()
+        for k, v in over.items():
+            if k == "reserved" or not hasattr(t, k):
+                raise AttributeError(k)
+            setattr(t, k, int(v))
+        self._chk(lib().uwt_set_tuning(self._h, C.byref(t)))
 
     def close(self):
         if self._h:

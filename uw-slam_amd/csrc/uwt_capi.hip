@@ -13,7 +13,7 @@
 #include <string>
 #include <vector>
 
-#include "uwt_kernels.h"
+#include "uwt_launch.h"
 
 using namespace uwt;
 
@@ -23,24 +23,23 @@ struct uwt_ctx {
   uwt_params p;
   uwt_level info[UWT_MAX_LEVELS];
   LevelK lv[UWT_MAX_LEVELS];
-  int vec = 1;                          // pixels per vector group (4 when every level width is a multiple of 4)
+  int vecl[UWT_MAX_LEVELS];             // pixels per vector group at each level (level_vec: 4 where the width is a multiple of 4, else 1)
   int slices[UWT_MAX_LEVELS];
   int groups_per_block[UWT_MAX_LEVELS];
   hipStream_t stream = nullptr;
   // Side stream of uwt_track_batch_async: the gradients of the finer levels (HBM-bound) run beside the first, coarse
-  // iterations of the alignment (VALU-bound), which only read the coarsest iterated level.  UWT_OVERLAP_GRAD=0: off.
+  // iterations of the alignment (VALU-bound), which only read the coarsest iterated level (uwt_tuning::overlap_gradients).
   hipStream_t side = nullptr;
   static constexpr int kMaxParts = 4;
   int dep_first = 0, dep_n = 0;         // slot range the running tracker call depends on (track_batch_enqueue)
   hipStream_t part_stream[kMaxParts] = {};   // compute streams of parts 1.. of a split batch (part 0: `stream`)
   hipEvent_t ev_fork = nullptr, ev_join[kMaxParts] = {};
-  int split = 2;                        // parts a fixed-schedule batch is cut into (UWT_SPLIT; 1 = one stream)
-  int split_min = 8;                    // pairs per part at least (UWT_SPLIT_MIN)
-  long long stream_bytes = 200LL << 20; // a level whose planes of the whole batch exceed this is read non-temporally (UWT_STREAM_MB)
-  long long split_min_px = 32LL * 640 * 480;   // level-0 pixels of the batch at least: below, a launch is too short for a
-                                        // second stream to pay (the host enqueues twice as many) (UWT_SPLIT_MIN_PX)
+  // launch-shape switches (uwt_tuning; defaults: default_tuning()).  split: parts a fixed-schedule batch is cut into (1 = one
+  // stream); split_min: pairs per part at least; stream_bytes: a level whose planes of the whole batch exceed this is read
+  // non-temporally; split_min_px: level-0 pixels of the batch at least — below, a launch is too short for a second stream to pay
+  // (the host enqueues twice as many)
+  uwt_tuning tn;
   hipEvent_t ev_pyramids = nullptr, ev_side_done = nullptr, ev_level[UWT_MAX_LEVELS] = {};
-  bool overlap_gradients = true;
   uint8_t* img[UWT_MAX_LEVELS] = {};
   uint16_t* depth[UWT_MAX_LEVELS] = {};
   int16_t* gx[UWT_MAX_LEVELS] = {};
@@ -77,13 +76,12 @@ struct uwt_ctx {
   PairScale* scale = nullptr;           // general path: [pair]
   int* d_active = nullptr;              // early-exit polling counters
   unsigned int* d_tickets = nullptr;    // tail update: one counter per pair, zero between launches
-  int tail_update = 1;                  // the update in the tail of the residual launch instead of a k_gn_update launch: 1 = where a
-                                        // batch runs as parts on streams of their own (the tail's ~10 us of dependent round trips
-                                        // and the solve run under the other part's launches: +1.2 % at 1024 pairs, +3 % with Huber
-                                        // weights at 256; on one stream the tail is exposed at the end of every launch and loses
-                                        // ~3 us per evaluation to the update launch), 0 = never, 2 = always (UWT_TAIL_UPDATE)
-  int target_blocks = 0;                // blocks per residual launch the batch-dependent slicing aims at (UWT_TARGET_BLOCKS);
-                                        // 0: 1024 for a batch that runs as two halves (one block per slot of the chip), else 4096
+  // tn.tail_update: the update in the tail of the residual launch instead of a k_gn_update launch: 1 = where a batch runs as
+  // parts on streams of their own (the tail's ~10 us of dependent round trips and the solve run under the other part's
+  // launches: +1.2 % at 1024 pairs, +3 % with Huber weights at 256; on one stream the tail is exposed at the end of every
+  // launch and loses ~3 us per evaluation to the update launch), 0 = never, 2 = always.  tn.target_blocks: blocks per residual
+  // launch the batch-dependent slicing aims at; 0: 1024 for a batch that runs as two halves (one block per slot of the chip),
+  // else 4096
   int* h_active = nullptr;              // pinned
   void* scratch = nullptr;              // per-stage entry points
   size_t scratch_bytes = 0;
@@ -98,13 +96,9 @@ struct uwt_ctx {
   SmallResults* d_small = nullptr;      // its device address
   bool inline_pairs = false;
   bool deferred = false;                // uwt_set_deferred: stage calls return once enqueued
-  bool coarse = true;                   // k_coarse for the coarsest levels of the chained flow (UWT_NO_COARSE=1: off)
-  int coarse_batch_px = 0;              // batches: levels of up to this many pixels run in one k_coarse launch (UWT_COARSE_BATCH_PX)
   int pair_slots[4] = {0, 0, 0, 0};
-  int first_poll = 3;                   // evaluations of a level before the first early-exit read-back
   unsigned poll_seq = 0;                // batch path: read-backs alternate between two counters / events (taken one evaluation late)
   hipEvent_t ev_poll[2] = {};
-  int chained = -1;                     // -1: chained flow for a few pairs (takes_chained_flow); UWT_CHAINED=1 / 0: always / never (A/B runs)
   const uint32_t* prof_records = nullptr;
   bool compute_only = false;            // uwt_profile_enable(ctx, 2): residual launches run their no-memory diagnostic twin
   std::vector<hipEvent_t> ev_pool;      // start/stop pairs
@@ -131,19 +125,35 @@ int fail(uwt_ctx* c, int code, const std::string& msg) {
   return code;
 }
 
-// runs the statements with AR a compile-time constant: the context's arithmetic set (uwt_params::arith)
-#define UWT_WITH_ARITH(ctx, ...)                                             \
-  do {                                                                       \
-    if ((ctx)->p.arith == UWT_ARITH_LEGACY) { constexpr int AR = kArithLegacy; __VA_ARGS__; }  \
-    else { constexpr int AR = kArithOpenCV; __VA_ARGS__; }                   \
-  } while (0)
-
 #define HIPCHK(ctx, expr)                                                                                   \
   do {                                                                                                      \
     hipError_t e_ = (expr);                                                                                 \
     if (e_ != hipSuccess)                                                                                   \
       return fail(ctx, UWT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                     \
   } while (0)
+
+// the defaults of uwt_tuning (include/uwt.h); measured choices, see the comments at their uses
+uwt_tuning default_tuning() {
+  uwt_tuning t;
+  std::memset(&t, 0, sizeof(t));
+  t.split = 2;
+  t.split_min = 8;
+  t.split_min_px = 32LL * 640 * 480;
+  t.stream_bytes = 200LL << 20;
+  t.tail_update = 1;
+  t.target_blocks = 0;
+  t.coarse = 1;
+  t.coarse_batch_px = kCoarseMaxPixels;   // e.g. level 3 of 640x480: +0.8 % on the default batch; larger levels lose (2 waves / SIMD)
+  t.coarse_weighted = 1;
+  t.overlap_gradients = 1;
+  t.first_poll = 3;
+  t.chained = -1;
+  t.speculation = 1;
+  t.fused_stages = 1;
+  t.pyramid_batch = 1;
+  t.persistent = 1;
+  return t;
+}
 
 int ensure_scratch(uwt_ctx* c, size_t bytes) {
   if (bytes <= c->scratch_bytes) return UWT_OK;
@@ -241,58 +251,24 @@ int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int 
                          first_slot);
     }
   } else {
-    if (d_slots) return fail(c, UWT_ERR_INVALID_ARG, "slot lists need level widths that are multiples of 4");
     const int tiles = ((w + kGradTW - 1) / kGradTW) * ((h + kGradTH - 1) / kGradTH);
-    hipLaunchKernelGGL(k_scharr3, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src + first_slot * fs,
-                       gx + first_slot * fs, gy + first_slot * fs, w, h, fs);
+    hipLaunchKernelGGL(k_scharr3, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, fs, d_slots, first_slot);
   }
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
 }
 
-template <int AR, int VEC, bool DEPTH, bool UNIT, bool DUMP>
-void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64, bool compute_only) {
-  if constexpr (VEC == 4 && UNIT && !DUMP) {
-    if (compute_only && acc64 && a.L.fx == a.L.fy) {  // diagnostic twin of the production instantiation
-      hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
-      return;
-    }
-  }
-  if (acc64 && UNIT && VEC == 4 && !DUMP && a.L.fx == a.L.fy) {   // the production instantiation, and its streamed twin (load_group)
-    if (a.stream_planes) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, false, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
-    else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
-  } else if (acc64)
-    hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
-  else
-    hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, float>), dim3(a.slices, n_pairs), dim3(kBlock), 0, s, a);
+LaunchSel launch_sel(const uwt_ctx* c) {
+  LaunchSel sel;
+  sel.arith = c->p.arith == UWT_ARITH_LEGACY ? kArithLegacy : kArithOpenCV;
+  sel.depth = c->p.has_depth != 0;
+  sel.acc64 = c->p.accumulate_f64 != 0;
+  sel.compute_only = c->compute_only;
+  return sel;
 }
 
 int launch_residual(uwt_ctx* c, const ResidualArgs& a, int n_pairs, bool dump) {
-  const bool depth = c->p.has_depth != 0;
-  const bool unit = (a.zf == 1.0f && a.af == 1.0f);
-  const int key = (c->vec == 4 ? 8 : 0) | (depth ? 4 : 0) | (unit ? 2 : 0) | (dump ? 1 : 0);
-  hipStream_t s = c->stream;
-  const bool acc64 = c->p.accumulate_f64 != 0;
-  const bool co = c->compute_only && !dump;
-  UWT_WITH_ARITH(c,
-  switch (key) {
-    case 0: launch_residual_t<AR, 1, false, false, false>(s, a, n_pairs, acc64, co); break;
-    case 1: launch_residual_t<AR, 1, false, false, true>(s, a, n_pairs, acc64, co); break;
-    case 2: launch_residual_t<AR, 1, false, true, false>(s, a, n_pairs, acc64, co); break;
-    case 3: launch_residual_t<AR, 1, false, true, true>(s, a, n_pairs, acc64, co); break;
-    case 4: launch_residual_t<AR, 1, true, false, false>(s, a, n_pairs, acc64, co); break;
-    case 5: launch_residual_t<AR, 1, true, false, true>(s, a, n_pairs, acc64, co); break;
-    case 6: launch_residual_t<AR, 1, true, true, false>(s, a, n_pairs, acc64, co); break;
-    case 7: launch_residual_t<AR, 1, true, true, true>(s, a, n_pairs, acc64, co); break;
-    case 8: launch_residual_t<AR, 4, false, false, false>(s, a, n_pairs, acc64, co); break;
-    case 9: launch_residual_t<AR, 4, false, false, true>(s, a, n_pairs, acc64, co); break;
-    case 10: launch_residual_t<AR, 4, false, true, false>(s, a, n_pairs, acc64, co); break;
-    case 11: launch_residual_t<AR, 4, false, true, true>(s, a, n_pairs, acc64, co); break;
-    case 12: launch_residual_t<AR, 4, true, false, false>(s, a, n_pairs, acc64, co); break;
-    case 13: launch_residual_t<AR, 4, true, false, true>(s, a, n_pairs, acc64, co); break;
-    case 14: launch_residual_t<AR, 4, true, true, false>(s, a, n_pairs, acc64, co); break;
-    default: launch_residual_t<AR, 4, true, true, true>(s, a, n_pairs, acc64, co); break;
-  });
+  uwt::launch_residual(c->stream, launch_sel(c), a, n_pairs, dump);
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
 }
@@ -358,90 +334,17 @@ GeneralArgs general_args(uwt_ctx* c) {
   return ga;
 }
 
-// One residual evaluation on the general path (robust weights and/or bilinear sampler) for pairs [pair_base, +n):
-// with weights on, one histogram pass estimates the scale first (MedianMat / MedianAbsoluteDeviation,
-// src/Tracker.cpp:1571-1619), then the weighted accumulation runs.  Records use one pixel per point and 8192 per block.
-template <int AR, int VEC, bool DEPTH, bool UNIT>
-void launch_general_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sampler, int weights) {
-  const dim3 grid(a.slices, n_pairs), blk(kBlock);
-  const int key = sampler * 3 + weights;
-  if constexpr (VEC == 4 && UNIT) {
-    if (a.L.fx == a.L.fy) {   // SQUARE: the Jacobian's coinciding products once (pixel_jacobian), as on the identity path
-      if (a.stream_planes) {   // the streamed twins (load_group)
-        switch (key) {
-          case 1: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 1, false, true>), grid, blk, 0, s, a); break;
-          case 2: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 2, false, true>), grid, blk, 0, s, a); break;
-          case 3: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 1, 0, false, true>), grid, blk, 0, s, a); break;
-          default:
-            if constexpr (AR == kArithOpenCV) hipLaunchKernelGGL((k_residual_w4<AR, VEC, DEPTH, UNIT, false, double, true, 1, 2, true>), grid, blk, 0, s, a);
-            else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 1, 2, false, true>), grid, blk, 0, s, a);
-            break;
-        }
-        return;
-      }
-      switch (key) {
-        case 1: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 1>), grid, blk, 0, s, a); break;
-        case 2: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 0, 2>), grid, blk, 0, s, a); break;
-        case 3: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 1, 0>), grid, blk, 0, s, a); break;
-        default:   // bilinear + Huber: 129 registers under the OpenCV set, held to 128 (one value parked in scratch outside the loop)
-          if constexpr (AR == kArithOpenCV) hipLaunchKernelGGL((k_residual_w4<AR, VEC, DEPTH, UNIT, false, double, true, 1, 2>), grid, blk, 0, s, a);
-          else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, true, 1, 2>), grid, blk, 0, s, a);
-          break;
-      }
-      return;
-    }
-  }
-  switch (key) {
-    case 1: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 0, 1>), grid, blk, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 0, 2>), grid, blk, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 1, 0>), grid, blk, 0, s, a); break;
-    default: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 1, 2>), grid, blk, 0, s, a); break;
-  }
-}
-
-// The alignment loop's launch on the general path: the scale pass (weights only), then the dense kernel specialised for
-// the sampler / weights.  Same slicing as the fast path.
+// One residual evaluation on the general path (robust weights and/or bilinear sampler): with weights on, one histogram pass
+// estimates the scale first (MedianMat / MedianAbsoluteDeviation, src/Tracker.cpp:1571-1619), then the weighted accumulation runs.
 int launch_general(uwt_ctx* c, const ResidualArgs& ra, int n_pairs) {
-  const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f);
-  GeneralArgs ga = general_args(c);
-  if (ga.weights) {
-    // the scale pass: residual histograms per pair, the scale derived in the tail of the pair's last block; the histograms
-    // are all-zero before and after (cleared once per alignment call, enqueue_estimate)
-    const dim3 grid(ra.slices, n_pairs), blk(kBlock);
-    const int hk = (c->vec == 4 ? 4 : 0) | (depth ? 2 : 0) | (ga.sampler ? 1 : 0);
-    UWT_WITH_ARITH(c,
-    switch (hk) {
-      case 0: hipLaunchKernelGGL((k_resid_hist_v<AR, 1, false, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 1: hipLaunchKernelGGL((k_resid_hist_v<AR, 1, false, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 2: hipLaunchKernelGGL((k_resid_hist_v<AR, 1, true, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 3: hipLaunchKernelGGL((k_resid_hist_v<AR, 1, true, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 4: hipLaunchKernelGGL((k_resid_hist_v<AR, 4, false, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 5: hipLaunchKernelGGL((k_resid_hist_v<AR, 4, false, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      case 6: hipLaunchKernelGGL((k_resid_hist_v<AR, 4, true, 0>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-      default: hipLaunchKernelGGL((k_resid_hist_v<AR, 4, true, 1>), grid, blk, 0, c->stream, ra, c->hist, c->scale, ga.weights); break;
-    });
-    HIPCHK(c, hipGetLastError());
-  }
-  const int key = (c->vec == 4 ? 4 : 0) | (depth ? 2 : 0) | (unit ? 1 : 0);
-  hipStream_t s = c->stream;
-  UWT_WITH_ARITH(c,
-  switch (key) {
-    case 0: launch_general_t<AR, 1, false, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 1: launch_general_t<AR, 1, false, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 2: launch_general_t<AR, 1, true, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 3: launch_general_t<AR, 1, true, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 4: launch_general_t<AR, 4, false, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 5: launch_general_t<AR, 4, false, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    case 6: launch_general_t<AR, 4, true, false>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-    default: launch_general_t<AR, 4, true, true>(s, ra, n_pairs, ga.sampler, ga.weights); break;
-  });
+  uwt::launch_general(c->stream, launch_sel(c), ra, n_pairs, c->p.sampler, c->p.weights, c->hist, c->scale);
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
 }
 
-// The per-stage (dump-capable) form of the same evaluation: k_residual_general, one pixel per thread step.
+// The per-stage (dump-capable) form of the same evaluation: k_residual_general, one pixel per thread step.  Records use one
+// pixel per point and 8192 per block.
 int launch_general_dump(uwt_ctx* c, ResidualArgs ra, int n_pairs, int* slices_out = nullptr) {
-  const bool depth = c->p.has_depth != 0, unit = (ra.zf == 1.0f && ra.af == 1.0f);
   GeneralArgs ga = general_args(c);
   // pixels per record: 8192, or more where the level's create-time slicing (whose record count sized `partials`) is
   // coarser than that — very large levels, where init raises the groups per thread to stay under kMaxSlices
@@ -452,21 +355,9 @@ int launch_general_dump(uwt_ctx* c, ResidualArgs ra, int n_pairs, int* slices_ou
   ra.slices = (ra.L.n + ra.groups_per_block - 1) / ra.groups_per_block;
   if ((size_t)ra.slices * n_pairs > c->partial_records) return fail(c, UWT_ERR_CAPACITY, "per-stage dump needs more partial records than the context holds");
   if (slices_out) *slices_out = ra.slices;
-  const dim3 grid(ra.slices, n_pairs), blk(kBlock);
-  if (ga.weights) {
+  if (ga.weights)
     HIPCHK(c, hipMemsetAsync(c->hist + (size_t)ra.pair_base * kHistBins, 0, sizeof(unsigned int) * kHistBins * n_pairs, c->stream));
-    UWT_WITH_ARITH(c,
-      if (depth) hipLaunchKernelGGL((k_resid_hist<AR, true>), grid, blk, 0, c->stream, ra, ga);
-      else hipLaunchKernelGGL((k_resid_hist<AR, false>), grid, blk, 0, c->stream, ra, ga));
-    HIPCHK(c, hipGetLastError());
-    hipLaunchKernelGGL(k_scale_stage, dim3((n_pairs + 3) / 4), dim3(256), 0, c->stream, ga, ra.state, n_pairs, ra.pair_base);
-    HIPCHK(c, hipGetLastError());
-  }
-  UWT_WITH_ARITH(c,
-    if (depth && unit) hipLaunchKernelGGL((k_residual_general<AR, true, true>), grid, blk, 0, c->stream, ra, ga);
-    else if (depth) hipLaunchKernelGGL((k_residual_general<AR, true, false>), grid, blk, 0, c->stream, ra, ga);
-    else if (unit) hipLaunchKernelGGL((k_residual_general<AR, false, true>), grid, blk, 0, c->stream, ra, ga);
-    else hipLaunchKernelGGL((k_residual_general<AR, false, false>), grid, blk, 0, c->stream, ra, ga));
+  uwt::launch_general_dump(c->stream, launch_sel(c), ra, ga, n_pairs);
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
 }
@@ -500,27 +391,8 @@ void arm_tail(uwt_ctx* c, ResidualArgs& ra, const UpdateArgs& ua) {
   ra.tail.gain = ua.gain;
 }
 
-// k_iterate launch for the dense nearest-neighbour / identity-weights path (VEC = 4)
-template <int AR, bool DEPTH, bool UNIT>
-void launch_iterate_t(hipStream_t s, const ResidualArgs& a, const IterArgs& ia, int n_pairs, bool acc64, bool compute_only) {
-  const dim3 grid(a.slices, n_pairs), blk(kBlock);
-  const bool square = a.L.fx == a.L.fy;
-  const bool wide = n_pairs > 3;   // four blocks per CU (two-pass reduction) instead of blocks alone on their CUs
-  if (acc64 && square && UNIT && compute_only) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, double, true, true>), grid, blk, 0, s, a, ia);
-  else if (acc64 && square && UNIT && wide) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, double, true, false, 14>), grid, blk, 0, s, a, ia);
-  else if (acc64 && square && UNIT) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, double, true>), grid, blk, 0, s, a, ia);
-  else if (acc64 && wide) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, double, false, false, 14>), grid, blk, 0, s, a, ia);
-  else if (acc64) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, double, false>), grid, blk, 0, s, a, ia);
-  else hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, UNIT, float, false>), grid, blk, 0, s, a, ia);
-}
-
 int launch_iterate(uwt_ctx* c, const ResidualArgs& a, const IterArgs& ia, int n_pairs) {
-  const bool depth = c->p.has_depth != 0, unit = (a.zf == 1.0f && a.af == 1.0f), acc64 = c->p.accumulate_f64 != 0;
-  UWT_WITH_ARITH(c,
-    if (depth && unit) launch_iterate_t<AR, true, true>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
-    else if (depth) launch_iterate_t<AR, true, false>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
-    else if (unit) launch_iterate_t<AR, false, true>(c->stream, a, ia, n_pairs, acc64, c->compute_only);
-    else launch_iterate_t<AR, false, false>(c->stream, a, ia, n_pairs, acc64, c->compute_only));
+  uwt::launch_iterate(c->stream, launch_sel(c), a, ia, n_pairs);
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
 }
@@ -550,21 +422,20 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
   // take plus one, nothing is read back, and the level switch notes on the device whether a pair was cut short — the
   // caller looks once, behind the results, and redoes the alignment the careful way in that (rare) case.
   const bool speculate = c->speculate && p.early_exit;
-  const int spec_iters = std::min(p.max_iters, c->first_poll + 1);
+  const int spec_iters = std::min(p.max_iters, c->tn.first_poll + 1);
   ia.cut_short = speculate ? &c->d_small->cut : nullptr;
   if (speculate) c->h_small->cut = 0;   // host store into page-locked memory, ahead of the launches that may set it
   ia.inline_pairs = c->inline_pairs ? 1 : 0;
   for (int i = 0; i < 4; i++) ia.pair_slots[i] = c->pair_slots[i];
-  // The coarsest levels — those a single block evaluates — run to their end in one launch (k_coarse): default constants
-  // of the dense path only (f64 sums, unit factors, square pixels), at least one finer level left for k_iterate.
+  // The coarsest levels — those a single block evaluates, rows of whole groups of four — run to their end in one launch
+  // (k_coarse), at least one finer level left for k_iterate.
   int start_lvl = p.first_level;
   bool after_coarse = false;
   {
-    const LevelK& L0 = c->lv[p.first_level];
-    const bool plain = p.accumulate_f64 != 0 && p.z_factor == 1.0f && p.angle_factor == 1.0f && L0.fx == L0.fy;
     int nc = 0;
-    while (nc < kCoarseMaxLevels && start_lvl - nc > p.last_level && c->lv[start_lvl - nc].n <= kCoarseMaxPixels) nc++;
-    if (nc > 0 && plain && c->coarse && !c->profiling && !c->compute_only) {
+    while (nc < kCoarseMaxLevels && start_lvl - nc > p.last_level && c->lv[start_lvl - nc].n <= kCoarseMaxPixels &&
+           c->vecl[start_lvl - nc] == 4) nc++;
+    if (nc > 0 && c->tn.coarse && !c->profiling && !c->compute_only) {
       CoarseArgs ca;
       std::memset(&ca, 0, sizeof(ca));
       for (int i = 0; i < nc; i++) {
@@ -581,9 +452,7 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
       ca.initial_error = ia.initial_error;
       ca.inline_pairs = ia.inline_pairs;
       for (int i = 0; i < 4; i++) ca.pair_slots[i] = ia.pair_slots[i];
-      UWT_WITH_ARITH(c,
-        if (p.has_depth) hipLaunchKernelGGL((k_coarse<AR, true, true, double, true>), dim3(n_pairs), dim3(kBlock), 0, c->stream, ca);
-        else hipLaunchKernelGGL((k_coarse<AR, false, true, double, true>), dim3(n_pairs), dim3(kBlock), 0, c->stream, ca));
+      uwt::launch_coarse_chain(c->stream, launch_sel(c), ca, n_pairs);
       HIPCHK(c, hipGetLastError());
       start_lvl = p.first_level - nc;
       after_coarse = true;
@@ -594,14 +463,14 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
     ResidualArgs ra = residual_args(c, lvl);
     ra.state = nullptr;
     {  // slicing follows the batch, as in enqueue_estimate
-      const int n_groups = c->lv[lvl].n / c->vec;
-      int want = ((c->target_blocks ? c->target_blocks : 4096) + n_pairs - 1) / n_pairs;
+      const int n_groups = c->lv[lvl].n / c->vecl[lvl];
+      int want = ((c->tn.target_blocks ? c->tn.target_blocks : 4096) + n_pairs - 1) / n_pairs;
       want = std::max(1, std::min(want, c->slices[lvl]));
       const int gpt = (n_groups + want * kBlock - 1) / (want * kBlock);
       ra.groups_per_block = gpt * kBlock;
       ra.slices = (n_groups + ra.groups_per_block - 1) / ra.groups_per_block;
     }
-    int next_poll = c->first_poll;   // see enqueue_estimate
+    int next_poll = c->tn.first_poll;   // see enqueue_estimate
     int k = 0;
     for (; k < (speculate ? spec_iters : p.max_iters); k++) {
       ia.mode = first ? (after_coarse ? 3 : 0) : (k == 0 ? 2 : 1);
@@ -658,33 +527,9 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
   // The final state lands in whichever of the two buffers the last evaluation did not read (that depends on the parity of
   // the launch count); nothing reads either buffer after a chained call — results leave through d_poses / d_stats.
   ia.state_out = ia.state_in == c->state ? c->state2 : c->state;
-  hipLaunchKernelGGL(k_finish, dim3(n_pairs), dim3(kUpdateBlock), 0, c->stream, ia, d_poses, d_stats);
+  uwt::launch_finish(c->stream, ia, n_pairs, d_poses, d_stats);
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
-}
-
-// one coarse level of a batch (one block per pair, the level's iterations in one launch): identity weights k_coarse_w4, robust
-// weights over the nearest sampler k_coarse_weighted
-template <int AR>
-void launch_coarse_level(hipStream_t s, const CoarseArgs& ca, int cnt, bool depth, bool general, int weights) {
-  const dim3 grid(cnt), blk(kBlock);
-  if (general) {
-    if (weights == kWeightsTukeyRef) {
-      if (depth) hipLaunchKernelGGL((k_coarse_weighted<AR, true, kWeightsTukeyRef, 1>), grid, blk, 0, s, ca);
-      else hipLaunchKernelGGL((k_coarse_weighted<AR, false, kWeightsTukeyRef, 1>), grid, blk, 0, s, ca);
-    } else {
-      if (depth) hipLaunchKernelGGL((k_coarse_weighted<AR, true, kWeightsHuber, 1>), grid, blk, 0, s, ca);
-      else hipLaunchKernelGGL((k_coarse_weighted<AR, false, kWeightsHuber, 1>), grid, blk, 0, s, ca);
-    }
-    return;
-  }
-#ifdef UWT_EXP_NO_W4
-  if (depth) hipLaunchKernelGGL((k_coarse<AR, true, true, double, true, 14, 1>), grid, blk, 0, s, ca);
-  else hipLaunchKernelGGL((k_coarse<AR, false, true, double, true, 14, 1>), grid, blk, 0, s, ca);
-#else
-  if (depth) hipLaunchKernelGGL((k_coarse_w4<AR, true, true, double, true, 14, 1>), grid, blk, 0, s, ca);
-  else hipLaunchKernelGGL((k_coarse_w4<AR, false, true, double, true, 14, 1>), grid, blk, 0, s, ca);
-#endif
 }
 
 // Tracker::EstimatePose for a batch, enqueued on the context's stream (src/Tracker.cpp:362-597)
@@ -694,7 +539,7 @@ void launch_coarse_level(hipStream_t s, const CoarseArgs& ca, int cnt, bool dept
 // the launches between two read-backs), level from there on (UWT_CHAINED=1 / 0 force it on / off for A/B runs).
 static bool takes_chained_flow(const uwt_ctx* c, int n_pairs) {
   const int few = c->p.early_exit ? 16 : 6;
-  return c->vec == 4 && c->p.sampler == 0 && c->p.weights == 0 && (c->chained > 0 || (c->chained < 0 && n_pairs <= few));
+  return c->p.accumulate_f64 != 0 && c->p.sampler == 0 && c->p.weights == 0 && (c->tn.chained > 0 || (c->tn.chained < 0 && n_pairs <= few));
 }
 
 int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats, const hipEvent_t* level_ready = nullptr) {
@@ -706,11 +551,11 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   // over the chip; a batch that fills it alone runs fewer, longer blocks (less reduction overhead per pixel, fewer
   // records to fold), still at least target_blocks per launch.
   // (early-exit schedules stay on one stream: interleaving the two halves' read-backs was built and gave +1.7 %)
-  const int parts = (p.early_exit || c->profiling || (long long)n_pairs * c->lv[0].n < c->split_min_px)
-                        ? 1 : std::min(c->split, n_pairs / std::max(1, c->split_min));
-  const int target_blocks = c->target_blocks ? c->target_blocks : (parts >= 2 ? 1024 : 4096);
+  const int parts = (p.early_exit || c->profiling || (long long)n_pairs * c->lv[0].n < c->tn.split_min_px)
+                        ? 1 : std::min(c->tn.split, n_pairs / std::max(1, c->tn.split_min));
+  const int target_blocks = c->tn.target_blocks ? c->tn.target_blocks : (parts >= 2 ? 1024 : 4096);
   auto slicing = [&](int lvl, int& groups_per_block, int& slices) {
-    const int n_groups = c->lv[lvl].n / c->vec;
+    const int n_groups = c->lv[lvl].n / c->vecl[lvl];
     int want = (target_blocks + n_pairs - 1) / n_pairs;
     want = std::max(1, std::min(want, c->slices[lvl]));
     // Fixed schedules (every pair stays to the level's end): a block should also be long enough to carry its fixed costs — the
@@ -728,9 +573,9 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   };
   // the accumulation kernels stream a level's reference planes past the caches (ResidualArgs::stream_planes) when the batch's
   // planes of that level — u8 + 2 x i16 [+ u16] per reference pixel, the target's u8 — exceed what the 256 MB memory-side cache
-  // holds across an evaluation; a smaller batch finds them there again at the next evaluation (UWT_STREAM_MB: the threshold)
+  // holds across an evaluation; a smaller batch finds them there again at the next evaluation (uwt_tuning::stream_bytes)
   auto streams = [&](int lvl) -> int {
-    return (long long)n_pairs * c->lv[lvl].n * (p.has_depth ? 8 : 6) > c->stream_bytes ? 1 : 0;
+    return (long long)n_pairs * c->lv[lvl].n * (p.has_depth ? 8 : 6) > c->tn.stream_bytes ? 1 : 0;
   };
   int smax = 1;
   for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
@@ -742,64 +587,59 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   // pass leaves them so (k_resid_hist_v)
   if (general && p.weights)
     HIPCHK(c, hipMemsetAsync(c->hist, 0, sizeof(unsigned int) * kHistBins * n_pairs, c->stream));
-  // The coarsest levels of a batch in ONE launch (round 3): one block per pair runs each of them to its end — evaluation,
-  // update, exit test and hand-off on the device, the record in LDS (k_coarse, four blocks per CU) — instead of a residual
-  // and an update launch per evaluation whose blocks, a few pixel groups long, run 25-50 % below the level-0 rate.  Dense
-  // path with the default constants (f64 sums, unit factors, square pixels); levels of up to coarse_batch_px pixels.
-  int n_coarse = 0;
-  {
-    const LevelK& L0 = c->lv[p.first_level];
-    const bool shape = c->vec == 4 && p.accumulate_f64 != 0 && p.z_factor == 1.0f && p.angle_factor == 1.0f && L0.fx == L0.fy;
-    // identity weights: k_coarse_w4; robust weights over the nearest sampler: k_coarse_weighted (histogram, scale, weighted
-    // sums and update of a whole level in one block).  The bilinear sampler stays on the launches.
-    const bool plain = shape && (!general || (p.sampler == 0 && p.weights != 0 && !std::getenv("UWT_NO_COARSE_WEIGHTED")));
-    if (plain && c->coarse_batch_px > 0 && !c->compute_only && !(c->profiling && p.early_exit))
-      while (n_coarse < kCoarseMaxLevels && p.first_level - n_coarse >= p.last_level &&
-             c->lv[p.first_level - n_coarse].n <= c->coarse_batch_px) n_coarse++;
-  }
-  auto run_coarse = [&](int base, int cnt, hipStream_t s) -> int {
-    for (int i = 0; i < n_coarse; i++) {   // a launch per level (one level per launch: 4 waves / SIMD), each to the level's end
-      const int lvl = p.first_level - i;
-      if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(s, level_ready[lvl], 0));  // its gradients
-      CoarseArgs ca;
-      std::memset(&ca, 0, sizeof(ca));
-      ca.lv[0] = residual_args(c, lvl);
-      ca.lv[0].state = nullptr;
-      ca.level_id[0] = lvl;
-      ca.n_levels = 1;
-      UpdateArgs u = update_args(c, lvl);
-      u.pair_base = base;
-      ca.u = u;
-      ca.state_out = c->state;
-      ca.scale_t = p.handoff_scale_t;
-      ca.initial_error = p.initial_error;
-      ca.resume = i > 0;
-      size_t ev = 0;
-      if (c->profiling) {
-        int st = prof_begin(c, &ev, lvl, p.max_iters);
-        if (st) return st;
-      }
-      UWT_WITH_ARITH(c, launch_coarse_level<AR>(s, ca, cnt, p.has_depth != 0, general, p.weights));
-      HIPCHK(c, hipGetLastError());
-      if (c->profiling) {   // (fixed schedules only: the level runs max_iters evaluations; the launch stands for that many)
-        HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], s));
-        c->prof_launches += p.max_iters;
-        c->prof_pixels += (long long)cnt * c->lv[lvl].n * p.max_iters;
-      }
+  // The coarsest levels of a batch in ONE launch each (round 3): one block per pair runs the level to its end — evaluation,
+  // update, exit test and hand-off on the device, the record in LDS (four blocks per CU) — instead of a residual and an update
+  // launch per evaluation whose blocks, a few pixel groups long, run 25-50 % below the level-0 rate.  f64 sums, levels of up to
+  // coarse_batch_px pixels whose rows are whole groups of four (others stay on the launches); identity weights: k_coarse_w4;
+  // robust weights over the nearest sampler: k_coarse_weighted (histogram, scale, weighted sums and update of a whole level in
+  // one block); the bilinear sampler stays on the launches.  Square pixels with unit factors or not: the kernels' PLAIN switch.
+  bool coarse_lvl[UWT_MAX_LEVELS] = {};
+  if (p.accumulate_f64 != 0 && (!general || (p.sampler == 0 && p.weights != 0 && c->tn.coarse_weighted)) && c->tn.coarse_batch_px > 0 &&
+      !c->compute_only && !(c->profiling && p.early_exit))
+    for (int lvl = p.first_level; lvl >= p.last_level; lvl--)
+      coarse_lvl[lvl] = c->vecl[lvl] == 4 && c->lv[lvl].n <= c->tn.coarse_batch_px;
+  // one coarse level of pairs [base, base + cnt) on stream s; resume: the pairs' states exist (a level ran before this one)
+  auto run_coarse = [&](int base, int cnt, hipStream_t s, int lvl, bool resume) -> int {
+    CoarseArgs ca;
+    std::memset(&ca, 0, sizeof(ca));
+    ca.lv[0] = residual_args(c, lvl);
+    ca.lv[0].state = nullptr;
+    ca.level_id[0] = lvl;
+    ca.n_levels = 1;
+    UpdateArgs u = update_args(c, lvl);
+    u.pair_base = base;
+    ca.u = u;
+    ca.state_out = c->state;
+    ca.scale_t = p.handoff_scale_t;
+    ca.initial_error = p.initial_error;
+    ca.resume = resume ? 1 : 0;
+    size_t ev = 0;
+    if (c->profiling) {
+      int st = prof_begin(c, &ev, lvl, p.max_iters);
+      if (st) return st;
+    }
+    uwt::launch_coarse_level(s, launch_sel(c), ca, cnt, general ? p.weights : 0);
+    HIPCHK(c, hipGetLastError());
+    if (c->profiling) {   // (fixed schedules only: the level runs max_iters evaluations; the launch stands for that many)
+      HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], s));
+      c->prof_launches += p.max_iters;
+      c->prof_pixels += (long long)cnt * c->lv[lvl].n * p.max_iters;
     }
     return UWT_OK;
   };
   // the schedule for pairs [base, base + cnt) of a batch of n_pairs, on c->stream
   auto run = [&](int base, int cnt) -> int {
-    if (n_coarse > 0) {
-      int st = run_coarse(base, cnt, c->stream);
-      if (st) return st;
-    } else {
+    if (!coarse_lvl[p.first_level]) {
       hipLaunchKernelGGL(k_init_state, dim3((cnt + tb - 1) / tb), dim3(tb), 0, c->stream, c->state + base, cnt, p.initial_error);
       HIPCHK(c, hipGetLastError());
     }
-    for (int lvl = p.first_level - n_coarse; lvl >= p.last_level; lvl--) {
+    for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
       if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(c->stream, level_ready[lvl], 0));  // its gradients
+      if (coarse_lvl[lvl]) {
+        int stc = run_coarse(base, cnt, c->stream, lvl, lvl != p.first_level);
+        if (stc) return stc;
+        continue;
+      }
       ResidualArgs ra = residual_args(c, lvl);
       UpdateArgs ua = update_args(c, lvl);
       ra.pair_base = base;
@@ -820,7 +660,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
       // behind its update, evaluation k + 1 is enqueued, and only then does the host wait for the copy — the GPU works on
       // k + 1 meanwhile instead of idling for the host's round trip (~25 us per look).  When the count says "nobody left",
       // evaluation k + 1 has been enqueued for nothing: its blocks see level_done and return at once (a few us).
-      int next_poll = c->first_poll;
+      int next_poll = c->tn.first_poll;
       int pending = -1;   // slot of the look not yet taken
       for (int k = 0; k < p.max_iters; k++) {
         size_t ev = 0;
@@ -838,7 +678,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         const int slot = c->poll_seq & 1;
         ua.active = poll ? c->d_active + slot : nullptr;
         if (poll) HIPCHK(c, hipMemsetAsync(c->d_active + slot, 0, sizeof(int), c->stream));
-        const bool tail = c->tail_update >= 2 && !c->compute_only;   // (one stream: only when forced, see tail_update)
+        const bool tail = c->tn.tail_update >= 2 && !c->compute_only;   // (one stream: only when forced, see tail_update)
         if (tail) arm_tail(c, ra, ua);
         int st = general ? launch_general(c, ra, cnt) : launch_residual(c, ra, cnt, false);
         if (st) return st;
@@ -880,7 +720,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   // three parts gain nothing more, four lose (measured).  Results do not depend on it (a pair's blocks, records and state
   // are its own; the slicing is the whole batch's).
   if (parts < 2) {
-    if (c->tail_update >= 2) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, sizeof(unsigned int) * (size_t)n_pairs, c->stream));
+    if (c->tn.tail_update >= 2) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, sizeof(unsigned int) * (size_t)n_pairs, c->stream));
     return run(0, n_pairs);
   }
   // (fixed schedule, not profiled: no read-backs, no events around launches).  The parts' launches are enqueued in turns,
@@ -899,7 +739,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
     }
   } guard{c, parts, main_stream};
   // (the pairs' ticket counters are zero between launches by construction; a call that an error cut short may have left some)
-  if (c->tail_update >= 1) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, sizeof(unsigned int) * (size_t)n_pairs, main_stream));
+  if (c->tn.tail_update >= 1) HIPCHK(c, hipMemsetAsync(c->d_tickets, 0, sizeof(unsigned int) * (size_t)n_pairs, main_stream));
   HIPCHK(c, hipEventRecord(c->ev_fork, main_stream));
   for (int i = 0; i < parts; i++) {
     Part& q = pt[i];
@@ -907,16 +747,20 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
     q.cnt = (int)((long long)n_pairs * (i + 1) / parts) - q.base;
     q.s = i ? c->part_stream[i] : main_stream;
     if (i) HIPCHK(c, hipStreamWaitEvent(q.s, c->ev_fork, 0));
-    if (n_coarse > 0) {
-      int stc = run_coarse(q.base, q.cnt, q.s);
-      if (stc) return stc;
-    } else {
+    if (!coarse_lvl[p.first_level])
       hipLaunchKernelGGL(k_init_state, dim3((q.cnt + tb - 1) / tb), dim3(tb), 0, q.s, c->state + q.base, q.cnt, p.initial_error);
-    }
   }
   HIPCHK(c, hipGetLastError());
   int st = UWT_OK;
-  for (int lvl = p.first_level - n_coarse; lvl >= p.last_level && st == UWT_OK; lvl--) {
+  for (int lvl = p.first_level; lvl >= p.last_level && st == UWT_OK; lvl--) {
+    if (coarse_lvl[lvl]) {
+      for (int i = 0; i < parts; i++) {
+        if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(pt[i].s, level_ready[lvl], 0));  // its gradients
+        int stc = run_coarse(pt[i].base, pt[i].cnt, pt[i].s, lvl, lvl != p.first_level);
+        if (stc) return stc;
+      }
+      continue;
+    }
     for (int i = 0; i < parts; i++) {
       Part& q = pt[i];
       if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(q.s, level_ready[lvl], 0));  // its gradients
@@ -939,7 +783,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         Part& q = pt[i];
         q.ua.k = k;
         q.ua.active = nullptr;
-        const bool tail = c->tail_update >= 1 && !c->compute_only;   // the update in the tail of the evaluation's launch
+        const bool tail = c->tn.tail_update >= 1 && !c->compute_only;   // the update in the tail of the evaluation's launch
         if (tail) arm_tail(c, q.ra, q.ua);
         c->stream = q.s;      // every launch helper enqueues on c->stream
         st = general ? launch_general(c, q.ra, q.cnt) : launch_residual(c, q.ra, q.cnt, false);
@@ -1089,10 +933,6 @@ int uwt_default_params(uwt_params* p, int32_t width, int32_t height, float fx, f
   p->max_pairs = 1;
   p->device = 0;
   p->arith = UWT_ARITH_OPENCV;
-  // UWT_ARITH=legacy: the default of processes that take their parameters from here (A/B runs, the parity suite's children)
-  if (const char* e = std::getenv("UWT_ARITH")) {
-    if (!std::strcmp(e, "legacy")) p->arith = UWT_ARITH_LEGACY;
-  }
   return UWT_OK;
 }
 
@@ -1118,14 +958,12 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   if (!c) return UWT_ERR_CAPACITY;
   c->p = *p;
   init_levels(c);
-  c->vec = 4;
-  for (int l = 0; l < p->n_levels; l++)
-    if (c->lv[l].w % 4) c->vec = 1;
+  c->tn = default_tuning();
   size_t max_slices = 1;
   for (int l = 0; l < p->n_levels; l++) {
-    const int n_groups = c->lv[l].n / c->vec;
-    int gpt = std::max(kGroupsPerThread, (n_groups + kMaxSlices * kBlock - 1) / (kMaxSlices * kBlock));
-    if (const char* e = std::getenv("UWT_GROUPS_PER_THREAD")) gpt = std::max(1, std::atoi(e));  // tuning experiments only
+    c->vecl[l] = level_vec(c->lv[l]);   // per level: only the levels whose rows are not whole groups of four go pixel by pixel
+    const int n_groups = c->lv[l].n / c->vecl[l];
+    const int gpt = std::max(kGroupsPerThread, (n_groups + kMaxSlices * kBlock - 1) / (kMaxSlices * kBlock));
     c->groups_per_block[l] = kBlock * gpt;
     c->slices[l] = (n_groups + c->groups_per_block[l] - 1) / c->groups_per_block[l];
     if ((size_t)c->slices[l] > max_slices) max_slices = c->slices[l];
@@ -1149,13 +987,6 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
     CREATE_CHK(hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming));
   }
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
-  if (const char* e = std::getenv("UWT_SPLIT")) c->split = std::max(1, std::min(uwt_ctx::kMaxParts, std::atoi(e)));
-  if (std::getenv("UWT_NO_COARSE")) c->coarse = false;
-  c->coarse_batch_px = kCoarseMaxPixels;   // e.g. level 3 of 640x480: +0.8 % on the default batch; larger levels lose (2 waves / SIMD)
-  if (const char* e = std::getenv("UWT_COARSE_BATCH_PX")) c->coarse_batch_px = std::max(0, std::atoi(e));
-  if (const char* e = std::getenv("UWT_SPLIT_MIN")) c->split_min = std::max(1, std::atoi(e));
-  if (const char* e = std::getenv("UWT_STREAM_MB")) c->stream_bytes = std::max(0LL, std::atoll(e)) << 20;
-  if (const char* e = std::getenv("UWT_SPLIT_MIN_PX")) c->split_min_px = std::max(1LL, std::atoll(e));
   CREATE_CHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
   for (int i = 0; i < uwt_ctx::kDeps; i++) {
     CREATE_CHK(hipEventCreateWithFlags(&c->busy[i].ev, hipEventDisableTiming));
@@ -1165,9 +996,6 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_pyramids, hipEventDisableTiming));
   CREATE_CHK(hipEventCreateWithFlags(&c->ev_side_done, hipEventDisableTiming));
   for (int l = 0; l < UWT_MAX_LEVELS; l++) CREATE_CHK(hipEventCreateWithFlags(&c->ev_level[l], hipEventDisableTiming));
-  if (const char* e = std::getenv("UWT_OVERLAP_GRAD")) c->overlap_gradients = std::atoi(e) != 0;
-  if (const char* e = std::getenv("UWT_FIRST_POLL")) c->first_poll = std::max(1, std::atoi(e));
-  if (const char* e = std::getenv("UWT_CHAINED")) c->chained = std::atoi(e) != 0 ? 1 : 0;
   for (int l = 0; l < p->n_levels; l++) {
     const size_t n = (size_t)c->lv[l].n * p->max_frames;
     CREATE_CHK(hipMalloc((void**)&c->img[l], n + 4096));
@@ -1186,11 +1014,9 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipMalloc((void**)&c->d_active, 2 * sizeof(int)));
   CREATE_CHK(hipMalloc((void**)&c->d_tickets, sizeof(unsigned int) * (size_t)c->p.max_pairs));
   CREATE_CHK(hipMemset(c->d_tickets, 0, sizeof(unsigned int) * (size_t)c->p.max_pairs));
-  if (const char* e = std::getenv("UWT_TAIL_UPDATE")) c->tail_update = std::max(0, std::min(2, std::atoi(e)));
   for (int i = 0; i < 2; i++) CREATE_CHK(hipEventCreateWithFlags(&c->ev_poll[i], hipEventDisableTiming));
   CREATE_CHK(hipHostMalloc((void**)&c->h_small, sizeof(uwt_ctx::SmallResults)));
   CREATE_CHK(hipHostGetDevicePointer((void**)&c->d_small, c->h_small, 0));
-  if (const char* e = std::getenv("UWT_TARGET_BLOCKS")) c->target_blocks = std::max(1, std::atoi(e));  // tuning experiments only
   if (p->sampler || p->weights) {
     CREATE_CHK(hipMalloc((void**)&c->hist, sizeof(unsigned int) * kHistBins * p->max_pairs));
     CREATE_CHK(hipMalloc((void**)&c->scale, sizeof(PairScale) * p->max_pairs));
@@ -1262,6 +1088,28 @@ int uwt_destroy(uwt_ctx* c) {
 int uwt_get_params(const uwt_ctx* c, uwt_params* out) {
   if (!c || !out) return UWT_ERR_INVALID_ARG;
   *out = c->p;
+  return UWT_OK;
+}
+
+int uwt_get_tuning(const uwt_ctx* c, uwt_tuning* out) {
+  if (!c || !out) return UWT_ERR_INVALID_ARG;
+  *out = c->tn;
+  return UWT_OK;
+}
+
+int uwt_set_tuning(uwt_ctx* c, const uwt_tuning* t) {
+  if (!c || !t) return UWT_ERR_INVALID_ARG;
+  if (t->split < 1 || t->split > uwt_ctx::kMaxParts || t->split_min < 1 || t->split_min_px < 1 || t->stream_bytes < 0 ||
+      t->tail_update < 0 || t->tail_update > 2 || t->target_blocks < 0 || t->coarse_batch_px < 0 || t->first_poll < 1 ||
+      t->chained < -1 || t->chained > 1)
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_tuning: value out of range");
+  (void)hipSetDevice(c->p.device);
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  c->tn = *t;
+  for (int32_t* b : {&c->tn.coarse, &c->tn.coarse_weighted, &c->tn.overlap_gradients, &c->tn.speculation, &c->tn.fused_stages,
+                     &c->tn.pyramid_batch, &c->tn.persistent})
+    *b = *b != 0;
+  std::memset(c->tn.reserved, 0, sizeof(c->tn.reserved));
   return UWT_OK;
 }
 
@@ -1385,7 +1233,7 @@ int uwt_get_plane(uwt_ctx* c, int32_t slot, int32_t lvl, int32_t plane, void* ho
 // (src/Tracker.cpp:1266-1272).
 static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n, const int* depth_slots = nullptr, int n_depth = 0) {
   const bool fused = n <= kFewFrames && c->p.n_levels >= 3 && c->p.n_levels <= kPyrMaxLevels && c->lv[0].w % 4 == 0 &&
-                     c->lv[0].h % 4 == 0 && !std::getenv("UWT_NO_FUSED_STAGES");
+                     c->lv[0].h % 4 == 0 && c->tn.fused_stages;
   if (fused) {   // the whole pyramid of each plane in one launch
     if (n) launch_pyramid_all<uint8_t>(c, c->img, c->img, n, nullptr, first_slot);
     if (c->p.has_depth) {
@@ -1397,7 +1245,7 @@ static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n, const int* depth_
   }
   // batches: levels 1..3 in one pass over level 0 (k_pyramid_batch), the levels beyond by the per-level chain
   int l0 = 1;
-  if (c->p.n_levels >= 4 && c->lv[0].w % 16 == 0 && c->lv[0].h % 8 == 0 && !std::getenv("UWT_NO_PYRAMID_BATCH")) {
+  if (c->p.n_levels >= 4 && c->lv[0].w % 16 == 0 && c->lv[0].h % 8 == 0 && c->tn.pyramid_batch) {
     const int tiles = ((c->lv[0].w + 127) / 128) * ((c->lv[0].h + 63) / 64);
     if (n) {
       PyramidBatchArgs<uint8_t> a;
@@ -1435,7 +1283,7 @@ static int enqueue_gradient_level(uwt_ctx* c, int l, int first_slot, int n, cons
 }
 
 static int enqueue_gradients(uwt_ctx* c, int first_slot, int n, const int* d_slots = nullptr) {
-  if (n && n <= kFewFrames && c->p.n_levels <= kGradMaxLevels && !std::getenv("UWT_NO_FUSED_STAGES")) {   // every level in one launch
+  if (n && n <= kFewFrames && c->p.n_levels <= kGradMaxLevels && c->tn.fused_stages) {   // every level in one launch
     GradLevelsArgs a;
     std::memset(&a, 0, sizeof(a));
     int tiles = 0;
@@ -1519,7 +1367,7 @@ int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slot
   static_assert(sizeof(StatsOut) == sizeof(uwt_stats), "stats are copied as they are");
   // One or two pairs under an early-exit schedule are launched speculatively (see enqueue_estimate_chained): no read-back
   // inside the alignment, one look at the "cut short" flag behind the results, a careful second run if it is set.
-  c->speculate = n_pairs <= 2 && c->p.early_exit && !c->profiling && takes_chained_flow(c, n_pairs) && !std::getenv("UWT_NO_SPECULATION");
+  c->speculate = n_pairs <= 2 && c->p.early_exit && !c->profiling && takes_chained_flow(c, n_pairs) && c->tn.speculation;
   for (int attempt = 0; attempt < 2; attempt++) {
     st = enqueue_estimate(c, n_pairs, small ? c->d_small->poses : c->d_poses, small ? c->d_small->stats : c->d_stats);
     if (st) { c->speculate = false; c->inline_pairs = false; return st; }
@@ -1577,13 +1425,13 @@ static int track_batch_enqueue(uwt_ctx* c, int32_t first_slot, int32_t n_frames,
   // grad_refs_only computes those planes — gradients of every level, depth levels 1.. — for the pairs' reference slots
   // alone; otherwise every prepared frame gets them, as System::AddFrame / System::Tracking do for each new frame
   // (src/System.cpp:246-251, 197-213).
-  const int* g_slots = (grad_refs_only && c->vec == 4) ? c->d_ref : nullptr;   // gradient frames: a slot list or the range
+  const int* g_slots = grad_refs_only ? c->d_ref : nullptr;   // gradient frames: a slot list or the range
   const int g_first = g_slots ? 0 : first_slot, g_n = g_slots ? n_pairs : n_frames;
   st = grad_refs_only ? enqueue_pyramids(c, first_slot, n_frames, c->d_ref, n_pairs) : enqueue_pyramids(c, first_slot, n_frames);
   if (st) return st;
   // The side stream pays from ~768 pairs on (+1.7 % at 1024); below, its events cost more than the overlap returns
   // (one pair: +14 % latency).  A profiled call times its kernels alone: nothing runs beside them.
-  if (!c->overlap_gradients || c->profiling || n_pairs < 768) {
+  if (!c->tn.overlap_gradients || c->profiling || n_pairs < 768) {
     st = enqueue_gradients(c, g_first, g_n, g_slots);
     if (st) return st;
     return enqueue_estimate(c, n_pairs, d_poses_out, reinterpret_cast<StatsOut*>(d_stats_out));
@@ -1698,13 +1546,6 @@ int uwt_profile_read(uwt_ctx* c, double* ms_total, int64_t* launches, int64_t* p
   return UWT_OK;
 }
 
-#ifdef UWT_EXP_STAMPS
-int uwt_exp_read_records(uwt_ctx* c, int parity, uint32_t* out, int n_words) {
-  hipStreamSynchronize(c->stream);
-  if (parity == 2) return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_exp_stamps), 64) == hipSuccess ? 0 : 1;
-  return hipMemcpy(out, parity ? c->partials2 : c->partials, (size_t)n_words * 4, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-#endif
 
 int uwt_profile_clock(uwt_ctx* c, double* shader_ghz) {
   if (c) (void)hipSetDevice(c->p.device);
@@ -1787,7 +1628,7 @@ int uwt_warp(uwt_ctx* c, int32_t lvl, const float* pts, int32_t n, const float p
   Pose P;
   for (int k = 0; k < 4; k++) P.q[k] = pose[k];
   for (int k = 0; k < 3; k++) P.t[k] = pose[4 + k];
-  UWT_WITH_ARITH(c, hipLaunchKernelGGL(k_warp_table<AR>, dim3((n + 255) / 256), dim3(256), 0, c->stream, din, dout, n, P, c->lv[lvl]));
+  UWT_WITH_AR(c->p.arith == UWT_ARITH_LEGACY ? kArithLegacy : kArithOpenCV, hipLaunchKernelGGL(k_warp_table<AR>, dim3((n + 255) / 256), dim3(256), 0, c->stream, din, dout, n, P, c->lv[lvl]));
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(warped_out, dout, bytes, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2016,7 +1857,6 @@ int uwt_estimate_pose_points(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, con
   const int tb = 64;
   hipLaunchKernelGGL(k_init_state, dim3(1), dim3(tb), 0, c->stream, c->state, 1, p.initial_error);
   HIPCHK(c, hipGetLastError());
-  const bool unit = (p.z_factor == 1.0f && p.angle_factor == 1.0f), acc64 = p.accumulate_f64 != 0;
   const int per_block = kBlock * 32;
   for (int lvl = p.first_level; lvl >= p.last_level; lvl--) {
     ResidualArgs ra = residual_args(c, lvl);
@@ -2029,12 +1869,7 @@ int uwt_estimate_pose_points(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, con
     ua.slices = ra.slices;
     int next_poll = 2;
     for (int k = 0; k < p.max_iters; k++) {
-      const dim3 grid(ra.slices), blk(kBlock);
-      UWT_WITH_ARITH(c,
-        if (unit && acc64) hipLaunchKernelGGL((k_residual_points<AR, true, false, double>), grid, blk, 0, c->stream, ra, pa);
-        else if (unit) hipLaunchKernelGGL((k_residual_points<AR, true, false, float>), grid, blk, 0, c->stream, ra, pa);
-        else if (acc64) hipLaunchKernelGGL((k_residual_points<AR, false, false, double>), grid, blk, 0, c->stream, ra, pa);
-        else hipLaunchKernelGGL((k_residual_points<AR, false, false, float>), grid, blk, 0, c->stream, ra, pa));
+      uwt::launch_points(c->stream, launch_sel(c), ra, pa);
       HIPCHK(c, hipGetLastError());
       ua.k = k;
       const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);

@@ -305,10 +305,13 @@ __device__ __forceinline__ void scharr_tile_scalar(unsigned char* __restrict__ l
   }
 }
 
-__global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
-                                                    int16_t* __restrict__ gy, int w, int h, size_t frame_stride) {
+// (src / gx / gy point at slot 0; the frames processed are slots[0..gridDim.y) if given, else first_slot..)
+static __global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
+                                                           int16_t* __restrict__ gy, int w, int h, size_t frame_stride,
+                                                           const int* __restrict__ slots, int first_slot) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kGradTH + 2) * (kGradTW + 4)];
-  scharr_tile_scalar(lds, src, gx, gy, w, h, frame_stride, blockIdx.y, (int)blockIdx.x);
+  const size_t frame = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;
+  scharr_tile_scalar(lds, src, gx, gy, w, h, frame_stride, frame, (int)blockIdx.x);
 }
 
 // Vector variant for level widths that are multiples of 4: a 128 x (8·RPT) output tile per block, the source patch (tile
@@ -447,7 +450,7 @@ struct GradLevelsArgs {
   int first_slot;
 };
 
-__global__ __launch_bounds__(kBlock) void k_scharr3_levels(const GradLevelsArgs a) {
+static __global__ __launch_bounds__(kBlock) void k_scharr3_levels(const GradLevelsArgs a) {
   constexpr int kV4Bytes = scharr_v4_lds_rows(1) * (kGradVW / 4 + 2) * 4, kScBytes = (kGradTH + 2) * (kGradTW + 4);
   __shared__ __attribute__((aligned(16))) unsigned char lds[kV4Bytes > kScBytes ? kV4Bytes : kScBytes];
   const int slot = a.slots ? a.slots[blockIdx.y] : a.first_slot + (int)blockIdx.y;
@@ -963,12 +966,6 @@ __device__ __forceinline__ void masked_sums_hi(double acc[kAccFloats], double& x
   }
 }
 
-#ifdef UWT_EXP_STAMPS
-__device__ uint32_t g_exp_stamps[16];
-#define EXP_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) g_exp_stamps[i] = (uint32_t)__builtin_amdgcn_s_memrealtime(); } while (0)
-#else
-#define EXP_STAMP(i) do { } while (0)
-#endif
 // Deterministic block reduction of the per-thread accumulators through LDS (fixed order, no atomics).
 // Threads accumulate a handful of pixels in f32; from here on every sum is f64 so that the totals are, to ~1e-9,
 // the exact sums the reference's double-accumulating gemm produces (src/Tracker.cpp:560-561).
@@ -998,7 +995,6 @@ __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict_
   double(*seg_f)[8] = reinterpret_cast<double(*)[8]>(lds + kPass * kBlock * 8 + 2 * kBlock * 8);
   const int tid = (int)thread_here();   // (opaque: see thread_here)
   const int v = tid >> 3, seg = tid & 7;
-  EXP_STAMP(11);
   cnt2[0][tid] = (double)n_valid;
   cnt2[1][tid] = (double)sum_r2;
 #pragma unroll
@@ -1033,10 +1029,8 @@ __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict_
         seg_f[27 + v - kPass][seg] = s;
       }
     }
-    EXP_STAMP(12 + pass);
   }
   __syncthreads();
-  EXP_STAMP(14);
   if (tid < (HAS_EXTRA ? 30 : 29)) {
     double s = seg_f[tid][0];
 #pragma unroll
@@ -1054,18 +1048,15 @@ __device__ __forceinline__ void block_reduce_store_at(unsigned char* __restrict_
     } else if (tid == 27) rec[54] = (uint32_t)(unsigned long long)s;                              // valid pixels
     else if (tid == 28) reinterpret_cast<unsigned long long*>(rec)[28] = (unsigned long long)s;   // Σ r² (integer residuals)
     else reinterpret_cast<double*>(rec)[tid] = s;   // 29: Σ r·(r·w), the error numerator when residuals are not integers / weighted
-    EXP_STAMP(15);
   }
 }
 
-#ifndef UWT_EXP_PASS
-#define UWT_EXP_PASS 14
-#endif
+constexpr int kBatchPass = 14;   // rows per LDS pass of the block reduction in the batch kernels (two passes, 34 KB: four blocks per CU)
 template <typename AccT, bool HAS_EXTRA = false, typename R2T = uint32_t>
 __device__ __forceinline__ void block_reduce_store(const AccT acc[kAccFloats], R2T sum_r2, uint32_t n_valid,
                                                    uint32_t* __restrict__ rec, AccT extra = (AccT)0, bool coherent = false) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[reduce_lds_bytes(UWT_EXP_PASS)];
-  block_reduce_store_at<AccT, HAS_EXTRA, UWT_EXP_PASS, R2T>(lds, acc, sum_r2, n_valid, rec, extra, coherent);
+  __shared__ __attribute__((aligned(16))) unsigned char lds[reduce_lds_bytes(kBatchPass)];
+  block_reduce_store_at<AccT, HAS_EXTRA, kBatchPass, R2T>(lds, acc, sum_r2, n_valid, rec, extra, coherent);
 }
 
 // robust weights / bilinear sampler shared by the dense kernels and the general (dump-capable) kernel
@@ -1156,7 +1147,7 @@ __device__ __forceinline__ void fill_weight_table(WeightEntry* __restrict__ tab,
 // vector (src/Tracker.cpp:1571-1654).  One block: a 256-bin LDS histogram of the saturated, rounded values gives the
 // median by the reference's rule (first bin whose cumulative count exceeds float(n / 2)), a second histogram of the
 // deviations gives the MAD, then the weights.  out_stats: [median, 1.4826 * median deviation].
-__global__ __launch_bounds__(1024) void k_robust_weights(const float* __restrict__ r, int n, int kind, float* __restrict__ w,
+static __global__ __launch_bounds__(1024) void k_robust_weights(const float* __restrict__ r, int n, int kind, float* __restrict__ w,
                                                          float* __restrict__ out_stats) {
   __shared__ unsigned int hist[256];
   __shared__ float s_med, s_mad;
@@ -1240,10 +1231,12 @@ struct ResidualArgs {
 // What a caller that evaluates a level inside its own launch (k_coarse) changes of a level's ResidualArgs — handed over beside
 // the arguments instead of in a modified copy: the copy (200 bytes, no longer backed by the kernel-argument segment) would have
 // to live in registers for the whole launch.
+// The caller evaluates the whole level as ONE slice of its pair: `rec` is the record itself (the caller's LDS), `scale` (robust
+// weights) the pair's scale itself — neither is indexed by the pair.
 struct CoreOverride {
-  int groups_per_block, slices;
-  uint32_t* partials;
-  const PairScale* scale = nullptr;   // robust-weight scale of the pair, indexed like ResidualArgs::scale (k_coarse_weighted: in LDS)
+  int groups_per_block;
+  uint32_t* rec;
+  const PairScale* scale = nullptr;   // k_coarse_weighted: in LDS
 };
 
 // reference planes of one group of VEC pixels, as loaded (one vector load per plane)
@@ -1257,11 +1250,7 @@ struct RefGroup {
 template <int VEC, bool DEPTH, bool COMPUTE_ONLY = false, bool STREAM = false>
 __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __restrict__ I1, const int16_t* __restrict__ GX,
                                            const int16_t* __restrict__ GY, const uint16_t* __restrict__ DP, uint32_t idx) {
-#ifdef UWT_EXP_TWIN_KEEP_PLANES
-  constexpr bool FAKE_PLANES = false;   // experiment: the twin keeps its plane loads (tools/exp/r4_twin_ab.sh)
-#else
   constexpr bool FAKE_PLANES = COMPUTE_ONLY;
-#endif
   if constexpr (FAKE_PLANES) {  // diagnostic instantiation: plane values made up from the index, no memory operation
 #pragma unroll
     for (int j = 0; j < VEC; j++) { r.i1[j] = (uint8_t)(idx + j); r.gx[j] = (int16_t)(idx * 3 + j); r.gy[j] = (int16_t)(idx * 5 - j); r.dp[j] = (uint16_t)(4000 + (idx & 255)); }
@@ -1339,8 +1328,6 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
                                               unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot,
                                               const CoreOverride* ov) {
   const int a_groups_per_block = ov ? ov->groups_per_block : a.groups_per_block;
-  const int a_slices = ov ? ov->slices : a.slices;
-  uint32_t* const a_partials = ov ? ov->partials : a.partials;
   const bool a_probe = ov ? false : a.probe != 0;
   // MASKED: f64 sums added under an EXEC mask of the valid lanes (masked_sums_*), nothing of an invalid pixel sanitised
   constexpr bool MASKED = std::is_same<AccT, double>::value && !DUMP;
@@ -1349,11 +1336,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   // scalar registers the 12 doubles do not fit beside the kernel's ~95 (the compiler then keeps them in 24 vector registers
   // for the whole loop: 151 registers, three waves per SIMD); read per step they are live through the warp phase only,
   // where the pressure is lowest.  6 ds_read_b128 per 4 pixels, no vector-ALU instruction.
-#ifdef UWT_EXP_NO_TD_LDS
-  constexpr bool TD_LDS = false;
-#else
   constexpr bool TD_LDS = AR == kArithOpenCV && !DUMP;
-#endif
   __shared__ __attribute__((aligned(16))) double s_td[TD_LDS ? 12 : 2];
   if constexpr (TD_LDS) {
     warp_setup<kArithLegacy>(pose, K);   // T in scalar registers (the hand-over of the block's pose); Td goes through LDS
@@ -1392,7 +1375,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   constexpr bool GENERAL = SAMPLER != 0 || WEIGHTS != 0;  // float residuals and/or robust weights
   AccT err = (AccT)0;                                      // Σ r·(r·w), the error numerator on the general path
   float inv_mad = 1.f;
-  if constexpr (WEIGHTS != 0) inv_mad = (ov && ov->scale ? ov->scale : a.scale)[pair].inv_mad;
+  if constexpr (WEIGHTS != 0) inv_mad = ov ? ov->scale->inv_mad : a.scale[pair].inv_mad;
   // robust weights over integer residuals: the per-value table (see WeightEntry) in the bytes of the reduction's image
   constexpr bool TABLE = WEIGHTS != 0 && SAMPLER == 0;
   static_assert(!TABLE || EXT_LDS == 0, "the weighted path reduces in its own LDS");
@@ -1434,15 +1417,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   auto body = [&](RefGroup<VEC>& rg, const int ahead) __attribute__((always_inline)) {
     const bool active = g < g_end;
     const unsigned long long active_mask = __builtin_amdgcn_sicmp(g, g_end, kIcmpSLT);
-#ifdef UWT_EXP_TWIN_NO_TD
-    constexpr bool TD_READ = TD_LDS && !COMPUTE_ONLY;   // experiment: the twin without the LDS reads of the rigid matrix
-    if constexpr (TD_LDS && COMPUTE_ONLY) {
-#pragma unroll
-      for (int i = 0; i < 12; i++) K.Td[i] = 0.5 + 0.25 * i;
-    }
-#else
     constexpr bool TD_READ = TD_LDS;
-#endif
     if constexpr (TD_READ) {
       unsigned off = 0;
       asm volatile("" : "+v"(off));   // an offset the compiler cannot see through: the reads stay inside the loop
@@ -1497,11 +1472,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     float s2[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
-#ifdef UWT_EXP_TWIN_KEEP_GATHER
-      constexpr bool FAKE_GATHER = false;   // experiment: the twin keeps its gathers
-#else
       constexpr bool FAKE_GATHER = COMPUTE_ONLY;
-#endif
       if constexpr (FAKE_GATHER) i2[j] = (int)i1[j] + (int)(gidx[j] & 1);
       else if constexpr (SAMPLER == 0) i2[j] = I2[gidx[j]];   // nearest-neighbour gather of the target level (:472)
       else s2[j] = sample_bilinear(I2, L, get(x2[j / N], j % N), get(y2[j / N], j % N));  // EXTENSION; x2 = y2 = 0 for sanitised invalid pixels
@@ -1535,11 +1506,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     __builtin_amdgcn_sched_barrier(0);
     // kArithOpenCV, identity path: a unit's row is formed in double and goes straight into the sums, one unit at a time (no f32
     // rows of all four pixels held across the phase: the doubles of the small products take their registers)
-#ifdef UWT_EXP_NO_DIRECT
-    constexpr bool DIRECT = false;
-#else
     constexpr bool DIRECT = AR == kArithOpenCV && MASKED && !GENERAL;
-#endif
     if constexpr (DIRECT) {
 #pragma unroll
       for (int u = 0; u < NU; u++) {
@@ -1555,9 +1522,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
           masked_sums_lo(acc, Jd, okm[j]);
           masked_sums_hi<0>(acc, r2d, Jd, (double)ri, 0.0, okm[j]);
           n_valid_wave += (uint32_t)__builtin_popcountll(okm[j]);  // scalar
-#ifndef UWT_EXP_NO_UNIT_FENCE
           __builtin_amdgcn_sched_barrier(0);
-#endif
         }
       }
     } else if constexpr (MASKED && GENERAL && !TABLE) {
@@ -1711,26 +1676,9 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     xf0 -= wrap ? wf : 0.f;
     yf += wrap ? 1.f : 0.f;
   };
-#ifdef UWT_EXP_PF2
-  // experiment: the planes two steps ahead (two register sets that take turns)
-  RefGroup<VEC> rgB;
-  load_group<VEC, DEPTH, COMPUTE_ONLY>(rgB, I1, GX, GY, DP, (uint32_t)min(g + kBlock, n_groups - 1) * VEC);
-  for (int it = 0; it < iters; it += 2) {
-    body(rg, 2);
-    g += kBlock;
-    if (it + 1 < iters) {
-      body(rgB, 2);
-      g += kBlock;
-    }
-  }
-#else
   for (int it = 0; it < iters; it++, g += kBlock) body(rg, 1);
-#endif
   const uint32_t n_valid = (threadIdx.x & 63) == 0 ? n_valid_wave : 0u;
-  uint32_t* out_rec = a_partials + ((size_t)pair * a_slices + slice) * kRecWords;
-#ifdef UWT_EXP_STAMPS
-  if (threadIdx.x == 0) out_rec[62] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
+  uint32_t* out_rec = ov ? ov->rec : a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
   constexpr bool R2D = MASKED && !GENERAL;   // the identity path's sum of r^2 is the f64 one
   const bool coherent = !ov && a.tail.on != 0;   // the record is read in this launch (tail_update_wave)
   if constexpr (EXT_LDS != 0 && R2D) block_reduce_store_at<AccT, false, EXT_LDS, double>(lds, acc, r2d, n_valid, out_rec, err);   // the caller's bytes: k_iterate
@@ -1741,7 +1689,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   } else if constexpr (R2D) block_reduce_store<AccT, false, double>(acc, r2d, n_valid, out_rec, err, coherent);
   else block_reduce_store<AccT, GENERAL>(acc, sum_r2, n_valid, out_rec, err, coherent);
   if (a_probe && threadIdx.x == 0) {
-    uint32_t* rec = a_partials + ((size_t)pair * a_slices + slice) * kRecWords;
+    uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
     rec[60] = (uint32_t)(__builtin_amdgcn_s_memtime() - s_probe[0]);
     rec[61] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - s_probe[1]);
   }
@@ -1749,14 +1697,9 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 
 __device__ __forceinline__ void tail_update_wave(const ResidualArgs& a, int pair);   // (behind update_solve_wave)
 
-#ifndef UWT_EXP_WAVES
-#define UWT_RESIDUAL_BOUNDS __launch_bounds__(kBlock)
-#else
-#define UWT_RESIDUAL_BOUNDS __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(UWT_EXP_WAVES, UWT_EXP_WAVES)))
-#endif
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
           bool COMPUTE_ONLY = false, bool STREAM = false>
-__global__ UWT_RESIDUAL_BOUNDS void k_residual(const ResidualArgs a) {
+__global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
   const int pair = (int)blockIdx.y + a.pair_base;
   const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, STREAM>(a, pair, (int)blockIdx.x);
   if constexpr (!COMPUTE_ONLY && !DUMP) {
@@ -1939,7 +1882,7 @@ __device__ __forceinline__ PairScale wave_scale(const unsigned int mine[8], unsi
   return sc;
 }
 
-__global__ __launch_bounds__(256) void k_scale_stage(const GeneralArgs ga, const PairState* state, int n_pairs, int pair_base) {
+static __global__ __launch_bounds__(256) void k_scale_stage(const GeneralArgs ga, const PairState* state, int n_pairs, int pair_base) {
   __shared__ unsigned int sh[4][kHistBins];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
@@ -2255,15 +2198,11 @@ __device__ __forceinline__ void update_solve_wave(const UpdateArgs& a, PairState
 #pragma unroll
     for (int i = 0; i < 6; i++)
       b[i] = a.general ? (float)(-sums[21 + i]) : (float)(-((double)a.gain * sums[21 + i]));  // :559-561
-    EXP_STAMP(6);
     solve_delta_wave(sums, b, delta, a.legacy_solve != 0);                                             // :554-564, A = (float)sums[0..20]
-    EXP_STAMP(7);
     Pose d, np;
     se3_exp_wave(delta, d);                                                         // :574
-    EXP_STAMP(8);
     se3_mul(st.pose, d, np);
     st.pose = np;
-    EXP_STAMP(9);
     if (count_active && a.active && lane == 0) atomicAdd(a.active, 1);
   }
 }
@@ -2362,7 +2301,6 @@ __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const u
   }
   PairState st = *st_in;
   const bool live = !(st.level_done || st.status);  // block-uniform
-  EXP_STAMP(0);
   if (live) {
     double cs = 0.0;
     long long is = 0;
@@ -2383,7 +2321,6 @@ __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const u
     part_f[part][slot] = cs;
     part_i[part][slot] = is;
     __syncthreads();
-    EXP_STAMP(1);
     if (tid < 32) {
       double fs = part_f[0][tid];
       long long ls = part_i[0][tid];
@@ -2399,17 +2336,15 @@ __device__ __forceinline__ PairState update_compute(const UpdateArgs& a, const u
     }
   }
   __builtin_amdgcn_wave_barrier();   // the sums were written by lanes of wave 0, which alone reads them
-  EXP_STAMP(5);
   if (tid < 64) {   // wave 0 runs the tail together on the same (uniform) values
     if (live) update_solve_wave(a, st, sums, isums, count_active, lane);
     if (lane == 0) *s_state = st;
   }
   __syncthreads();
-  EXP_STAMP(10);
   return *s_state;
 }
 
-__global__ __launch_bounds__(kUpdateBlock) void k_gn_update(const UpdateArgs a) {
+static __global__ __launch_bounds__(kUpdateBlock) void k_gn_update(const UpdateArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kUpdateLdsBytes];
   const int pair = (int)blockIdx.x + a.pair_base;
   const PairState st = update_compute(a, a.partials + (size_t)pair * a.slices * kRecWords, &a.state[pair], lds, true);
@@ -2472,24 +2407,22 @@ constexpr int iterate_lds_bytes(int pass) { return kUpdateLdsBytes > reduce_lds_
 // PASS: rows per LDS pass of the block reduction — kIteratePass (one pass, 60 KB) while the blocks have their CUs to
 // themselves (up to 3 pairs: 0.40 against 0.42 ms for one), 14 (two passes, 34 KB, four blocks per CU) from 4 pairs on
 // (6 pairs: 0.49 against 0.52 ms).
-template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, bool COMPUTE_ONLY = false, int PASS = kIteratePass>
-__global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterArgs ia) {
+// PLAIN (the flow kernels' one shape switch): true = the reference's constants — square pixels (fx == fy bitwise) and unit
+// z / angle factors —, i.e. residual_core<UNIT_FACTORS, SQUARE>; false = the general form (fx != fy and / or other factors:
+// every product written out, the factors multiplied in), which computes the same bits where both apply (x * 1.0f == x).
+// f64 sums only (a context with accumulate_f64 = 0 stays on the per-evaluation launches).
+template <int AR, int VEC, bool DEPTH, bool PLAIN, bool COMPUTE_ONLY = false, int PASS = kIteratePass>
+__global__ __launch_bounds__(kBlock) void k_iterate(const ResidualArgs a, const IterArgs ia) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[iterate_lds_bytes(PASS)];   // the update's staging, then the reduction's image
   const int pair = (int)blockIdx.y + a.pair_base, slice = (int)blockIdx.x;
   // the first group's reference planes do not depend on the pose: their (cold) loads travel while the update runs
   RefGroup<VEC> first;
-#ifdef UWT_EXP_STAMPS
-  const uint32_t stamp0 = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
   const int lp = (int)blockIdx.y;
   // (selects, not an indexed read: indexing the by-value argument would send it through scratch memory)
   const int ref_slot = ia.inline_pairs ? (lp == 0 ? ia.pair_slots[0] : ia.pair_slots[2]) : a.ref_slots[pair];
   const int tgt_slot = ia.inline_pairs ? (lp == 0 ? ia.pair_slots[1] : ia.pair_slots[3]) : a.tgt_slots[pair];
   load_first_group<VEC, DEPTH, COMPUTE_ONLY>(first, a, ref_slot, slice);
   PairState st = iterate_state(ia, pair, lds, slice == 0);
-#ifdef UWT_EXP_STAMPS
-  const uint32_t stamp1 = (uint32_t)__builtin_amdgcn_s_memrealtime();
-#endif
   if (slice == 0 && threadIdx.x == 0) ia.state_out[pair] = st;
   if constexpr (COMPUTE_ONLY) {
     st.level_done = 0;
@@ -2498,15 +2431,7 @@ __global__ UWT_RESIDUAL_BOUNDS void k_iterate(const ResidualArgs a, const IterAr
   }
   if (st.level_done || st.status) return;
   __syncthreads();   // the staging bytes become the reduction's
-  residual_core<AR, VEC, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, COMPUTE_ONLY, PASS>(a, pair, slice, st.pose, lds, &first, ref_slot, tgt_slot);
-#ifdef UWT_EXP_STAMPS
-  if (threadIdx.x == 0) {   // experiment: 100 MHz wall stamps of this block's phases in the record's spare words
-    uint32_t* rec = a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
-    rec[60] = stamp0;
-    rec[61] = stamp1;
-    rec[63] = (uint32_t)__builtin_amdgcn_s_memrealtime();
-  }
-#endif
+  residual_core<AR, VEC, DEPTH, PLAIN, false, double, PLAIN, 0, 0, COMPUTE_ONLY, PASS>(a, pair, slice, st.pose, lds, &first, ref_slot, tgt_slot);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2538,12 +2463,12 @@ struct CoarseArgs {
 // NLEV: levels the launch can run (the loop over them is unrolled).  The batch form (one block per pair of a whole batch, one
 // level per launch, PASS 14) stays at ~210 registers, two waves per SIMD: forced to 128 it spills and loses (measured), so it
 // pays only on the smallest levels, where the per-evaluation launches run furthest below the level-0 rate.
-template <int AR, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS, int NLEV>
+template <int AR, bool DEPTH, bool PLAIN, int PASS, int NLEV>
 __device__ __forceinline__ void coarse_body(const CoarseArgs& ca);
 
-template <int AR, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS = kIteratePass, int NLEV = kCoarseMaxLevels>
-__global__ UWT_RESIDUAL_BOUNDS void k_coarse(const CoarseArgs ca) {
-  coarse_body<AR, DEPTH, UNIT_FACTORS, AccT, SQUARE, PASS, NLEV>(ca);
+template <int AR, bool DEPTH, bool PLAIN, int PASS = kIteratePass, int NLEV = kCoarseMaxLevels>
+__global__ __launch_bounds__(kBlock) void k_coarse(const CoarseArgs ca) {
+  coarse_body<AR, DEPTH, PLAIN, PASS, NLEV>(ca);
 }
 // The batch form (one block per pair of a whole batch, PASS 14, one level per launch) held to four waves per SIMD: all blocks
 // of a 1024-pair batch are resident at once, and while one block's wave 0 runs its update the other three blocks of the CU
@@ -2552,11 +2477,11 @@ __global__ UWT_RESIDUAL_BOUNDS void k_coarse(const CoarseArgs ca) {
 // update had their ~40 constant registers hoisted above the iteration loop, live through the residual loop), and the thread
 // index behind the update's and the reduction's lane roles is opaque (thread_here).  What remains above 128 is parked in
 // scratch outside the residual loop (40 bytes per lane).
-template <int AR, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS = 14, int NLEV = 1>
+template <int AR, bool DEPTH, bool PLAIN, int PASS = 14, int NLEV = 1>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_coarse_w4(const CoarseArgs ca) {
-  coarse_body<AR, DEPTH, UNIT_FACTORS, AccT, SQUARE, PASS, NLEV>(ca);
+  coarse_body<AR, DEPTH, PLAIN, PASS, NLEV>(ca);
 }
-template <int AR, bool DEPTH, bool UNIT_FACTORS, typename AccT, bool SQUARE, int PASS, int NLEV>
+template <int AR, bool DEPTH, bool PLAIN, int PASS, int NLEV>
 __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
   constexpr int kLds = iterate_lds_bytes(PASS);
   __shared__ __attribute__((aligned(16))) unsigned char lds[kLds + kRecWords * 4 + 64];
@@ -2582,9 +2507,8 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
     if (li >= ca.n_levels) break;   // block-uniform
     const ResidualArgs& a = ca.lv[li];   // read in place (the kernel-argument segment); what differs travels in `ov`
     CoreOverride ov;
-    ov.slices = 1;
     ov.groups_per_block = ((a.L.n / 4 + kBlock - 1) / kBlock) * kBlock;   // the whole level
-    ov.partials = rec - (size_t)pair * kRecWords;                          // residual_core writes record (pair, slice 0)
+    ov.rec = rec;
     UpdateArgs u = ca.u;
     u.slices = 1;
     u.active = nullptr;
@@ -2592,7 +2516,7 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
       for (int k = 0; k < u.max_iters; k++) {
         __syncthreads();   // every thread has taken the state out of the update's LDS bytes: they become the reduction's
         if (threadIdx.x == 0) *cur = st;
-        residual_core<AR, 4, DEPTH, UNIT_FACTORS, false, AccT, SQUARE, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
+        residual_core<AR, 4, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
         __syncthreads();   // the record and the state are in LDS; the reduction's image is free
         u.k = k;
         st = update_compute(u, rec, cur, lds, false);   // ends with a barrier: every thread has the new state
@@ -2617,7 +2541,7 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
 // launch, the weighted launch and the update (three dependent launches of a few blocks each, ~20 us for a lone pair) by ~8 us
 // of one resident block.  Same device functions as the launches it replaces: same bits.
 // ------------------------------------------------------------------------------------------------------------
-template <int AR, bool DEPTH, int WEIGHTS, int NLEV = kCoarseMaxLevels>
+template <int AR, bool DEPTH, int WEIGHTS, bool PLAIN, int NLEV = kCoarseMaxLevels>
 __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca) {
   __shared__ unsigned int h[kHistBins * kHistRep];                                  // the residual histogram, kHistRep replicas per bin
   __shared__ unsigned int h_scratch[kHistBins];                                     // wave_scale's working copy
@@ -2647,10 +2571,9 @@ __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca)
     const LevelK L = a.L;
     const int n_groups = L.n / 4;
     CoreOverride ov;
-    ov.slices = 1;
     ov.groups_per_block = ((n_groups + kBlock - 1) / kBlock) * kBlock;   // the whole level
-    ov.partials = rec - (size_t)pair * kRecWords;                         // residual_core writes record (pair, slice 0)
-    ov.scale = &s_scale - pair;
+    ov.rec = rec;
+    ov.scale = &s_scale;
     UpdateArgs u = ca.u;
     u.slices = 1;
     u.active = nullptr;
@@ -2688,7 +2611,7 @@ __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca)
         }
         __syncthreads();
         // the weighted sums (src/Tracker.cpp:554-561) through the weight table; the record lands in LDS
-        residual_core<AR, 4, DEPTH, true, false, double, true, 0, WEIGHTS>(a, pair, 0, st.pose, nullptr, nullptr, ref_slot, tgt_slot, &ov);
+        residual_core<AR, 4, DEPTH, PLAIN, false, double, PLAIN, 0, WEIGHTS>(a, pair, 0, st.pose, nullptr, nullptr, ref_slot, tgt_slot, &ov);
         __syncthreads();
         u.k = k;
         st = update_compute(u, rec, &cur, ulds, false);   // ends with a barrier: every thread has the new state
@@ -2708,7 +2631,7 @@ __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca)
 struct StatsOut { int status, iterations, n_valid; float error; };
 
 // After the last evaluation: its update, the last level's hand-off, and the results (one block per pair).
-__global__ __launch_bounds__(kUpdateBlock) void k_finish(const IterArgs ia, float* __restrict__ poses, StatsOut* __restrict__ stats) {
+static __global__ __launch_bounds__(kUpdateBlock) void k_finish(const IterArgs ia, float* __restrict__ poses, StatsOut* __restrict__ stats) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[kUpdateLdsBytes];
   const int pair = (int)blockIdx.x + ia.u.pair_base;
   const PairState st = iterate_state(ia, pair, lds, true);
@@ -2723,7 +2646,7 @@ __global__ __launch_bounds__(kUpdateBlock) void k_finish(const IterArgs ia, floa
   }
 }
 
-__global__ void k_set_pose(PairState* state, Pose pose, float initial_error) {
+static __global__ void k_set_pose(PairState* state, Pose pose, float initial_error) {
   if (threadIdx.x || blockIdx.x) return;
   PairState st;
   st.pose = pose;
@@ -2736,7 +2659,7 @@ __global__ void k_set_pose(PairState* state, Pose pose, float initial_error) {
   state[0] = st;
 }
 
-__global__ void k_init_state(PairState* state, int n, float initial_error) {
+static __global__ void k_init_state(PairState* state, int n, float initial_error) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   PairState st;
@@ -2751,7 +2674,7 @@ __global__ void k_init_state(PairState* state, int n, float initial_error) {
 }
 
 // end of a pyramid level: hand-off (src/Tracker.cpp:580-590) and re-arm for the next level (:392-393)
-__global__ void k_level_end(PairState* state, int n, int lvl, int scale_t, float initial_error) {
+static __global__ void k_level_end(PairState* state, int n, int lvl, int scale_t, float initial_error) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;  // `state` points at the first pair of the launch
   if (i >= n) return;
   PairState st = state[i];
@@ -2763,7 +2686,7 @@ __global__ void k_level_end(PairState* state, int n, int lvl, int scale_t, float
   state[i] = st;
 }
 
-__global__ void k_write_out(const PairState* state, int n, float* poses, StatsOut* stats) {
+static __global__ void k_write_out(const PairState* state, int n, float* poses, StatsOut* stats) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const PairState st = state[i];
@@ -2951,7 +2874,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_points(const ResidualArgs a
 
 // gradient_ = addWeighted(convertScaleAbs(gx), 0.5, convertScaleAbs(gy), 0.5) (src/Tracker.cpp:1139-1142), u8,
 // plus its integer sum for cuda::meanStdDev (:1325).  (a + b)/2 with cvRound's round-half-to-even.
-__global__ __launch_bounds__(kBlock) void k_grad_mag(const int16_t* __restrict__ gx, const int16_t* __restrict__ gy, int n,
+static __global__ __launch_bounds__(kBlock) void k_grad_mag(const int16_t* __restrict__ gx, const int16_t* __restrict__ gy, int n,
                                                      uint8_t* __restrict__ mag, unsigned long long* __restrict__ sum) {
   unsigned int local = 0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
@@ -2974,7 +2897,7 @@ __global__ __launch_bounds__(kBlock) void k_grad_mag(const int16_t* __restrict__
 
 // Tracker::ObtainCandidatePoints (src/Tracker.cpp:1314-1362) for a batch of frames, many blocks per frame, three passes:
 // gradient_ and its per-frame sum: grid (blocks, frames)
-__global__ __launch_bounds__(kBlock) void k_grad_mag_batch(const int16_t* __restrict__ gx, const int16_t* __restrict__ gy, int n,
+static __global__ __launch_bounds__(kBlock) void k_grad_mag_batch(const int16_t* __restrict__ gx, const int16_t* __restrict__ gy, int n,
                                                            int first_slot, uint8_t* __restrict__ mag,
                                                            unsigned long long* __restrict__ sums) {
   const int f = blockIdx.y;
@@ -3035,7 +2958,7 @@ __global__ __launch_bounds__(kBlock) void k_candidates_batch(const uint8_t* __re
 }
 
 // exclusive scan of the m = w * bands counts of one frame (one block per frame), total to totals[f]
-__global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ counts, int m, int* __restrict__ offsets,
+static __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ counts, int m, int* __restrict__ offsets,
                                                       int* __restrict__ totals) {
   __shared__ int part[1024];
   const int f = blockIdx.x, tid = threadIdx.x;
@@ -3060,7 +2983,7 @@ __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restrict__ co
 // Tracker::ObtainPatchesPoints (src/Tracker.cpp:1178-1257): level 0, <= 200 key points, 11x11 patches
 // ("patch_size_ - 1 / 2" = 5), x-major inside a patch, key points in order.  One thread per key point counts, a
 // serial prefix orders, the thread then writes its patch.
-__global__ __launch_bounds__(256) void k_patch_points(const float2* __restrict__ kp, int n_kp, const uint16_t* __restrict__ depth0,
+static __global__ __launch_bounds__(256) void k_patch_points(const float2* __restrict__ kp, int n_kp, const uint16_t* __restrict__ depth0,
                                                       int w, int h, float4* __restrict__ out, int cap, int* __restrict__ count) {
   __shared__ int cnt[256];
   const int q = threadIdx.x;
@@ -3103,7 +3026,7 @@ __global__ __launch_bounds__(256) void k_patch_points(const float2* __restrict__
 // cells of the (2 * start + 1)^2 patch around its rounded position (x outer, y inner) that lie strictly inside the level
 // (i > 0, j > 0) and are not the centre, each carrying the point's z and w = 1.  One block: chunks of 256 points, the
 // cells of a chunk counted per point and scanned in point order, so that the output order is the reference's push_back order.
-__global__ __launch_bounds__(256) void k_add_patch_points(const float4* __restrict__ pts, int n, int w, int h, int start,
+static __global__ __launch_bounds__(256) void k_add_patch_points(const float4* __restrict__ pts, int n, int w, int h, int start,
                                                           float4* __restrict__ out, int cap, int* __restrict__ count) {
   __shared__ int cnt[256];
   __shared__ int base;
@@ -3149,7 +3072,7 @@ __global__ __launch_bounds__(256) void k_add_patch_points(const float4* __restri
 // (src/System.cpp:231-235) fused: each output pixel of the crop window gathers its 2x2 source patch through the
 // fixed-point maps (CV_16SC2 + 5-bit fractions) and blends with the 15-bit weights, border constant 0.
 // ------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_remap_crop(const uint8_t* __restrict__ src, int sw, int sh, size_t s_stride,
+static __global__ __launch_bounds__(kBlock) void k_remap_crop(const uint8_t* __restrict__ src, int sw, int sh, size_t s_stride,
                                                        const short2* __restrict__ map1, const uint16_t* __restrict__ map2,
                                                        int mw, int x0, int y0, uint8_t* __restrict__ dst, int cw, int ch) {
   const int q = blockIdx.x * kBlock + threadIdx.x;
@@ -3173,7 +3096,7 @@ __global__ __launch_bounds__(kBlock) void k_remap_crop(const uint8_t* __restrict
 // Visualizer::UpdateMessages pose accumulation (src/Visualizer.cpp:304-325): final_i = final_{i-1} * SE3(q_i, s·t_i).
 // Strictly sequential (float SE(3) products are not associative to the last bit), one lane; n is a trajectory
 // length, not a pixel count.
-__global__ void k_trajectory(const float* __restrict__ poses, int n, Pose prev, float t_scale, int reference_axes,
+static __global__ void k_trajectory(const float* __restrict__ poses, int n, Pose prev, float t_scale, int reference_axes,
                              float* __restrict__ out) {
   if (threadIdx.x || blockIdx.x) return;
   for (int i = 0; i < n; i++) {
@@ -3194,7 +3117,7 @@ __global__ void k_trajectory(const float* __restrict__ poses, int n, Pose prev, 
 // The same accumulation as a prefix product (SE(3) composition is associative; in floats the grouping shows in the last
 // bits, so this is the default "clean" mode, not the reference-visualiser one): one block, every thread multiplies its run
 // of poses, a Hillis-Steele scan over the 1024 run products, then every thread replays its run behind its prefix.
-__global__ __launch_bounds__(1024) void k_trajectory_scan(const float* __restrict__ poses, int n, Pose start, float t_scale,
+static __global__ __launch_bounds__(1024) void k_trajectory_scan(const float* __restrict__ poses, int n, Pose start, float t_scale,
                                                           int reference_axes, float* __restrict__ out) {
   __shared__ Pose part[1024];
   const int tid = threadIdx.x;
@@ -3237,7 +3160,7 @@ __global__ __launch_bounds__(1024) void k_trajectory_scan(const float* __restric
   }
 }
 
-__global__ void k_se3_ops(int op, const float* in_a, const float* in_b, float* out, int* flag) {
+static __global__ void k_se3_ops(int op, const float* in_a, const float* in_b, float* out, int* flag) {
   if (threadIdx.x || blockIdx.x) return;
   Pose a, b, o;
   if (op == 0) {  // exp

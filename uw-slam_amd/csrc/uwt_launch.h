@@ -1,0 +1,47 @@
+// uwt_launch.h — internal: the launch dispatchers of the heavy kernel templates, one translation unit per family so that the
+// library builds in parallel (uwt_launch_residual.hip, uwt_launch_general.hip, uwt_launch_flow.hip, uwt_launch_align.hip).
+// A dispatcher picks the instantiation from run-time facts (arithmetic set, depth plane, level width, intrinsics, factors) and
+// enqueues it; it reports nothing — the caller checks hipGetLastError().
+#pragma once
+
+#include "uwt_kernels.h"
+
+namespace uwt {
+
+struct LaunchSel {
+  int arith;           // kArithOpenCV / kArithLegacy (uwt_params::arith)
+  bool depth;          // the context has a depth plane
+  bool acc64;          // f64 normal-equation sums (uwt_params::accumulate_f64)
+  bool compute_only;   // the diagnostic twin (uwt_profile_enable bit 2)
+};
+
+// pixels per vector group at a level: 4 where the level's rows are whole groups, else 1 (the coarsest levels of sizes like
+// 736 x 480 x 5: 46 wide, or 752 x 480: 94 and 47 wide)
+inline int level_vec(const LevelK& L) { return L.w % 4 == 0 ? 4 : 1; }
+inline bool level_plain(const ResidualArgs& a) { return a.zf == 1.0f && a.af == 1.0f && a.L.fx == a.L.fy; }
+
+// k_residual, identity weights / nearest sampler (and the per-stage dump form)
+void launch_residual(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, int n_pairs, bool dump);
+// the scale pass (weights != 0: k_resid_hist_v) and the weighted / bilinear k_residual of one evaluation
+void launch_general(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, int n_pairs, int sampler, int weights,
+                    unsigned int* hist, PairScale* scale);
+// the per-stage (dump-capable) form: k_resid_hist + k_scale_stage (weights != 0), then k_residual_general
+void launch_general_dump(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const GeneralArgs& ga, int n_pairs);
+// explicit point tables (k_residual_points)
+void launch_points(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const PointsArgs& pa);
+
+// the chained flow of a few pairs: k_iterate, k_coarse (up to kCoarseMaxLevels levels in one launch), k_finish
+void launch_iterate(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const IterArgs& ia, int n_pairs);
+void launch_coarse_chain(hipStream_t s, const LaunchSel& sel, const CoarseArgs& ca, int n_pairs);
+void launch_finish(hipStream_t s, const IterArgs& ia, int n_pairs, float* d_poses, StatsOut* d_stats);
+// one coarse level of a batch, one block per pair: k_coarse_w4 (identity weights) / k_coarse_weighted
+void launch_coarse_level(hipStream_t s, const LaunchSel& sel, const CoarseArgs& ca, int cnt, int weights);
+
+// runs the statements with AR a compile-time constant
+#define UWT_WITH_AR(arith, ...)                                              \
+  do {                                                                       \
+    if ((arith) == kArithLegacy) { constexpr int AR = kArithLegacy; __VA_ARGS__; }  \
+    else { constexpr int AR = kArithOpenCV; __VA_ARGS__; }                   \
+  } while (0)
+
+}  // namespace uwt

@@ -1,0 +1,60 @@
+// uwt_launch_residual.hip — dispatch of k_residual on the identity-weights / nearest-sampler path (the dominant kernel), its
+// per-stage dump form, and k_residual_points.
+#include "uwt_launch.h"
+
+namespace uwt {
+namespace {
+
+template <int AR, int VEC, bool DEPTH, bool UNIT, bool DUMP>
+void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64, bool compute_only) {
+  const dim3 grid(a.slices, n_pairs), blk(kBlock);
+  if constexpr (VEC == 4 && UNIT && !DUMP) {
+    if (acc64 && a.L.fx == a.L.fy) {   // the production instantiation, its diagnostic twin and its streamed twin (load_group)
+      if (compute_only) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, true>), grid, blk, 0, s, a);
+      else if (a.stream_planes) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, false, true>), grid, blk, 0, s, a);
+      else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true>), grid, blk, 0, s, a);
+      return;
+    }
+  }
+  if (acc64) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double>), grid, blk, 0, s, a);
+  else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, float>), grid, blk, 0, s, a);
+}
+
+template <int AR, int VEC, bool DEPTH>
+void launch_residual_vd(hipStream_t s, const ResidualArgs& a, int n_pairs, bool unit, bool dump, bool acc64, bool co) {
+  if (unit) {
+    if (dump) launch_residual_t<AR, VEC, DEPTH, true, true>(s, a, n_pairs, acc64, false);
+    else launch_residual_t<AR, VEC, DEPTH, true, false>(s, a, n_pairs, acc64, co);
+  } else {
+    if (dump) launch_residual_t<AR, VEC, DEPTH, false, true>(s, a, n_pairs, acc64, false);
+    else launch_residual_t<AR, VEC, DEPTH, false, false>(s, a, n_pairs, acc64, co);
+  }
+}
+
+}  // namespace
+
+void launch_residual(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, int n_pairs, bool dump) {
+  const bool unit = (a.zf == 1.0f && a.af == 1.0f);
+  const bool co = sel.compute_only && !dump;
+  const int vec = level_vec(a.L);
+  UWT_WITH_AR(sel.arith,
+    if (vec == 4) {
+      if (sel.depth) launch_residual_vd<AR, 4, true>(s, a, n_pairs, unit, dump, sel.acc64, co);
+      else launch_residual_vd<AR, 4, false>(s, a, n_pairs, unit, dump, sel.acc64, co);
+    } else {
+      if (sel.depth) launch_residual_vd<AR, 1, true>(s, a, n_pairs, unit, dump, sel.acc64, co);
+      else launch_residual_vd<AR, 1, false>(s, a, n_pairs, unit, dump, sel.acc64, co);
+    });
+}
+
+void launch_points(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const PointsArgs& pa) {
+  const bool unit = (a.zf == 1.0f && a.af == 1.0f);
+  const dim3 grid(a.slices), blk(kBlock);
+  UWT_WITH_AR(sel.arith,
+    if (unit && sel.acc64) hipLaunchKernelGGL((k_residual_points<AR, true, false, double>), grid, blk, 0, s, a, pa);
+    else if (unit) hipLaunchKernelGGL((k_residual_points<AR, true, false, float>), grid, blk, 0, s, a, pa);
+    else if (sel.acc64) hipLaunchKernelGGL((k_residual_points<AR, false, false, double>), grid, blk, 0, s, a, pa);
+    else hipLaunchKernelGGL((k_residual_points<AR, false, false, float>), grid, blk, 0, s, a, pa));
+}
+
+}  // namespace uwt
