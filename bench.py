@@ -85,6 +85,9 @@ def parse_args(argv=None):
                     help="arithmetic set of the OpenCV steps (include/uwt.h uwt_arith): opencv = what OpenCV 3.x's generic gemm / "
                          "MatExpr / solve paths compute (default, the parity target); legacy = rounds 1-3 (f32 FMA chains, inverse then multiply)")
     ap.add_argument("--no-depth", action="store_true")
+    ap.add_argument("--intrinsics", default="",
+                    help="fx,fy,cx,cy of level 0 (default: TUM-like square pixels, 525 * width / 640, principal point at the centre); "
+                         "EUROC (calibration/calibrationEUROC.xml:16-21): 458.654,457.296,367.215,248.375")
     ap.add_argument("--weights", choices=["identity", "tukey", "huber"], default="identity",
                     help="robust weights (general path; identity is the reference's live setting)")
     ap.add_argument("--bilinear", action="store_true", help="bilinear sampler extension (general path)")
@@ -181,10 +184,37 @@ def latency_figure(capi, params, frames, depth, resident_pose, reps=200):
             poses, stats = ctx.estimate_pose_batch([0], [1])
         out[name + "_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
         out[name + "_evaluations"] = int(stats[0]["iterations"])
-        if name == "bench_schedule":
+        if name == "bench_schedule" and resident_pose is not None:
             out["pose_bit_identical_to_batch"] = bool(np.array_equal(poses[0].view(np.uint32), resident_pose.view(np.uint32)))
         ctx.close()
     return out
+
+
+def other_arith_figure(capi, params, pair_block, Pa, steps, warmup, dev):
+    """alignments/s of the same step (pyramids, gradients, alignment of Pa resident pairs) under the arithmetic set the timed
+    run did NOT use; a context of its own, inputs resident before the clock starts."""
+    import torch
+    h, w = params.height, params.width
+    over = {k: getattr(params, k) for k in ("n_levels", "first_level", "last_level", "max_iters", "early_exit", "has_depth",
+                                            "accumulate_f64", "weights", "sampler", "device")}
+    over["arith"] = 1 - params.arith
+    ctx = capi.Context(capi.default_params(w, h, params.fx, params.fy, params.cx, params.cy, max_frames=2 * Pa, max_pairs=Pa, **over))
+    for i0 in range(0, Pa, 128):
+        fr, dp = pair_block(i0, min(Pa, i0 + 128))
+        ctx.upload_frames(2 * i0, fr, dp)
+    buf = torch.empty((Pa, 7), dtype=torch.float32, device=dev)
+    ref = np.arange(Pa, dtype=np.int32) * 2
+    for _ in range(warmup):
+        ctx.track_batch_async(0, 2 * Pa, ref, ref + 1, buf.data_ptr())
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        ctx.track_batch_async(0, 2 * Pa, ref, ref + 1, buf.data_ptr())
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    ctx.close()
+    return {"arith": "legacy" if over["arith"] == 1 else "opencv", "value": round(Pa * steps / dt, 2), "unit": "alignments/s",
+            "ms_per_step": round(1e3 * dt / steps, 4), "pairs": Pa, "steps": steps}
 
 
 def main(args):
@@ -226,6 +256,10 @@ def main(args):
         raise SystemExit("bench.py: rank %d owns no pair (%d pairs over %d GPUs)" % (rank, total, world))
     f = 525.0 * w / 640.0                                  # TUM-like intrinsics (calibrationTUM.xml:18-22), scaled
     intr = (f, f, w / 2 - 0.5, h / 2 - 0.5)
+    if args.intrinsics:
+        intr = tuple(float(v) for v in args.intrinsics.split(","))
+        if len(intr) != 4:
+            raise SystemExit("bench.py: --intrinsics takes fx,fy,cx,cy")
     has_depth = 0 if args.no_depth else 1
     over = dict(n_levels=args.levels, first_level=args.levels - 1, last_level=0, max_iters=args.iters, early_exit=0,
                 has_depth=has_depth, accumulate_f64=1 if args.acc == "f64" else 0,
@@ -251,19 +285,33 @@ def main(args):
             ref, tgt, dep, _, _ = synth.render_pair(w, h, *intr, seed=gid, z=0.8 + 0.4 * ((gid * 7) % 11) / 10.0,
                                                     with_depth=bool(has_depth))
         refs.append(ref); tgts.append(tgt); deps.append(dep)
-    idx = np.arange(P) % U
-    frames = np.empty((2 * P, h, w), np.uint8)
-    frames[0::2] = np.stack(refs)[idx]
-    frames[1::2] = np.stack(tgts)[idx]
-    depth = None
-    if has_depth:
-        depth = np.empty((2 * P, h, w), np.uint16)
-        depth[0::2] = np.stack(deps)[idx]
-        depth[1::2] = depth[0::2]
-    t_up = time.perf_counter()
-    ctx.upload_frames(0, frames, depth)                    # inputs resident in HBM before the timed region
-    upload_s = time.perf_counter() - t_up                  # blocking copies from pageable numpy memory (secondary figure)
-    upload_bytes = frames.nbytes + (depth.nbytes if depth is not None else 0)
+    ref_stack, tgt_stack = np.stack(refs), np.stack(tgts)
+    dep_stack = np.stack(deps) if has_depth else None
+
+    def pair_block(i0, i1):
+        """frames (and depth) of resident pairs [i0, i1): pair i repeats distinct pair i mod U; slots 2i (reference), 2i + 1 (target)"""
+        ix = np.arange(i0, i1) % U
+        fr = np.empty((2 * (i1 - i0), h, w), np.uint8)
+        fr[0::2] = ref_stack[ix]
+        fr[1::2] = tgt_stack[ix]
+        dp = None
+        if has_depth:
+            dp = np.empty((2 * (i1 - i0), h, w), np.uint16)
+            dp[0::2] = dep_stack[ix]
+            dp[1::2] = dp[0::2]
+        return fr, dp
+
+    # inputs resident in HBM before the timed region.  Uploaded in blocks of CHUNK pairs built from the distinct ones: the host
+    # never holds the whole shard (8192 pairs of 640x480 with depth are 15 GB), only the block in flight
+    CHUNK = 128
+    upload_s, upload_bytes = 0.0, 0
+    for i0 in range(0, P, CHUNK):
+        fr, dp = pair_block(i0, min(P, i0 + CHUNK))
+        t_up = time.perf_counter()
+        ctx.upload_frames(2 * i0, fr, dp)
+        upload_s += time.perf_counter() - t_up             # blocking copies from pageable numpy memory (secondary figure)
+        upload_bytes += fr.nbytes + (dp.nbytes if dp is not None else 0)
+    del fr, dp
     ref_slots = np.arange(P, dtype=np.int32) * 2
     tgt_slots = ref_slots + 1
 
@@ -340,12 +388,21 @@ def main(args):
     streaming = None
     # (not under a profiler: its launches carry the residual kernel's name and, running beside the copies, would blur the
     # per-kernel statistics that are compared with roofline.avg_launch_ms)
+    Ps = min(P, 1024)                                       # pairs of the secondary legs (their own contexts hold 4 Ps and 2 Ps slots)
     if not args.no_profile and world == 1 and not args.reference_schedule and not _under_profiler():
-        streaming = streaming_figure(capi, params, frames, depth, P, max(3, args.steps // 2), gpu_poses)   # 2 batches per round
+        fr, dp = pair_block(0, Ps)
+        streaming = streaming_figure(capi, params, fr, dp, Ps, max(3, args.steps // 2), gpu_poses[:Ps])   # 2 batches per round
+        del fr, dp
     latency = None
-    if not args.no_profile and world == 1 and not args.reference_schedule and not args.bilinear and args.weights == "identity" \
-            and not _under_profiler():
-        latency = latency_figure(capi, params, frames, depth, gpu_poses[0])
+    if not args.no_profile and world == 1 and not args.bilinear and args.weights == "identity" and not _under_profiler():
+        fr, dp = pair_block(0, 1)
+        latency = latency_figure(capi, params, fr, dp, None if args.reference_schedule else gpu_poses[0])
+    # The same workload under the OTHER arithmetic set, measured in this run on a context of its own (never `value`): the default
+    # set (opencv: what OpenCV's generic code paths compute) costs ~19 % of the throughput the legacy set (f32 FMA chains) has,
+    # and which of the two a given reference build computes is unpinned — so both are reported, side by side.
+    other = None
+    if not args.no_profile and world == 1 and not _under_profiler():
+        other = other_arith_figure(capi, params, pair_block, Ps, args.steps, args.warmup, dev)
 
     value = total * args.steps / dt
     px_per_align = sum((w >> l) * (h >> l) for l in range(args.levels))
@@ -400,6 +457,12 @@ def main(args):
             out["streaming"] = streaming
         if latency:
             out["single_pair_latency"] = latency
+        if other:
+            mine = {"arith": args.arith, "value": round(value, 2), "unit": "alignments/s", "ms_per_step": round(1e3 * dt / args.steps, 4),
+                    "pairs": P, "steps": args.steps}
+            out["arith_sets"] = {args.arith: mine, other["arith"]: other,
+                                 "note": "the same step under both arithmetic sets of the OpenCV expressions on the path (include/uwt.h "
+                                         "uwt_arith), measured in this run; `value` is the set named in config.arithmetic"}
         if res_launches:
             facts, facts_note = _quoted_facts(capi, args.arith)
             alg_bytes = ALG_BYTES_PER_PIXEL_ITER * res_pixels
@@ -445,6 +508,14 @@ def main(args):
             if clock_ghz:
                 # SIMD cycles the chip spent per pixel-iteration: 1024 SIMDs x 64 lanes
                 valu["simd_cycles_per_pixel"] = round(res_ms * 1e-3 * clock_ghz * 1e9 * 1024 * 64 / res_pixels, 1)
+                vipp = facts.get("valu_instructions_per_pixel") if default_shape and args.weights == "identity" and not args.bilinear \
+                    and args.acc == "f64" else None
+                if vipp:
+                    # the bound the line names, as a fraction of its peak: vector instructions the kernel retires per second over
+                    # what the chip can issue — 1024 SIMDs x 16 lanes per cycle (a 64-lane instruction occupies its SIMD for four
+                    # cycles) at the clock the chip held under this kernel
+                    valu["frac_of_valu_peak"] = round(vipp * (res_pixels / (res_ms * 1e-3)) / (1024 * 16 * clock_ghz * 1e9), 4)
+                    valu["valu_peak_lane_instructions_per_s"] = round(1024 * 16 * clock_ghz * 1e9, 0)
             # counter and compiler facts of the production instantiation, only for the workload they were collected on
             for k in ("valu_instructions_per_pixel", "f64_fma_per_pixel", "instruction_mix_source", "vgprs", "waves_per_simd",
                       "lds_bytes_per_block", "resource_source"):

@@ -79,9 +79,9 @@ def _pipeline_worker(rank, world, port, n_pairs, steps, q):
     for k in range(steps):
         def align(buf, k=k):
             bufs.add(buf.data_ptr())
-            for j, gid in enumerate(mine):
-                buf[j] = torch.arange(7, dtype=torch.float32) + 10.0 * float(gid) + 1000.0 * k
+            buf.copy_(torch.arange(7, dtype=torch.float32)[None, :] + 10.0 * torch.from_numpy(mine).to(torch.float32)[:, None] + 1000.0 * k)
         glob = pipe.step(align)
+        assert pipe.wait() is glob                                   # (CPU: nothing to wait for; the handle is the same buffer)
         seen.append(glob.clone().numpy())
         assert np.array_equal(pipe.last_local().numpy()[:, 0], 10.0 * mine + 1000.0 * k)
     assert len(bufs) == min(2, steps)                                # the two pose buffers take turns
@@ -107,6 +107,27 @@ def test_bench_step_pipeline_world2_double_buffered_gather(n_pairs):
     seen = q.get(timeout=180)
     for p in procs:
         p.join(timeout=180)
+        assert p.exitcode == 0
+    for k in range(steps):
+        expect = np.arange(7, dtype=np.float32)[None, :] + 10.0 * np.arange(n_pairs, dtype=np.float32)[:, None] + 1000.0 * k
+        assert np.array_equal(seen[k], expect), k
+
+
+@pytest.mark.parametrize("n_pairs", [8192, 8191])
+def test_bench_step_pipeline_world8_config4_shards(n_pairs):
+    """BASELINE config 4's exchange at its own size: 8 192 pairs (and 8 191: uneven shards, the padded send block) sharded
+    round-robin over 8 ranks, the bench's double-buffered step loop for three steps over gloo — every step's gathered block is
+    all pairs' poses of that step in global pair order."""
+    world, steps = 8, 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_pipeline_worker, args=(r, world, port, n_pairs, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    seen = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=300)
         assert p.exitcode == 0
     for k in range(steps):
         expect = np.arange(7, dtype=np.float32)[None, :] + 10.0 * np.arange(n_pairs, dtype=np.float32)[:, None] + 1000.0 * k

@@ -1,7 +1,8 @@
 """BASELINE.json's configurations at their full size, as far as one GPU and no dataset allow (`-m gpu`).
 
   config 2  "EUROC MH_01 sequential tracking, 640x480, 4 pyramid levels, 10 GN iters/level": a 65-frame synthetic sequence
-            without depth (z = 1, as EUROC has none) through SequenceTracker, every pose against the oracle;
+            without depth (z = 1, as EUROC has none) under EUROC's own calibration (fx != fy) through SequenceTracker, every
+            pose against the oracle;
   config 1/2 data path: a 752x480 EUROC-layout directory (mav0/cam0/data + state_groundtruth_estimate0/data.csv) through
             tools/track_sequence.py, centre crop to 640x480 with the principal point shifted;
   config 5  "TUM freiburg1_desk 640x480 + Huber, pose accuracy vs ground truth": a TUM-layout directory (rgb/, depth/,
@@ -25,6 +26,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INTR = (525.0, 525.0, 319.5, 239.5)          # calibration/calibrationTUM.xml:18-22
+# calibration/calibrationEUROC.xml:16-21 (fx != fy), the principal point moved by the centre crop 752 -> 640 (56 columns)
+EUROC_INTR = (458.654, 457.296, 367.215 - 56.0, 248.375)
 FIXED = dict(n_levels=4, first_level=3, last_level=0, max_iters=10, early_exit=0)
 
 
@@ -47,11 +50,11 @@ def test_config2_sequential_640x480_no_depth_4x10_every_pose_is_the_oracles(synt
     S = importlib.import_module("uw-slam_amd.sequence")
     T = importlib.import_module("uw-slam_amd.trajectory")
     w, h, n = 640, 480, 65
-    frames, _, rel, absp = synth.render_sequence(w, h, *INTR, n=n, seed=21)
-    trk = S.SequenceTracker(w, h, *INTR, depth=False, chunk=24, **FIXED)        # 64 pairs streamed as 24 + 24 + 16
+    frames, _, rel, absp = synth.render_sequence(w, h, *EUROC_INTR, n=n, seed=21)
+    trk = S.SequenceTracker(w, h, *EUROC_INTR, depth=False, chunk=24, **FIXED)        # 64 pairs streamed as 24 + 24 + 16
     poses, stats = trk.track(frames)
     assert poses.shape == (n - 1, 7) and all(s["status"] == 0 and s["iterations"] == 40 for s in stats)
-    p = O.default_params(w, h, *INTR, has_depth=0, **FIXED)
+    p = O.default_params(w, h, *EUROC_INTR, has_depth=0, **FIXED)
     ref = _oracle_pairs(O, p, frames)
     for i, (st, pose_cpu) in enumerate(ref):
         assert st == 0
@@ -126,3 +129,38 @@ def test_config5_tum_layout_depth_huber_through_the_cli_with_ate(tmp_path, synth
     print("config 5 stand-in (Huber, depth): ATE %.4f m, RPE %.5f m / %.5f rad over %d pairs"
           % (m["ate_rmse_m"], m["rpe_trans_rmse_m"], m["rpe_rot_rmse_rad"], n - 1))
     assert m["rpe_trans_rmse_m"] < 0.02 and m["rpe_rot_rmse_rad"] < 0.02
+
+
+@pytest.mark.one_arith
+def test_config4_single_gpu_leg_8192_resident_pairs(O):
+    """BASELINE config 4's work on ONE GPU (its N = 1 point, SURVEY §8e "identical total work"): 8 192 pairs of 640x480 with
+    depth resident at once (16 384 frame slots, 60 GB of planes), the headline schedule (4 levels x 10 iterations), one call
+    of the whole per-frame path.  128 distinct pairs tiled: every one of the 8 192 poses equals its distinct original bit for
+    bit, and the 128 originals equal the oracle's.  Uploaded in blocks: the host never holds the shard."""
+    import torch
+    sys.path.insert(0, ROOT)
+    import bench
+    capi = importlib.import_module("uw-slam_amd.capi")
+    gen = bench._cpp_generator()
+    w, h, P, U = 640, 480, 8192, 128
+    refs, tgts, deps = zip(*[gen(w, h, INTR, gid, True) for gid in range(U)])
+    refs, tgts, deps = np.stack(refs), np.stack(tgts), np.stack(deps)
+    ctx = capi.Context(capi.default_params(w, h, *INTR, max_frames=2 * P, max_pairs=P, has_depth=1, **FIXED))
+    for i0 in range(0, P, 256):
+        ix = np.arange(i0, i0 + 256) % U
+        fr = np.empty((512, h, w), np.uint8); fr[0::2] = refs[ix]; fr[1::2] = tgts[ix]
+        dp = np.empty((512, h, w), np.uint16); dp[0::2] = deps[ix]; dp[1::2] = deps[ix]
+        ctx.upload_frames(2 * i0, fr, dp)
+    buf = torch.zeros((P, 7), dtype=torch.float32, device="cuda")
+    ref = np.arange(P, dtype=np.int32) * 2
+    ctx.track_batch_async(0, 2 * P, ref, ref + 1, buf.data_ptr())
+    ctx.sync()
+    poses = buf.cpu().numpy()
+    assert np.isfinite(poses).all()
+    assert np.array_equal(poses.view(np.uint32), poses[np.arange(P) % U].view(np.uint32))      # tiled copies = their originals
+    p = O.default_params(w, h, *INTR, has_depth=1, **FIXED)
+    with concurrent.futures.ThreadPoolExecutor(max_workers=os.cpu_count() or 4) as ex:
+        cpu = list(ex.map(lambda u: O.align_pair(p, refs[u], tgts[u], deps[u])[:2], range(U)))
+    for u, (st, pose_cpu) in enumerate(cpu):
+        assert st == 0 and np.array_equal(poses[u].view(np.uint32), pose_cpu.view(np.uint32)), u
+    ctx.close()

@@ -480,3 +480,59 @@ print("ok")
         env = dict(os.environ, TEST_TAIL_UPDATE=switch, **extra)
         r = subprocess.run([sys.executable, "-c", code], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=540)
         assert r.returncode == 0 and b"ok" in r.stdout, (switch, extra, r.stderr.decode()[-2000:])
+
+
+@pytest.mark.gpu
+def test_two_contexts_driven_from_two_host_threads_concurrently(capi, O, synth):
+    """include/uwt.h: "one ctx per host thread per GPU".  Two contexts (different sizes and schedules), each driven by a host
+    thread of its own at the same time — batches through uwt_track_batch_async, one pair per call, per-stage calls — give what
+    each gives alone, bit for bit, and the oracle's poses."""
+    import threading
+    cfgs = [dict(w=320, h=240, intr=(262.5, 262.5, 159.5, 119.5), n=24, seed=9100,
+                 over=dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0, has_depth=1)),
+            dict(w=160, h=96, intr=(131.25, 130.5, 79.5, 47.5), n=9, seed=9200,
+                 over=dict(has_depth=0, weights=2))]                      # the reference's early-exit schedule, Huber weights
+    work = []
+    for c in cfgs:
+        pairs = [synth.render_pair(c["w"], c["h"], *c["intr"], seed=c["seed"] + s, with_depth=bool(c["over"]["has_depth"]))[:3] for s in range(3)]
+        po = O.default_params(c["w"], c["h"], *c["intr"], **c["over"])
+        want = [O.align_pair(po, r, t, d if c["over"]["has_depth"] else None)[1] for r, t, d in pairs]
+        ctx = capi.Context(capi.default_params(c["w"], c["h"], *c["intr"], max_frames=2 * c["n"], max_pairs=c["n"], **c["over"]))
+        frames = np.stack([f for i in range(c["n"]) for f in pairs[i % 3][:2]])
+        depth = np.stack([pairs[i % 3][2] for i in range(c["n"]) for _ in (0, 1)]) if c["over"]["has_depth"] else None
+        ctx.upload_frames(0, frames, depth)
+        work.append((c, ctx, want))
+
+    def drive(c, ctx, want, out, reps):
+        try:
+            n = c["n"]
+            ref = np.arange(n, dtype=np.int32) * 2
+            for rep in range(reps):
+                ctx.build_pyramids(0, 2 * n)
+                ctx.apply_gradient(0, 2 * n)
+                batch, _ = ctx.estimate_pose_batch(ref, ref + 1, raise_on_pair_failure=True)
+                single, _ = ctx.estimate_pose_batch([2], [3], raise_on_pair_failure=True)
+                gx = ctx.get_plane(0, 1, capi.PLANE_GRADX)
+                out.append((batch.copy(), single[0].copy(), gx.copy()))
+        except Exception as e:      # a failure in a thread must fail the test, not vanish
+            out.append(e)
+
+    serial = [[] for _ in work]
+    for (c, ctx, want), out in zip(work, serial):
+        drive(c, ctx, want, out, 1)
+    together = [[] for _ in work]
+    threads = [threading.Thread(target=drive, args=(c, ctx, want, out, 6)) for (c, ctx, want), out in zip(work, together)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+        assert not t.is_alive()
+    for (c, ctx, want), s_out, t_out in zip(work, serial, together):
+        assert len(t_out) == 6 and not any(isinstance(r, Exception) for r in s_out + t_out), [r for r in s_out + t_out if isinstance(r, Exception)]
+        b0, s0, g0 = s_out[0]
+        for i in range(c["n"]):
+            assert np.array_equal(b0[i].view(np.uint32), want[i % 3].view(np.uint32)), i
+        for b, s1, g in t_out:
+            assert np.array_equal(b.view(np.uint32), b0.view(np.uint32)) and np.array_equal(s1.view(np.uint32), s0.view(np.uint32))
+            assert np.array_equal(g, g0)
+        ctx.close()

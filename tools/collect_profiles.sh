@@ -6,7 +6,7 @@
 # traffic counters (separate --pmc passes, never together with other trace domains), SQ counters of the residual kernel.
 set -u
 R=$(pwd)
-out=$R/gpurun_out/${1:-prof_r04}
+out=$R/gpurun_out/${1:-prof_r05}
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 stats() {  # name, bench args...
@@ -42,7 +42,7 @@ for a in opencv legacy; do
   python3 tools/sq_summary.py $out/sq_$a k_residual $((1024*640*480)) $out/sq_counters_k_residual_${a}_level0_p1024.csv
 done
 # the robust-weight path: level-0 launches of the scale pass and of the weighted accumulation at 256 pairs
-bash tools/exp/r3_sq.sh ${1:-prof_r04}/sq_huber k_resid_hist_v --pairs 256 --unique 8 --weights huber > /dev/null 2>&1
+bash tools/sq_passes.sh ${1:-prof_r05}/sq_huber k_resid_hist_v --pairs 256 --unique 8 --weights huber > /dev/null 2>&1
 python3 tools/sq_summary.py $out/sq_huber k_resid_hist_v $((256*640*480)) $out/sq_counters_k_resid_hist_v_level0_p256_huber.csv
 python3 tools/sq_summary.py $out/sq_huber "k_residual<" $((256*640*480)) $out/sq_counters_k_residual_weighted_level0_p256_huber.csv
 python3 tools/per_level_table.py $(find $out/stats_default_p1024 -name "*kernel_trace.csv" | head -1) > $out/per_level_launch_table_trace.md 2>/dev/null

@@ -86,6 +86,10 @@ struct uwt_ctx {
   void* scratch = nullptr;              // per-stage entry points
   size_t scratch_bytes = 0;
   bool profiling = false;
+  int spec_budget = 0;                  // speculative launching: evaluations a level gets (0: first_poll + 1); doubled when an alignment
+                                        // was cut short, halved again after kSpecCalm calls in a row that were not
+  int spec_calm = 0;
+  static constexpr int kSpecCalm = 64;
   bool speculate = false;               // set by the synchronous entry for one or two pairs: launch a level's usual number of
                                         // iterations without reading back, check once at the end, redo conservatively if cut short
   // the synchronous small-batch call: results and the cut-short flag are written by the last kernel straight into this
@@ -422,19 +426,18 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
   // take plus one, nothing is read back, and the level switch notes on the device whether a pair was cut short — the
   // caller looks once, behind the results, and redoes the alignment the careful way in that (rare) case.
   const bool speculate = c->speculate && p.early_exit;
-  const int spec_iters = std::min(p.max_iters, c->tn.first_poll + 1);
+  const int spec_iters = std::min(p.max_iters, std::max(c->spec_budget, c->tn.first_poll + 1));
   ia.cut_short = speculate ? &c->d_small->cut : nullptr;
   if (speculate) c->h_small->cut = 0;   // host store into page-locked memory, ahead of the launches that may set it
   ia.inline_pairs = c->inline_pairs ? 1 : 0;
   for (int i = 0; i < 4; i++) ia.pair_slots[i] = c->pair_slots[i];
-  // The coarsest levels — those a single block evaluates, rows of whole groups of four — run to their end in one launch
-  // (k_coarse), at least one finer level left for k_iterate.
+  // The coarsest levels — those a single block evaluates — run to their end in one launch (k_coarse), at least one finer level
+  // left for k_iterate.
   int start_lvl = p.first_level;
   bool after_coarse = false;
   {
     int nc = 0;
-    while (nc < kCoarseMaxLevels && start_lvl - nc > p.last_level && c->lv[start_lvl - nc].n <= kCoarseMaxPixels &&
-           c->vecl[start_lvl - nc] == 4) nc++;
+    while (nc < kCoarseMaxLevels && start_lvl - nc > p.last_level && c->lv[start_lvl - nc].n <= kCoarseMaxPixels) nc++;
     if (nc > 0 && c->tn.coarse && !c->profiling && !c->compute_only) {
       CoarseArgs ca;
       std::memset(&ca, 0, sizeof(ca));
@@ -535,8 +538,8 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
 // Tracker::EstimatePose for a batch, enqueued on the context's stream (src/Tracker.cpp:362-597)
 // The chained flow pays where an alignment is bound by kernel boundaries and dependent round trips, not by arithmetic: a
 // few pairs on their own (the drop-in call).  In a batch every block would repeat its pair's update.  Measured at 640x480
-// (tools/exp/latency_small_batches.py): ahead up to 6 pairs in fixed schedules, up to 16 in early-exit schedules (half
-// the launches between two read-backs), level from there on (UWT_CHAINED=1 / 0 force it on / off for A/B runs).
+// (round 2, profiles/r03/DESIGN_lab_notes_r01-r03.md): ahead up to 6 pairs in fixed schedules, up to 16 in early-exit schedules
+// (half the launches between two read-backs), level from there on (uwt_tuning::chained = 1 / 0 force it on / off).
 static bool takes_chained_flow(const uwt_ctx* c, int n_pairs) {
   const int few = c->p.early_exit ? 16 : 6;
   return c->p.accumulate_f64 != 0 && c->p.sampler == 0 && c->p.weights == 0 && (c->tn.chained > 0 || (c->tn.chained < 0 && n_pairs <= few));
@@ -590,14 +593,14 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   // The coarsest levels of a batch in ONE launch each (round 3): one block per pair runs the level to its end — evaluation,
   // update, exit test and hand-off on the device, the record in LDS (four blocks per CU) — instead of a residual and an update
   // launch per evaluation whose blocks, a few pixel groups long, run 25-50 % below the level-0 rate.  f64 sums, levels of up to
-  // coarse_batch_px pixels whose rows are whole groups of four (others stay on the launches); identity weights: k_coarse_w4;
+  // coarse_batch_px pixels (rows of whole groups of four or not: the kernels' VEC switch); identity weights: k_coarse_w4;
   // robust weights over the nearest sampler: k_coarse_weighted (histogram, scale, weighted sums and update of a whole level in
   // one block); the bilinear sampler stays on the launches.  Square pixels with unit factors or not: the kernels' PLAIN switch.
   bool coarse_lvl[UWT_MAX_LEVELS] = {};
   if (p.accumulate_f64 != 0 && (!general || (p.sampler == 0 && p.weights != 0 && c->tn.coarse_weighted)) && c->tn.coarse_batch_px > 0 &&
       !c->compute_only && !(c->profiling && p.early_exit))
     for (int lvl = p.first_level; lvl >= p.last_level; lvl--)
-      coarse_lvl[lvl] = c->vecl[lvl] == 4 && c->lv[lvl].n <= c->tn.coarse_batch_px;
+      coarse_lvl[lvl] = c->lv[lvl].n <= c->tn.coarse_batch_px;
   // one coarse level of pairs [base, base + cnt) on stream s; resume: the pairs' states exist (a level ran before this one)
   auto run_coarse = [&](int base, int cnt, hipStream_t s, int lvl, bool resume) -> int {
     CoarseArgs ca;
@@ -1106,6 +1109,7 @@ int uwt_set_tuning(uwt_ctx* c, const uwt_tuning* t) {
   (void)hipSetDevice(c->p.device);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->tn = *t;
+  c->spec_budget = c->spec_calm = 0;
   for (int32_t* b : {&c->tn.coarse, &c->tn.coarse_weighted, &c->tn.overlap_gradients, &c->tn.speculation, &c->tn.fused_stages,
                      &c->tn.pyramid_batch, &c->tn.persistent})
     *b = *b != 0;
@@ -1132,6 +1136,7 @@ int uwt_update_params(uwt_ctx* c, const uwt_params* p) {
     HIPCHK(c, hipMemset(c->scale, 0, sizeof(PairScale) * o.max_pairs));
   }
   c->p = *p;
+  c->spec_budget = c->spec_calm = 0;   // a new schedule: the speculative budget starts over
   return UWT_OK;
 }
 
@@ -1366,9 +1371,11 @@ int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slot
   const bool small = n_pairs <= uwt_ctx::kSmallBatch;
   static_assert(sizeof(StatsOut) == sizeof(uwt_stats), "stats are copied as they are");
   // One or two pairs under an early-exit schedule are launched speculatively (see enqueue_estimate_chained): no read-back
-  // inside the alignment, one look at the "cut short" flag behind the results, a careful second run if it is set.
+  // inside the alignment, one look at the "cut short" flag behind the results.  If it is set the alignment is run again with
+  // twice the evaluations per level (the budget stays: the next frames of a sequence tend to need what this one needed; it
+  // comes down again after kSpecCalm calls that were not cut), and the careful way — read-backs — if that is cut short too.
   c->speculate = n_pairs <= 2 && c->p.early_exit && !c->profiling && takes_chained_flow(c, n_pairs) && c->tn.speculation;
-  for (int attempt = 0; attempt < 2; attempt++) {
+  for (int attempt = 0; attempt < 3; attempt++) {
     st = enqueue_estimate(c, n_pairs, small ? c->d_small->poses : c->d_poses, small ? c->d_small->stats : c->d_stats);
     if (st) { c->speculate = false; c->inline_pairs = false; return st; }
     if (!small) {
@@ -1380,10 +1387,17 @@ int uwt_estimate_pose_batch(uwt_ctx* c, int32_t n_pairs, const int32_t* ref_slot
       std::memcpy(poses_out, c->h_small->poses, sizeof(float) * 7 * n_pairs);
       std::memcpy(tmp.data(), c->h_small->stats, sizeof(uwt_stats) * n_pairs);
     }
-    const bool redo = c->speculate && c->h_small->cut != 0;
-    c->speculate = false;
-    if (!redo) break;
+    if (!c->speculate) break;
+    const int base = c->tn.first_poll + 1;
+    if (c->h_small->cut == 0) {
+      if (c->spec_budget > base && ++c->spec_calm >= uwt_ctx::kSpecCalm) { c->spec_budget = std::max(base, c->spec_budget / 2); c->spec_calm = 0; }
+      break;
+    }
+    c->spec_calm = 0;
+    c->spec_budget = std::min(c->p.max_iters, 2 * std::max(c->spec_budget, base));
+    if (attempt == 1) c->speculate = false;   // cut short twice: the third run reads back
   }
+  c->speculate = false;
   c->inline_pairs = false;
   if (c->profiling) {
     st = prof_collect(c);

@@ -2463,12 +2463,14 @@ struct CoarseArgs {
 // NLEV: levels the launch can run (the loop over them is unrolled).  The batch form (one block per pair of a whole batch, one
 // level per launch, PASS 14) stays at ~210 registers, two waves per SIMD: forced to 128 it spills and loses (measured), so it
 // pays only on the smallest levels, where the per-evaluation launches run furthest below the level-0 rate.
-template <int AR, bool DEPTH, bool PLAIN, int PASS, int NLEV>
+// VECSEL: pixels per vector group of the levels the launch runs: 4 (every level's rows are whole groups of four), 1 (none's are:
+// a lone level like 46 x 30 or 47 x 30), 0 (decided per level at run time: a chain like 46 -> 92 wide)
+template <int AR, bool DEPTH, bool PLAIN, int PASS, int NLEV, int VECSEL>
 __device__ __forceinline__ void coarse_body(const CoarseArgs& ca);
 
-template <int AR, bool DEPTH, bool PLAIN, int PASS = kIteratePass, int NLEV = kCoarseMaxLevels>
+template <int AR, bool DEPTH, bool PLAIN, int PASS = kIteratePass, int NLEV = kCoarseMaxLevels, int VECSEL = 4>
 __global__ __launch_bounds__(kBlock) void k_coarse(const CoarseArgs ca) {
-  coarse_body<AR, DEPTH, PLAIN, PASS, NLEV>(ca);
+  coarse_body<AR, DEPTH, PLAIN, PASS, NLEV, VECSEL>(ca);
 }
 // The batch form (one block per pair of a whole batch, PASS 14, one level per launch) held to four waves per SIMD: all blocks
 // of a 1024-pair batch are resident at once, and while one block's wave 0 runs its update the other three blocks of the CU
@@ -2477,11 +2479,11 @@ __global__ __launch_bounds__(kBlock) void k_coarse(const CoarseArgs ca) {
 // update had their ~40 constant registers hoisted above the iteration loop, live through the residual loop), and the thread
 // index behind the update's and the reduction's lane roles is opaque (thread_here).  What remains above 128 is parked in
 // scratch outside the residual loop (40 bytes per lane).
-template <int AR, bool DEPTH, bool PLAIN, int PASS = 14, int NLEV = 1>
+template <int AR, bool DEPTH, bool PLAIN, int VECSEL = 4, int PASS = 14, int NLEV = 1>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_coarse_w4(const CoarseArgs ca) {
-  coarse_body<AR, DEPTH, PLAIN, PASS, NLEV>(ca);
+  coarse_body<AR, DEPTH, PLAIN, PASS, NLEV, VECSEL>(ca);
 }
-template <int AR, bool DEPTH, bool PLAIN, int PASS, int NLEV>
+template <int AR, bool DEPTH, bool PLAIN, int PASS, int NLEV, int VECSEL>
 __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
   constexpr int kLds = iterate_lds_bytes(PASS);
   __shared__ __attribute__((aligned(16))) unsigned char lds[kLds + kRecWords * 4 + 64];
@@ -2506,8 +2508,9 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
   for (int li = 0; li < NLEV; li++) {
     if (li >= ca.n_levels) break;   // block-uniform
     const ResidualArgs& a = ca.lv[li];   // read in place (the kernel-argument segment); what differs travels in `ov`
+    const bool v4 = VECSEL == 4 || (VECSEL == 0 && a.L.w % 4 == 0);   // block-uniform
     CoreOverride ov;
-    ov.groups_per_block = ((a.L.n / 4 + kBlock - 1) / kBlock) * kBlock;   // the whole level
+    ov.groups_per_block = ((a.L.n / (v4 ? 4 : 1) + kBlock - 1) / kBlock) * kBlock;   // the whole level
     ov.rec = rec;
     UpdateArgs u = ca.u;
     u.slices = 1;
@@ -2516,7 +2519,14 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
       for (int k = 0; k < u.max_iters; k++) {
         __syncthreads();   // every thread has taken the state out of the update's LDS bytes: they become the reduction's
         if (threadIdx.x == 0) *cur = st;
-        residual_core<AR, 4, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
+        if constexpr (VECSEL == 4) {
+          residual_core<AR, 4, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
+        } else if constexpr (VECSEL == 1) {
+          residual_core<AR, 1, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
+        } else {
+          if (v4) residual_core<AR, 4, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
+          else residual_core<AR, 1, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
+        }
         __syncthreads();   // the record and the state are in LDS; the reduction's image is free
         u.k = k;
         st = update_compute(u, rec, cur, lds, false);   // ends with a barrier: every thread has the new state
@@ -2541,7 +2551,7 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
 // launch, the weighted launch and the update (three dependent launches of a few blocks each, ~20 us for a lone pair) by ~8 us
 // of one resident block.  Same device functions as the launches it replaces: same bits.
 // ------------------------------------------------------------------------------------------------------------
-template <int AR, bool DEPTH, int WEIGHTS, bool PLAIN, int NLEV = kCoarseMaxLevels>
+template <int AR, bool DEPTH, int WEIGHTS, bool PLAIN, int NLEV = kCoarseMaxLevels, int VEC = 4>
 __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca) {
   __shared__ unsigned int h[kHistBins * kHistRep];                                  // the residual histogram, kHistRep replicas per bin
   __shared__ unsigned int h_scratch[kHistBins];                                     // wave_scale's working copy
@@ -2569,7 +2579,7 @@ __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca)
     if (li >= ca.n_levels) break;   // block-uniform
     const ResidualArgs& a = ca.lv[li];
     const LevelK L = a.L;
-    const int n_groups = L.n / 4;
+    const int n_groups = L.n / VEC;
     CoreOverride ov;
     ov.groups_per_block = ((n_groups + kBlock - 1) / kBlock) * kBlock;   // the whole level
     ov.rec = rec;
@@ -2588,7 +2598,7 @@ __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca)
         {
           WarpK K;
           warp_setup<AR>(st.pose, K);
-          hist_groups<AR, 4, DEPTH, 0>(L, K, a.img + ref_off, a.img + tgt_off, DEPTH ? a.depth + ref_off : nullptr,
+          hist_groups<AR, VEC, DEPTH, 0>(L, K, a.img + ref_off, a.img + tgt_off, DEPTH ? a.depth + ref_off : nullptr,
                                        h + 255 * kHistRep + (threadIdx.x & (kHistRep - 1)), 0, n_groups, n_groups);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // hist_groups' masked ds_add_u32 are its asm's own
@@ -2611,7 +2621,7 @@ __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca)
         }
         __syncthreads();
         // the weighted sums (src/Tracker.cpp:554-561) through the weight table; the record lands in LDS
-        residual_core<AR, 4, DEPTH, PLAIN, false, double, PLAIN, 0, WEIGHTS>(a, pair, 0, st.pose, nullptr, nullptr, ref_slot, tgt_slot, &ov);
+        residual_core<AR, VEC, DEPTH, PLAIN, false, double, PLAIN, 0, WEIGHTS>(a, pair, 0, st.pose, nullptr, nullptr, ref_slot, tgt_slot, &ov);
         __syncthreads();
         u.k = k;
         st = update_compute(u, rec, &cur, ulds, false);   // ends with a barrier: every thread has the new state

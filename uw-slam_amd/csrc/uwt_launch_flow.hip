@@ -25,16 +25,20 @@ void launch_iterate_t(hipStream_t s, const ResidualArgs& a, const IterArgs& ia, 
 template <int AR, bool DEPTH>
 void launch_coarse_level_t(hipStream_t s, const CoarseArgs& ca, int cnt, int weights) {
   const dim3 grid(cnt), blk(kBlock);
-  const bool plain = level_plain(ca.lv[0]);
+  const bool v4 = level_vec(ca.lv[0].L) == 4;
+  const bool plain = v4 && level_plain(ca.lv[0]);   // (a level that goes pixel by pixel takes the general form: one instantiation)
   if (weights == kWeightsTukeyRef) {
     if (plain) hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsTukeyRef, true, 1>), grid, blk, 0, s, ca);
-    else hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsTukeyRef, false, 1>), grid, blk, 0, s, ca);
+    else if (v4) hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsTukeyRef, false, 1>), grid, blk, 0, s, ca);
+    else hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsTukeyRef, false, 1, 1>), grid, blk, 0, s, ca);
   } else if (weights == kWeightsHuber) {
     if (plain) hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsHuber, true, 1>), grid, blk, 0, s, ca);
-    else hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsHuber, false, 1>), grid, blk, 0, s, ca);
+    else if (v4) hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsHuber, false, 1>), grid, blk, 0, s, ca);
+    else hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsHuber, false, 1, 1>), grid, blk, 0, s, ca);
   } else {
     if (plain) hipLaunchKernelGGL((k_coarse_w4<AR, DEPTH, true>), grid, blk, 0, s, ca);
-    else hipLaunchKernelGGL((k_coarse_w4<AR, DEPTH, false>), grid, blk, 0, s, ca);
+    else if (v4) hipLaunchKernelGGL((k_coarse_w4<AR, DEPTH, false>), grid, blk, 0, s, ca);
+    else hipLaunchKernelGGL((k_coarse_w4<AR, DEPTH, false, 1>), grid, blk, 0, s, ca);
   }
 }
 
@@ -46,22 +50,30 @@ void launch_iterate(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, 
     else launch_iterate_t<AR, false>(s, a, ia, n_pairs, sel.compute_only));
 }
 
-// up to kCoarseMaxLevels coarsest levels (each a multiple of 4 wide) of a few pairs, to their end, in one launch
+// up to kCoarseMaxLevels coarsest levels of a few pairs, to their end, in one launch; when one of them goes pixel by pixel
+// (rows that are not whole groups of four) the launch takes the general form with the group width decided per level
 void launch_coarse_chain(hipStream_t s, const LaunchSel& sel, const CoarseArgs& ca, int n_pairs) {
   const dim3 grid(n_pairs), blk(kBlock);
-  const bool plain = level_plain(ca.lv[0]);
+  bool all4 = true;
+  for (int i = 0; i < ca.n_levels; i++) all4 = all4 && level_vec(ca.lv[i].L) == 4;
+  const bool plain = all4 && level_plain(ca.lv[0]);
   UWT_WITH_AR(sel.arith,
-    if (sel.depth && plain) hipLaunchKernelGGL((k_coarse<AR, true, true>), grid, blk, 0, s, ca);
-    else if (sel.depth) hipLaunchKernelGGL((k_coarse<AR, true, false>), grid, blk, 0, s, ca);
-    else if (plain) hipLaunchKernelGGL((k_coarse<AR, false, true>), grid, blk, 0, s, ca);
-    else hipLaunchKernelGGL((k_coarse<AR, false, false>), grid, blk, 0, s, ca));
+    if (sel.depth) {
+      if (plain) hipLaunchKernelGGL((k_coarse<AR, true, true>), grid, blk, 0, s, ca);
+      else if (all4) hipLaunchKernelGGL((k_coarse<AR, true, false>), grid, blk, 0, s, ca);
+      else hipLaunchKernelGGL((k_coarse<AR, true, false, kIteratePass, kCoarseMaxLevels, 0>), grid, blk, 0, s, ca);
+    } else {
+      if (plain) hipLaunchKernelGGL((k_coarse<AR, false, true>), grid, blk, 0, s, ca);
+      else if (all4) hipLaunchKernelGGL((k_coarse<AR, false, false>), grid, blk, 0, s, ca);
+      else hipLaunchKernelGGL((k_coarse<AR, false, false, kIteratePass, kCoarseMaxLevels, 0>), grid, blk, 0, s, ca);
+    });
 }
 
 void launch_finish(hipStream_t s, const IterArgs& ia, int n_pairs, float* d_poses, StatsOut* d_stats) {
   hipLaunchKernelGGL(k_finish, dim3(n_pairs), dim3(kUpdateBlock), 0, s, ia, d_poses, d_stats);
 }
 
-// one coarse level (a multiple of 4 wide, up to kCoarseMaxPixels) of a batch, one block per pair, the level's iterations in one
+// one coarse level (up to kCoarseMaxPixels) of a batch, one block per pair, the level's iterations in one
 // launch: identity weights k_coarse_w4, robust weights over the nearest sampler k_coarse_weighted
 void launch_coarse_level(hipStream_t s, const LaunchSel& sel, const CoarseArgs& ca, int cnt, int weights) {
   UWT_WITH_AR(sel.arith,

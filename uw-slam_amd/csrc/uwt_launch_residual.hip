@@ -16,6 +16,14 @@ void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool a
       return;
     }
   }
+  if constexpr (VEC == 4 && !DUMP) {
+    // the general Jacobian form (fx != fy — the reference's own EUROC calibration: 458.654 / 457.296 — and / or non-unit
+    // factors): its streamed twin too
+    if (acc64 && a.stream_planes) {
+      hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, true>), grid, blk, 0, s, a);
+      return;
+    }
+  }
   if (acc64) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double>), grid, blk, 0, s, a);
   else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, float>), grid, blk, 0, s, a);
 }

@@ -117,7 +117,17 @@ class GatherPipeline:
             align(self.poses[b])
             self.gathered = self.gatherers[b].gather(self.poses[b])
         self.pending[b] = True
-        return self.gathered
+        return self.gathered      # valid on another stream only behind wait(); see there
 
     def last_local(self):
         return self.poses[self.last]
+
+    def wait(self, stream=None):
+        """Orders `stream` (default: torch's current stream) behind the exchange of the last step(): the tensor step() returned
+        — a buffer of the gatherer, overwritten by the next step but one — may be read on that stream after this call, and only
+        until the next-but-one step().  step() itself returns with the all_gather and the un-shuffle still in flight on the
+        pipeline's private stream; without this (or a device synchronisation, as bench.py's fence) a consumer races them.
+        No-op on a CPU device (the gloo form runs synchronously)."""
+        if self.cuda and self.pending[self.last]:
+            (stream or self.torch.cuda.current_stream()).wait_event(self.gather_done[self.last])
+        return self.gathered
