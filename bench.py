@@ -94,6 +94,8 @@ def parse_args(argv=None):
     ap.add_argument("--reference-schedule", action="store_true",
                     help="the reference's EstimatePose constants: 5 levels, iterate 4..1, <= 50 iterations, early exit "
                          "(src/Tracker.cpp:364-372); not the headline workload")
+    ap.add_argument("--tuning", default="", help="launch-shape switches for A/B runs: comma-separated uwt_tuning fields, e.g. "
+                    "residual_plane=0,split=1 (never changes results; include/uwt.h)")
     ap.add_argument("--cpu-pairs", type=int, default=96,
                     help="alignments timed on the CPU oracle, 1 thread (rank 0, N=1 only; 0 = skip); ~10 s at 640x480")
     ap.add_argument("--no-profile", action="store_true",
@@ -273,7 +275,11 @@ def main(args):
     gen = _cpp_generator() if args.generator == "cpp" else None
     # under a profiler, per-kernel statistics are to describe whole-batch launches, one at a time: the two-halves-on-two-streams
     # form of a batch overlaps launches of half the size, whose durations a trace cannot tell apart from waiting
-    ctx = capi.Context(params, tuning=dict(split=1) if _under_profiler() else None)
+    tuning = dict(split=1) if _under_profiler() else {}
+    for kv in filter(None, args.tuning.split(",")):
+        k, v = kv.split("=")
+        tuning[k.strip()] = int(v)
+    ctx = capi.Context(params, tuning=tuning or None)
 
     U = min(args.unique, P)
     refs, tgts, deps = [], [], []
@@ -435,7 +441,7 @@ def main(args):
                            "rounded once, MatExpr-folded unprojection, A.inv()*b as cv::solve (LU on the right-hand side)"
                            if args.arith == "opencv" else
                            "legacy (rounds 1-3): 4-/2-term products as f32 FMA chains, (x-cx)*invfx as written, inverse then f64-accumulated product"),
-            "normal_equation_accumulation": args.acc, "weights": args.weights,
+            "normal_equation_accumulation": args.acc, "weights": args.weights, "tuning": tuning or "defaults",
             "sampler": "bilinear" if args.bilinear else "nearest", "total_pairs": total, "pairs_on_rank0": P,
             "sharding": "round-robin pairs, RCCL all_gather of poses, global order on every rank" if use_dist else "single GPU",
         },

@@ -126,8 +126,7 @@ typedef struct uwt_tuning {
   int32_t speculation;       /* one or two pairs, early exit: launch without read-backs, redo carefully if cut short [1]    */
   int32_t fused_stages;      /* a few frames: whole pyramid / all gradient levels in one launch each [1]                    */
   int32_t pyramid_batch;     /* batches: pyramid levels 1..3 in one pass over level 0 [1]                                   */
-  int32_t persistent;        /* one pair per call: the whole alignment in ONE launch (k_align_one) [1]                      */
-  int32_t reserved[4];
+  int32_t reserved[5];
 } uwt_tuning;
 
 /* ---- lifecycle -------------------------------------------------------------------------------------------- */

@@ -171,7 +171,7 @@ def test_speculative_launching_redoes_a_cut_short_alignment(capi, O, synth, monk
     out = []
     for forced in (False, True):
         ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, has_depth=1),
-                           tuning=dict(first_poll=1, persistent=0) if forced else dict(persistent=0))
+                           tuning=dict(first_poll=1) if forced else None)
         _upload_pair(ctx, ref, tgt, dep)
         poses, stats = ctx.estimate_pose_batch([0], [1], raise_on_pair_failure=True)
         out.append((poses[0].copy(), stats[0]["iterations"]))
@@ -326,7 +326,7 @@ def test_coarse_levels_in_one_launch_match_the_per_launch_form(capi, O, synth, m
     po = O.default_params(w, h, *intr, **over)
     want = [O.align_pair(po, r, t, d, want_trace=True) for r, t, d in pairs]
     for no_coarse in (False, True):
-        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, **over), tuning=dict(coarse=int(not no_coarse), persistent=0))
+        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, **over), tuning=dict(coarse=int(not no_coarse)))
         for (r, t, d), (st, pose_cpu, tr) in zip(pairs, want):
             _upload_pair(ctx, r, t, d)
             poses, stats = ctx.estimate_pose_batch([0], [1])

@@ -195,3 +195,4 @@ def test_tracker_mirror_weight_helpers(O):
     ox, oy = O.scharr3(img)
     assert np.array_equal(gx, ox) and np.array_equal(gy, oy)
 
+

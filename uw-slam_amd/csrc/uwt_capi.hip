@@ -155,7 +155,6 @@ uwt_tuning default_tuning() {
   t.speculation = 1;
   t.fused_stages = 1;
   t.pyramid_batch = 1;
-  t.persistent = 1;
   return t;
 }
 
@@ -1111,7 +1110,7 @@ int uwt_set_tuning(uwt_ctx* c, const uwt_tuning* t) {
   c->tn = *t;
   c->spec_budget = c->spec_calm = 0;
   for (int32_t* b : {&c->tn.coarse, &c->tn.coarse_weighted, &c->tn.overlap_gradients, &c->tn.speculation, &c->tn.fused_stages,
-                     &c->tn.pyramid_batch, &c->tn.persistent})
+                     &c->tn.pyramid_batch})
     *b = *b != 0;
   std::memset(c->tn.reserved, 0, sizeof(c->tn.reserved));
   return UWT_OK;
