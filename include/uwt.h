@@ -126,7 +126,9 @@ typedef struct uwt_tuning {
   int32_t speculation;       /* one or two pairs, early exit: launch without read-backs, redo carefully if cut short [1]    */
   int32_t fused_stages;      /* a few frames: whole pyramid / all gradient levels in one launch each [1]                    */
   int32_t pyramid_batch;     /* batches: pyramid levels 1..3 in one pass over level 0 [1]                                   */
-  int32_t reserved[5];
+  int32_t typed_loads;       /* the dominant kernel reads gradients and depth through typed buffer loads (the texture path
+                                converts int16 to float: three vector conversions per pixel less) [1]                       */
+  int32_t reserved[4];
 } uwt_tuning;
 
 /* ---- lifecycle -------------------------------------------------------------------------------------------- */

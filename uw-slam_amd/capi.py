@@ -35,8 +35,8 @@ class Tuning(C.Structure):
         ("split", C.c_int32), ("split_min", C.c_int32), ("split_min_px", C.c_int64), ("stream_bytes", C.c_int64),
         ("tail_update", C.c_int32), ("target_blocks", C.c_int32), ("coarse", C.c_int32), ("coarse_batch_px", C.c_int32),
         ("coarse_weighted", C.c_int32), ("overlap_gradients", C.c_int32), ("first_poll", C.c_int32), ("chained", C.c_int32),
-        ("speculation", C.c_int32), ("fused_stages", C.c_int32), ("pyramid_batch", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("speculation", C.c_int32), ("fused_stages", C.c_int32), ("pyramid_batch", C.c_int32), ("typed_loads", C.c_int32),
+        ("reserved", C.c_int32 * 4),
     ]
 
 

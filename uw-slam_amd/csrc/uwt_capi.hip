@@ -155,6 +155,7 @@ uwt_tuning default_tuning() {
   t.speculation = 1;
   t.fused_stages = 1;
   t.pyramid_batch = 1;
+  t.typed_loads = 1;
   return t;
 }
 
@@ -294,6 +295,7 @@ ResidualArgs residual_args(uwt_ctx* c, int lvl) {
   a.partials = c->partials;
   a.scale = c->scale;
   a.gain = c->p.gain;
+  a.typed_loads = c->tn.typed_loads;
   return a;
 }
 
@@ -1110,7 +1112,7 @@ int uwt_set_tuning(uwt_ctx* c, const uwt_tuning* t) {
   c->tn = *t;
   c->spec_budget = c->spec_calm = 0;
   for (int32_t* b : {&c->tn.coarse, &c->tn.coarse_weighted, &c->tn.overlap_gradients, &c->tn.speculation, &c->tn.fused_stages,
-                     &c->tn.pyramid_batch})
+                     &c->tn.pyramid_batch, &c->tn.typed_loads})
     *b = *b != 0;
   std::memset(c->tn.reserved, 0, sizeof(c->tn.reserved));
   return UWT_OK;

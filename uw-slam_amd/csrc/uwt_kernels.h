@@ -1222,6 +1222,7 @@ struct ResidualArgs {
   float* dumpR;
   uint8_t* dumpV;
   float* dumpW;             // per-pixel robust weights (general path only)
+  int typed_loads;          // 1: the launch takes the TYPED instantiation where one exists (uwt_tuning::typed_loads; load_group_typed)
   int stream_planes;        // 1: the launch takes the STREAM instantiation (load_group) where one exists: the batch's planes of this level exceed the caches
   int probe;                // 1: thread 0 of every block leaves its shader-clock / 100 MHz real-time deltas in words 60, 61
                             // of the block's record (uwt_profile_clock: the clock the chip holds under this kernel)
@@ -1239,15 +1240,21 @@ struct CoreOverride {
   const PairScale* scale = nullptr;   // k_coarse_weighted: in LDS
 };
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef int i4v __attribute__((ext_vector_type(4)));
 // reference planes of one group of VEC pixels, as loaded (one vector load per plane)
 template <int VEC>
 struct RefGroup {
   uint8_t i1[VEC];
   int16_t gx[VEC], gy[VEC];
   uint16_t dp[VEC];
+  f4v gx4, gy4, dp4;    // TYPED (VEC = 4): the same values as floats, converted by the texture path (load_group_typed)
 };
 
-template <int VEC, bool DEPTH, bool COMPUTE_ONLY = false, bool STREAM = false>
+// STREAM (the loads of the loop; a template parameter of everything down to here): bit 0 = non-temporal plane loads (below), bit 1 =
+// TYPED plane loads (load_group_typed).
+constexpr int kLoadsPlain = 0, kLoadsStream = 1, kLoadsTyped = 2;
+template <int VEC, bool DEPTH, bool COMPUTE_ONLY = false, int STREAM = 0>
 __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __restrict__ I1, const int16_t* __restrict__ GX,
                                            const int16_t* __restrict__ GY, const uint16_t* __restrict__ DP, uint32_t idx) {
   constexpr bool FAKE_PLANES = COMPUTE_ONLY;
@@ -1266,7 +1273,7 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
     // pairs +3 %.  A batch that fits the 256 MB memory-side cache keeps the plain loads (its planes come back from there at the
     // next evaluation; streamed: 64 pairs -3.6 %).  A template parameter, not a flag: the compiler merges the two sides of a
     // run-time choice into plain loads.
-    if constexpr (STREAM) {
+    if constexpr ((STREAM & kLoadsStream) != 0) {
       *reinterpret_cast<uint32_t*>(r.i1) = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(I1 + idx));
       *reinterpret_cast<u2v*>(r.gx) = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(reinterpret_cast<const uint8_t*>(GX) + o2));
       *reinterpret_cast<u2v*>(r.gy) = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(reinterpret_cast<const uint8_t*>(GY) + o2));
@@ -1286,11 +1293,59 @@ __device__ __forceinline__ void load_group(RefGroup<VEC>& r, const uint8_t* __re
   }
 }
 
+// TYPED plane loads (round 5).  The gradients and the depth are 16-bit integers in memory and floats in the arithmetic: three
+// conversions per pixel on the vector ALU, which is what bounds the kernel.  A typed buffer load (tbuffer_load_format_xyzw,
+// 16_16_16_16 SSCALED: the texture path's format conversion) delivers the four values of a group as floats — the same floats
+// (every int16 is exact in f32; tools/ubench/tbuffer_check.hip) — for no vector instruction; the price is registers (16 bytes
+// per plane and group in flight instead of 8).  The compiler has no builtin for typed loads, and loads hidden in asm
+// statements are invisible to its s_waitcnt bookkeeping, so in this form EVERY vector-memory operation of the loop is an asm
+// statement and the waits are written out: vmcnt retires in order, the gathers are issued ahead of the next group's planes,
+// so "the gathers have landed" is vmcnt(<plane loads issued behind them>) and "the planes have landed" is vmcnt(0) at the head
+// of the next step.  Each wait names the registers it releases as in-out operands: nothing that reads them can be scheduled
+// above it.
+// raw buffer resource of `bytes` bytes at p (uniform): stride 0, destination select xyzw; the format comes from the instruction
+__device__ __forceinline__ i4v make_rsrc(const void* p, uint32_t bytes) {
+  const unsigned long long b = (unsigned long long)p;
+  i4v r;
+  r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+  r.z = __builtin_amdgcn_readfirstlane((int)bytes);
+  r.w = __builtin_amdgcn_readfirstlane(0x00027FAC);
+  return r;
+}
+struct TypedPlanes { const uint8_t* I1; i4v gx, gy, dp; };
+// The request is IN PLACE: the asm's operands are in-out, so the registers of the group that is being consumed are the ones the
+// next group lands in (whatever still needs an old value has copied it out before — a copy of landed data), and between this
+// request and the wait that releases them no instruction touches them.
+template <bool DEPTH, bool NT>
+__device__ __forceinline__ void load_group_typed(RefGroup<4>& r, const TypedPlanes& P, uint32_t idx) {
+  const uint32_t o2 = idx * 2u;
+  uint32_t& w = *reinterpret_cast<uint32_t*>(r.i1);
+  if constexpr (NT) {
+    asm volatile("global_load_dword %0, %1, %2 nt" : "+v"(w) : "v"(idx), "s"(P.I1));
+    asm volatile("tbuffer_load_format_xyzw %0, %1, %2, 0 format:[BUF_DATA_FORMAT_16_16_16_16,BUF_NUM_FORMAT_SSCALED] offen nt" : "+v"(r.gx4) : "v"(o2), "s"(P.gx));
+    asm volatile("tbuffer_load_format_xyzw %0, %1, %2, 0 format:[BUF_DATA_FORMAT_16_16_16_16,BUF_NUM_FORMAT_SSCALED] offen nt" : "+v"(r.gy4) : "v"(o2), "s"(P.gy));
+    if constexpr (DEPTH) asm volatile("tbuffer_load_format_xyzw %0, %1, %2, 0 format:[BUF_DATA_FORMAT_16_16_16_16,BUF_NUM_FORMAT_SSCALED] offen nt" : "+v"(r.dp4) : "v"(o2), "s"(P.dp));
+  } else {
+    asm volatile("global_load_dword %0, %1, %2" : "+v"(w) : "v"(idx), "s"(P.I1));
+    asm volatile("tbuffer_load_format_xyzw %0, %1, %2, 0 format:[BUF_DATA_FORMAT_16_16_16_16,BUF_NUM_FORMAT_SSCALED] offen" : "+v"(r.gx4) : "v"(o2), "s"(P.gx));
+    asm volatile("tbuffer_load_format_xyzw %0, %1, %2, 0 format:[BUF_DATA_FORMAT_16_16_16_16,BUF_NUM_FORMAT_SSCALED] offen" : "+v"(r.gy4) : "v"(o2), "s"(P.gy));
+    if constexpr (DEPTH) asm volatile("tbuffer_load_format_xyzw %0, %1, %2, 0 format:[BUF_DATA_FORMAT_16_16_16_16,BUF_NUM_FORMAT_SSCALED] offen" : "+v"(r.dp4) : "v"(o2), "s"(P.dp));
+  }
+}
+// "the planes of rg have landed": everything issued so far has (the head of a step, and behind the loop)
+template <bool DEPTH>
+__device__ __forceinline__ void wait_planes_typed(RefGroup<4>& r) {
+  uint32_t& w = *reinterpret_cast<uint32_t*>(r.i1);
+  if constexpr (DEPTH) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w), "+v"(r.gx4), "+v"(r.gy4), "+v"(r.dp4));
+  else asm volatile("s_waitcnt vmcnt(0)" : "+v"(w), "+v"(r.gx4), "+v"(r.gy4));
+}
+
 // COMPUTE_ONLY (diagnostic, uwt_profile_enable(ctx, 2)): the same instruction stream with every load of the loop replaced
 // by register arithmetic — results are meaningless, its duration is the kernel's own instruction-issue floor.
 // residual_core evaluates one slice of one pair at `pose`; `lds` (optional) is the caller's buffer for the block reduction.
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, int EXT_LDS = 0, bool STREAM = false>   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's; STREAM: load_group
+          bool COMPUTE_ONLY = false, int EXT_LDS = 0, int STREAM = 0>   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's; STREAM: load_group
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first = nullptr, int ref_slot = -1,
                                               int tgt_slot = -1, const CoreOverride* ov = nullptr);
@@ -1306,7 +1361,7 @@ __device__ __forceinline__ void load_first_group(RefGroup<VEC>& rg, const Residu
 }
 
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, bool STREAM = false>
+          bool COMPUTE_ONLY = false, int STREAM = 0>
 __device__ __forceinline__ bool residual_block(const ResidualArgs& a, const int pair, const int slice) {   // false: the pair is not iterating
   Pose pose;
   if constexpr (COMPUTE_ONLY) {
@@ -1323,7 +1378,7 @@ __device__ __forceinline__ bool residual_block(const ResidualArgs& a, const int 
 }
 
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
-          int EXT_LDS, bool STREAM>
+          int EXT_LDS, int STREAM>
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot,
                                               const CoreOverride* ov) {
@@ -1398,7 +1453,21 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   // are needed last, for the residuals).
   RefGroup<VEC> rg;
   int g = g_begin + (int)threadIdx.x;
-  if (first) rg = *first;   // requested by the caller ahead of the pose (k_iterate: before the update)
+  // TYPED: the planes' 16-bit values arrive as floats (load_group_typed): no conversion on the vector ALU
+  constexpr bool TYPED = (STREAM & kLoadsTyped) != 0;
+  constexpr bool NT = (STREAM & kLoadsStream) != 0;
+  static_assert(!TYPED || (VEC == 4 && std::is_same<AccT, double>::value && !DUMP && !COMPUTE_ONLY && SAMPLER == 0 && WEIGHTS == 0),
+                "typed plane loads: the identity path's production shape");
+  TypedPlanes TP;
+  if constexpr (TYPED) {
+    TP.I1 = I1;
+    TP.gx = make_rsrc(GX, (uint32_t)L.n * 2u);
+    TP.gy = make_rsrc(GY, (uint32_t)L.n * 2u);
+    TP.dp = make_rsrc(DEPTH ? (const void*)DP : (const void*)GX, (uint32_t)L.n * 2u);
+    *reinterpret_cast<uint32_t*>(rg.i1) = 0u;
+    rg.gx4 = rg.gy4 = rg.dp4 = (f4v)(0.f);
+    load_group_typed<DEPTH, NT>(rg, TP, (uint32_t)min(g, n_groups - 1) * VEC);
+  } else if (first) rg = *first;   // requested by the caller ahead of the pose (k_iterate: before the update)
   else load_group<VEC, DEPTH, COMPUTE_ONLY, STREAM>(rg, I1, GX, GY, DP, (uint32_t)min(g, n_groups - 1) * VEC);
   // Pixel coordinates of the thread's group, as floats (small integers: exact).  One division up front, then each step
   // of kBlock groups moves (x, y) by the level's fixed (step mod w, step / w) with at most one wrap.  Lanes past the end
@@ -1414,7 +1483,8 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   using F = typename std::conditional<N == 2, v2f, float>::type;
   constexpr int NU = VEC / N;
   // one step of the loop on the planes in `rg`, which are re-requested in place for the group `ahead` steps on
-  auto body = [&](RefGroup<VEC>& rg, const int ahead) __attribute__((always_inline)) {
+  // (`nxt`: where the next group's planes are requested — `rg` itself, or the other register set of the TYPED form)
+  auto body = [&](RefGroup<VEC>& rg, const int ahead, RefGroup<VEC>& nxt) __attribute__((always_inline)) {
     const bool active = g < g_end;
     const unsigned long long active_mask = __builtin_amdgcn_sicmp(g, g_end, kIcmpSLT);
     constexpr bool TD_READ = TD_LDS;
@@ -1426,6 +1496,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
       for (int i = 0; i < 12; i++) K.Td[i] = tdp[i];
     }
     const uint32_t idx = (uint32_t)min(g, n_groups - 1) * VEC;
+    if constexpr (TYPED) wait_planes_typed<DEPTH>(rg);   // this group's planes, requested a step ago, have landed
     uint8_t i1[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) i1[j] = rg.i1[j];
@@ -1441,7 +1512,11 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
       for (int c = 0; c < N; c++) {
         const int j = u * N + c;
         okin[c] = active_mask;
-        if constexpr (DEPTH) {
+        if constexpr (DEPTH && TYPED) {
+          const float d = rg.dp4[j];              // the same signed 16-bit value, converted by the load
+          okin[c] &= __builtin_amdgcn_fcmpf(d, 0.f, kFcmpOGT);
+          put(z, c, d);
+        } else if constexpr (DEPTH) {
           const int d = (int)(int16_t)rg.dp[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
           okin[c] &= __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
           put(z, c, (float)d);
@@ -1474,6 +1549,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     for (int j = 0; j < VEC; j++) {
       constexpr bool FAKE_GATHER = COMPUTE_ONLY;
       if constexpr (FAKE_GATHER) i2[j] = (int)i1[j] + (int)(gidx[j] & 1);
+      else if constexpr (TYPED) asm volatile("global_load_ubyte %0, %1, %2" : "=v"(i2[j]) : "v"(gidx[j]), "s"(I2));   // (waited for by gathers_landed)
       else if constexpr (SAMPLER == 0) i2[j] = I2[gidx[j]];   // nearest-neighbour gather of the target level (:472)
       else s2[j] = sample_bilinear(I2, L, get(x2[j / N], j % N), get(y2[j / N], j % N));  // EXTENSION; x2 = y2 = 0 for sanitised invalid pixels
     }
@@ -1482,8 +1558,10 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 #pragma unroll
     for (int j = 0; j < VEC; j++) {
       if constexpr (MASKED) {
-        float gxf = (float)rg.gx[j], gyf = (float)rg.gy[j];
-        if constexpr (AR == kArithOpenCV) {
+        float gxf, gyf;
+        if constexpr (TYPED) { gxf = rg.gx4[j]; gyf = rg.gy4[j]; }
+        else { gxf = (float)rg.gx[j]; gyf = (float)rg.gy[j]; }
+        if constexpr (AR == kArithOpenCV && !TYPED) {
           // the gradient is needed as f32 (columns 0, 1) and as f64 (columns 2..5).  Opaque here, so that the double is widened
           // from the float (one conversion with the 16-bit extraction folded in — SDWA — and one widening) instead of being
           // converted from the integer a second time, which costs a separate sign extension per value.
@@ -1502,8 +1580,13 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     // behind the gathers.  The request is unconditional (the index is clamped): inside a branch, the compiler's wait for
     // the gathers would have to assume the branch not taken and count the plane loads in.
     __builtin_amdgcn_sched_barrier(0);
-    load_group<VEC, DEPTH, COMPUTE_ONLY, STREAM>(rg, I1, GX, GY, DP, (uint32_t)min(g + ahead * kBlock, n_groups - 1) * VEC);
+    if constexpr (TYPED) load_group_typed<DEPTH, NT>(nxt, TP, (uint32_t)min(g + ahead * kBlock, n_groups - 1) * VEC);
+    else load_group<VEC, DEPTH, COMPUTE_ONLY, STREAM>(nxt, I1, GX, GY, DP, (uint32_t)min(g + ahead * kBlock, n_groups - 1) * VEC);
     __builtin_amdgcn_sched_barrier(0);
+    // TYPED: "the gathers have landed" = all but the plane loads issued behind them have (vmcnt retires in order)
+    auto gathers_landed = [&]() __attribute__((always_inline)) {
+      if constexpr (TYPED) asm volatile("s_waitcnt vmcnt(%4)" : "+v"(i2[0]), "+v"(i2[1]), "+v"(i2[2]), "+v"(i2[3]) : "n"(DEPTH ? 4 : 3));
+    };
     // kArithOpenCV, identity path: a unit's row is formed in double and goes straight into the sums, one unit at a time (no f32
     // rows of all four pixels held across the phase: the doubles of the small products take their registers)
     constexpr bool DIRECT = AR == kArithOpenCV && MASKED && !GENERAL;
@@ -1518,6 +1601,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
           const int j = u * N + c;
           double Jd[6];
           jacobian_row_f64<SQUARE, F>(g0[u], g1[u], j0, j1, av, bv, c, Jd);
+          if (u == 0 && c == 0) gathers_landed();
           const int ri = i2[j] - (int)i1[j];
           masked_sums_lo(acc, Jd, okm[j]);
           masked_sums_hi<0>(acc, r2d, Jd, (double)ri, 0.0, okm[j]);
@@ -1577,6 +1661,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     for (int u = 0; u < NU; u++)
       pixel_jacobian<AR, UNIT_FACTORS, SQUARE, DUMP, F>(L, a.zf, a.af, x2[u], y2[u], iz[u], g0[u], g1[u], J[u]);
     __builtin_amdgcn_sched_barrier(0);
+    gathers_landed();
     // phase 4: residuals and accumulation
     if constexpr (TABLE) {
       // weights from the per-value table; J <- w * J over packed pairs (src/Tracker.cpp:554-557)
@@ -1676,7 +1761,27 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     xf0 -= wrap ? wf : 0.f;
     yf += wrap ? 1.f : 0.f;
   };
-  for (int it = 0; it < iters; it++, g += kBlock) body(rg, 1);
+  if constexpr (TYPED) {
+    // Two register sets take turns: while the floats of one are being consumed (the gradients live until the step's Jacobians)
+    // the next group lands in the other, whose contents are dead by then — requested in place, no copy of anything in flight
+    // and none of anything landed.  (One set re-requested in place would have to copy the eight gradient floats out first:
+    // what the conversions used to do for nothing.)
+    RefGroup<VEC> rgB;
+    *reinterpret_cast<uint32_t*>(rgB.i1) = 0u;
+    rgB.gx4 = rgB.gy4 = rgB.dp4 = (f4v)(0.f);
+    for (int it = 0; it < iters; it += 2) {
+      body(rg, 1, rgB);
+      g += kBlock;
+      if (it + 1 < iters) {   // block-uniform
+        body(rgB, 1, rg);
+        g += kBlock;
+      }
+    }
+    wait_planes_typed<DEPTH>(rg);    // the last step's request (a clamped, unused group) must not land in registers that have moved on
+    wait_planes_typed<DEPTH>(rgB);
+  } else {
+    for (int it = 0; it < iters; it++, g += kBlock) body(rg, 1, rg);
+  }
   const uint32_t n_valid = (threadIdx.x & 63) == 0 ? n_valid_wave : 0u;
   uint32_t* out_rec = ov ? ov->rec : a.partials + ((size_t)pair * a.slices + slice) * kRecWords;
   constexpr bool R2D = MASKED && !GENERAL;   // the identity path's sum of r^2 is the f64 one
@@ -1698,7 +1803,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 __device__ __forceinline__ void tail_update_wave(const ResidualArgs& a, int pair);   // (behind update_solve_wave)
 
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, bool STREAM = false>
+          bool COMPUTE_ONLY = false, int STREAM = 0>
 __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
   const int pair = (int)blockIdx.y + a.pair_base;
   const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, STREAM>(a, pair, (int)blockIdx.x);
@@ -1710,7 +1815,7 @@ __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
 // The same kernel held to four waves per SIMD (128 registers), for the one instantiation whose allocation lands just above
 // (bilinear sampler + Huber: 129 — the 129th register holds scalar registers the compiler parks across the loop).
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool STREAM = false>
+          int STREAM = 0>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_residual_w4(const ResidualArgs a) {
   const int pair = (int)blockIdx.y + a.pair_base;
   const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, false, STREAM>(a, pair, (int)blockIdx.x);

@@ -11,7 +11,9 @@ void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool a
   if constexpr (VEC == 4 && UNIT && !DUMP) {
     if (acc64 && a.L.fx == a.L.fy) {   // the production instantiation, its diagnostic twin and its streamed twin (load_group)
       if (compute_only) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, true>), grid, blk, 0, s, a);
-      else if (a.stream_planes) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, false, true>), grid, blk, 0, s, a);
+      else if (a.typed_loads && a.stream_planes) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, false, kLoadsTyped | kLoadsStream>), grid, blk, 0, s, a);
+      else if (a.typed_loads) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, false, kLoadsTyped>), grid, blk, 0, s, a);
+      else if (a.stream_planes) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, false, kLoadsStream>), grid, blk, 0, s, a);
       else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true>), grid, blk, 0, s, a);
       return;
     }
@@ -19,8 +21,10 @@ void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool a
   if constexpr (VEC == 4 && !DUMP) {
     // the general Jacobian form (fx != fy — the reference's own EUROC calibration: 458.654 / 457.296 — and / or non-unit
     // factors): its streamed twin too
-    if (acc64 && a.stream_planes) {
-      hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, true>), grid, blk, 0, s, a);
+    if (acc64 && (a.stream_planes || a.typed_loads)) {
+      if (a.typed_loads && a.stream_planes) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsTyped | kLoadsStream>), grid, blk, 0, s, a);
+      else if (a.typed_loads) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsTyped>), grid, blk, 0, s, a);
+      else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsStream>), grid, blk, 0, s, a);
       return;
     }
   }
