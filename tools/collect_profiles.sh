@@ -1,7 +1,8 @@
 #!/bin/bash
 # Collect the round's profiles on the GPU box (run from the repo root through gpurun):
 #   tools/collect_profiles.sh <out dir under gpurun_out>
-# Round 4: every figure of the default workload under both arithmetic sets (opencv = the default, legacy).
+# Round 5: every figure of the default workload under both arithmetic sets (opencv = the default, legacy), the reference's EUROC
+# geometry, config 4's single-GPU leg.
 # kernel-trace statistics and the bench line of the default workload and of the other quoted configurations, HBM
 # traffic counters (separate --pmc passes, never together with other trace domains), SQ counters of the residual kernel.
 set -u
@@ -25,6 +26,15 @@ stats nodepth_p1024 --no-depth --cpu-pairs 16
 stats bilinear_huber_p256 --bilinear --weights huber --pairs 256 --cpu-pairs 8 --unique 8
 stats huber_p1024 --weights huber --cpu-pairs 8 --unique 8
 stats legacy_huber_p256 --arith legacy --weights huber --pairs 256 --cpu-pairs 8 --unique 8
+E=458.654,457.296,367.215,248.375; E736=458.654,457.296,359.215,248.375
+stats euroc_640x480_l4_p1024 --intrinsics $E --cpu-pairs 16
+stats euroc_640x480_l4_nodepth_p1024 --intrinsics $E --no-depth --cpu-pairs 16
+stats euroc_736x480_l5_p1024 --width 736 --intrinsics $E736 --levels 5 --no-depth --unique 64 --cpu-pairs 16
+stats euroc_752x480_l5_p1024 --width 752 --intrinsics $E --levels 5 --no-depth --unique 64 --cpu-pairs 16
+stats euroc_736x480_refsched_p1024 --width 736 --intrinsics $E736 --reference-schedule --no-depth --unique 64 --cpu-pairs 16
+(cd $R && python3 bench.py --gpus 1 --total-pairs 8192 --steps 5 --warmup 2 > $out/bench_total8192_g1.json 2> $out/bench_total8192_g1.err)
+(cd $R && python3 tools/exp/latency_general.py 200 > $out/latency_single_pair.txt 2>/dev/null)
+(cd $R && python3 tools/exp/stage_timing.py > $out/stage_timing.txt 2>/dev/null)
 for a in opencv legacy; do
   for c in FETCH_SIZE WRITE_SIZE; do
     (cd $R && rocprofv3 --kernel-trace --pmc $c -d $out/pmc_${a}_$c --output-format csv -- python3 bench.py --arith $a --cpu-pairs 0 --steps 2 --warmup 1 --no-profile > $out/pmc_${a}_$c.log 2>&1)

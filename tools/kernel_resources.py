@@ -27,11 +27,13 @@ def main():
     if a.remarks:
         text = open(a.remarks).read()
     else:
-        r = subprocess.run(["make", "-B", "-C", os.path.join(ROOT, "uw-slam_amd", "csrc"), "asm"], capture_output=True, text=True)
-        text = r.stdout + r.stderr
-        if r.returncode:
-            sys.stderr.write(text[-4000:])
-            return 1
+        text = ""
+        for unit in ("uwt_capi", "uwt_launch_residual", "uwt_launch_general", "uwt_launch_flow"):   # one object per kernel family
+            r = subprocess.run(["make", "-C", os.path.join(ROOT, "uw-slam_amd", "csrc"), "asm", "UNIT=" + unit], capture_output=True, text=True)
+            text += r.stdout + r.stderr
+            if r.returncode:
+                sys.stderr.write(text[-4000:])
+                return 1
     rows, cur = [], None
     for line in text.splitlines():
         m = re.search(r"remark:\s+(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|"
@@ -58,7 +60,8 @@ def main():
         with open(a.output, "w") as f:
             f.write("# Kernel resource usage (hipcc -Rpass-analysis=kernel-resource-usage, gfx950)\n\n"
                     "Template arguments of `k_residual`: `<ARITH (0 OpenCV, 1 legacy), VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, "
-                    "SAMPLER, WEIGHTS, COMPUTE_ONLY>`.\n\n" + txt)
+                    "SAMPLER, WEIGHTS, COMPUTE_ONLY, LOADS (bit 0: non-temporal plane loads, bit 1: typed plane loads)>`; of `k_iterate`: "
+                    "`<ARITH, VEC, DEPTH, PLAIN, COMPUTE_ONLY, PASS>`; of `k_coarse` / `k_coarse_w4`: `<ARITH, DEPTH, PLAIN, ...>`.\n\n" + txt)
     else:
         sys.stdout.write(txt)
     return 0

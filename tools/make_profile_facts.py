@@ -18,9 +18,9 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# (the last argument: the streamed twin — non-temporal plane loads — that a batch larger than the caches runs at its fine levels)
-PRODUCTION = {"opencv": "k_residual<0, 4, true, true, false, double, true, 0, 0, false, true>",
-              "legacy": "k_residual<1, 4, true, true, false, double, true, 0, 0, false, true>"}
+# (the last argument, 3: typed + non-temporal plane loads — what a batch larger than the caches runs at its fine levels)
+PRODUCTION = {"opencv": "k_residual<0, 4, true, true, false, double, true, 0, 0, false, 3>",
+              "legacy": "k_residual<1, 4, true, true, false, double, true, 0, 0, false, 3>"}
 
 
 def per_dispatch(path, counter):

@@ -19,6 +19,8 @@ ap.add_argument("--single", type=int, default=0, help="1: one pair per synchrono
 ap.add_argument("--weights", type=int, default=0, help="0 identity, 1 Tukey (reference medians), 2 Huber")
 ap.add_argument("--sampler", type=int, default=0, help="0 nearest, 1 bilinear")
 ap.add_argument("--arith", default="opencv", choices=["opencv", "legacy"], help="arithmetic set of both sides")
+ap.add_argument("--intrinsics", default="", help="fx,fy,cx,cy (default: square pixels, 525 * w / 640)")
+ap.add_argument("--tuning", default="", help="uwt_tuning fields of the GPU context, k=v[,k=v] (launch shapes; never results)")
 a = ap.parse_args()
 ARITH = {"opencv": 0, "legacy": 1}[a.arith]
 capi.DEFAULT_ARITH = ARITH
@@ -26,8 +28,12 @@ O.DEFAULT_ARITH = ARITH
 w, h = a.w, a.h
 f = 525.0 * w / 640.0
 intr = (f, f, w / 2 - 0.5, h / 2 - 0.5)
+if a.intrinsics:
+    intr = tuple(float(v) for v in a.intrinsics.split(","))
 if a.mode == "fixed":
     over = dict(n_levels=4, first_level=3, last_level=0, max_iters=10, early_exit=0)
+elif a.mode == "fixed5":     # all five levels, a few iterations each
+    over = dict(n_levels=5, first_level=4, last_level=0, max_iters=4, early_exit=0)
 else:
     over = dict()
 if a.depth:
@@ -37,7 +43,8 @@ if a.weights:
 if a.sampler:
     over["sampler"] = a.sampler
 n = a.n
-ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
+tuning = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in a.tuning.split(",") if kv}
+ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over), tuning=tuning or None)
 po = O.default_params(w, h, *intr, **over)
 frames, depths, cpu = [], [], []
 t0 = time.time()
@@ -73,7 +80,7 @@ dr = np.array([rot_angle(poses[i][:4], cpu[i][1][:4]) for i in range(n)])
 dt = np.array([np.linalg.norm(poses[i][4:].astype(np.float64) - cpu[i][1][4:]) for i in range(n)])
 bit = sum(np.array_equal(poses[i].view(np.uint32), cpu[i][1].view(np.uint32)) for i in range(n))
 it_eq = sum(stats[i]["iterations"] == cpu[i][2] for i in range(n))
-print("arith %s mode %s%s weights=%d sampler=%d %dx%d depth=%d n=%d: bit-identical %d, iterations equal %d, status!=0 %d" % (a.arith, a.mode, " (one pair per call)" if a.single else " (one batch)", a.weights, a.sampler, w, h, a.depth, n, bit, it_eq, sum(s["status"] != 0 for s in stats)))
+print("arith %s%s%s mode %s%s weights=%d sampler=%d %dx%d depth=%d n=%d: bit-identical %d, iterations equal %d, status!=0 %d" % (a.arith, " fx!=fy" if intr[0] != intr[1] else "", " [%s]" % a.tuning if a.tuning else "", a.mode, " (one pair per call)" if a.single else " (one batch)", a.weights, a.sampler, w, h, a.depth, n, bit, it_eq, sum(s["status"] != 0 for s in stats)))
 print("  rot  diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dr), np.percentile(dr, 90), dr.max(), (dr > 1e-4).sum()))
 print("  trans diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dt), np.percentile(dt, 90), dt.max(), (dt > 1e-4).sum()))
 print("  |t| median %.2e ; cpu time/pair %.3fs" % (np.median([np.linalg.norm(c[1][4:]) for c in cpu]), t_cpu / n))

@@ -1456,6 +1456,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   // TYPED: the planes' 16-bit values arrive as floats (load_group_typed): no conversion on the vector ALU
   constexpr bool TYPED = (STREAM & kLoadsTyped) != 0;
   constexpr bool NT = (STREAM & kLoadsStream) != 0;
+  // (measured on the weighted path and on the general Jacobian form too: no gain there — profiles/r05/EXPERIMENTS.md)
   static_assert(!TYPED || (VEC == 4 && std::is_same<AccT, double>::value && !DUMP && !COMPUTE_ONLY && SAMPLER == 0 && WEIGHTS == 0),
                 "typed plane loads: the identity path's production shape");
   TypedPlanes TP;

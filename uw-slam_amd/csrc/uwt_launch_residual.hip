@@ -21,10 +21,8 @@ void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool a
   if constexpr (VEC == 4 && !DUMP) {
     // the general Jacobian form (fx != fy — the reference's own EUROC calibration: 458.654 / 457.296 — and / or non-unit
     // factors): its streamed twin too
-    if (acc64 && (a.stream_planes || a.typed_loads)) {
-      if (a.typed_loads && a.stream_planes) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsTyped | kLoadsStream>), grid, blk, 0, s, a);
-      else if (a.typed_loads) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsTyped>), grid, blk, 0, s, a);
-      else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsStream>), grid, blk, 0, s, a);
+    if (acc64 && a.stream_planes) {
+      hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsStream>), grid, blk, 0, s, a);
       return;
     }
   }
