@@ -21,6 +21,13 @@ void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool a
   if constexpr (VEC == 4 && !DUMP) {
     // the general Jacobian form (fx != fy — the reference's own EUROC calibration: 458.654 / 457.296 — and / or non-unit
     // factors): its streamed twin too
+    if constexpr (UNIT) {   // fx != fy with unit factors (EUROC): typed plane loads here too
+      if (acc64 && a.typed_loads) {
+        if (a.stream_planes) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsTyped | kLoadsStream>), grid, blk, 0, s, a);
+        else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsTyped>), grid, blk, 0, s, a);
+        return;
+      }
+    }
     if (acc64 && a.stream_planes) {
       hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsStream>), grid, blk, 0, s, a);
       return;
