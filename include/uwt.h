@@ -123,7 +123,7 @@ typedef struct uwt_tuning {
   int32_t first_poll;        /* early-exit schedules: evaluations of a level before the host first looks [3]                */
   int32_t chained;           /* -1: update chained into the next evaluation's launch for a few pairs; 1 / 0: always / never
                                 [-1]                                                                                        */
-  int32_t speculation;       /* one or two pairs, early exit: launch without read-backs, redo carefully if cut short [1]    */
+  int32_t speculation;       /* one or two pairs, early exit: launch without read-backs, run again if cut short [1]         */
   int32_t fused_stages;      /* a few frames: whole pyramid / all gradient levels in one launch each [1]                    */
   int32_t pyramid_batch;     /* batches: pyramid levels 1..3 in one pass over level 0 [1]                                   */
   int32_t typed_loads;       /* the dominant kernel reads gradients and depth through typed buffer loads (the texture path
@@ -196,8 +196,9 @@ int uwt_apply_gradient(uwt_ctx* ctx, int32_t first_slot, int32_t n);
  * Dense points (Tracker::ObtainAllPoints, :1259-1310) are implicit: the pixel grid is never materialised.
  * Synchronous.  How the launches are laid out follows the batch (same results either way): a few pairs per call take
  * the chained flow (one launch per evaluation, the coarsest levels in one launch, results written straight into
- * page-locked memory; one or two pairs of an early-exit schedule are launched without read-backs and redone the careful
- * way if a level was cut short), batches take one residual and one update launch per evaluation, large fixed-schedule
+ * page-locked memory; one or two pairs of an early-exit schedule are launched without read-backs, each level with a budget of
+ * evaluations, and run again with twice the budget — then with read-backs — if a level was cut short), batches take one
+ * residual and one update launch per evaluation (coarse levels one launch per level, one block per pair), large fixed-schedule
  * batches run as two halves on two streams with the update in the tail of the residual launch. */
 int uwt_estimate_pose_batch(uwt_ctx* ctx, int32_t n_pairs, const int32_t* ref_slots, const int32_t* tgt_slots,
                             float* poses_out, uwt_stats* stats_out_or_null);

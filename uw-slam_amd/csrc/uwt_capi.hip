@@ -659,7 +659,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
       ua.partials = c->partials + shift;
       // Early exit: the host reads back how many pairs are still iterating after the update of evaluation first_poll - 1,
       // then after twice as many, ...  With the reference's constants a level ends at its third evaluation as a rule
-      // (error rises or stalls, src/Tracker.cpp:508), so the first look comes after three (UWT_FIRST_POLL).
+      // (error rises or stalls, src/Tracker.cpp:508), so the first look comes after three (uwt_tuning::first_poll).
       // The read-back is taken one evaluation late (round 3): the count of evaluation k is copied to page-locked memory
       // behind its update, evaluation k + 1 is enqueued, and only then does the host wait for the copy — the GPU works on
       // k + 1 meanwhile instead of idling for the host's round trip (~25 us per look).  When the count says "nobody left",
