@@ -1509,25 +1509,45 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     for (int u = 0; u < NU; u++) {
       F z = bc<F>(1.0f), xf;
       unsigned long long okin[N];
+      float dlow[N];   // MASKED with depth: the depth as a float (its "> 0" test joins the lower bounds below)
 #pragma unroll
       for (int c = 0; c < N; c++) {
         const int j = u * N + c;
         okin[c] = active_mask;
+        dlow[c] = 1.0f;
         if constexpr (DEPTH && TYPED) {
           const float d = rg.dp4[j];              // the same signed 16-bit value, converted by the load
-          okin[c] &= __builtin_amdgcn_fcmpf(d, 0.f, kFcmpOGT);
+          dlow[c] = d;
           put(z, c, d);
         } else if constexpr (DEPTH) {
           const int d = (int)(int16_t)rg.dp[j];   // depths_ is read through at<short> (src/Tracker.cpp:1272)
-          okin[c] &= __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
-          put(z, c, (float)d);
+          dlow[c] = (float)d;
+          if constexpr (!MASKED) okin[c] &= __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
+          put(z, c, dlow[c]);
         }
         put(xf, c, (float)j);
       }
       if constexpr (DEPTH) z = z * bc<F>(L.zscale);
       xf = bc<F>(xf0) + xf;
       if constexpr (MASKED) {
-        pixel_warp_raw<AR, F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N]);
+        if constexpr (DEPTH) {
+          // The three lower bounds — depth > 0 (:1268), y2 > 0, x2 > 0 (:450) — as ONE compare of their minimum.  A NaN position
+          // (z2 = 0: both quotients are NaN, see pixel_warp_raw) drops out of the minimum, which the depth then decides — and
+          // fails the ordered upper-bound compares below, as it fails every compare of the reference's test; -0 and +0 are not
+          // greater than 0 either way.
+          F z2;
+          warp_point<AR, F>(L, K, xf, bc<F>(yf), z, x2[u], y2[u], z2, iz[u]);
+#pragma unroll
+          for (int c = 0; c < N; c++) {
+            const float uc = get(x2[u], c), vc = get(y2[u], c);
+            float lo;
+            asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(uc), "v"(vc), "v"(dlow[c]));
+            okm[u * N + c] = okin[c] & __builtin_amdgcn_fcmpf(lo, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(vc, (float)L.h, kFcmpOLT) &
+                             __builtin_amdgcn_fcmpf(uc, (float)L.w, kFcmpOLT);
+          }
+        } else {
+          pixel_warp_raw<AR, F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N]);
+        }
 #pragma unroll
         for (int c = 0; c < N; c++) {
           float r = get(iz[u], c);
@@ -2058,20 +2078,34 @@ __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, con
     for (int u = 0; u < VEC / N; u++) {
       F z = bc<F>(1.0f), xf, x2u, y2u, izu;
       unsigned long long okin_m[N], okm[N];
+      float dlow[N];
 #pragma unroll
       for (int c = 0; c < N; c++) {
         const int j = u * N + c;
         okin_m[c] = ~0ull;
+        dlow[c] = 1.0f;
         if constexpr (DEPTH) {
           const int d = (int)(int16_t)dp[j];
-          okin_m[c] = __builtin_amdgcn_sicmp(d, 0, kIcmpSGT);
-          put(z, c, (float)d);
+          dlow[c] = (float)d;
+          put(z, c, dlow[c]);
         }
         put(xf, c, (float)x + (float)j);
       }
       if constexpr (DEPTH) z = z * bc<F>(L.zscale);
       // the reciprocal's clamp and its select are of no use here: only x2, y2 (the sample position) are read
-      pixel_warp_raw<AR, F>(L, K, xf, bc<F>((float)y), z, okin_m, x2u, y2u, izu, okm);
+      if constexpr (DEPTH) {   // depth > 0, y2 > 0, x2 > 0 as one compare of their minimum (see residual_core)
+        F z2;
+        warp_point<AR, F>(L, K, xf, bc<F>((float)y), z, x2u, y2u, z2, izu);
+#pragma unroll
+        for (int c = 0; c < N; c++) {
+          const float uc = get(x2u, c), vc = get(y2u, c);
+          float lo;
+          asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(uc), "v"(vc), "v"(dlow[c]));
+          okm[c] = __builtin_amdgcn_fcmpf(lo, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(vc, (float)L.h, kFcmpOLT) & __builtin_amdgcn_fcmpf(uc, (float)L.w, kFcmpOLT);
+        }
+      } else {
+        pixel_warp_raw<AR, F>(L, K, xf, bc<F>((float)y), z, okin_m, x2u, y2u, izu, okm);
+      }
       if constexpr (SAMPLER == 0) {
         // nothing of an invalid pixel is sanitised: its sample index is clamped both ways (any in-range byte will do) and
         // its count is added under an EXEC mask of the valid lanes, like the sums of the accumulation kernel
