@@ -83,7 +83,7 @@ def parse_args(argv=None):
     ap.add_argument("--acc", choices=["f64", "f32"], default="f64")
     ap.add_argument("--arith", choices=["opencv", "legacy"], default="opencv",
                     help="arithmetic set of the OpenCV steps (include/uwt.h uwt_arith): opencv = what OpenCV 3.x's generic gemm / "
-                         "MatExpr / solve paths compute (default, the parity target); legacy = rounds 1-3 (f32 FMA chains, inverse then multiply)")
+                         "MatExpr / solve paths compute (default; which set a given reference build computes is unpinned: both are measured, arith_sets); legacy = rounds 1-3 (f32 FMA chains, inverse then multiply)")
     ap.add_argument("--no-depth", action="store_true")
     ap.add_argument("--intrinsics", default="",
                     help="fx,fy,cx,cy of level 0 (default: TUM-like square pixels, 525 * width / 640, principal point at the centre); "
