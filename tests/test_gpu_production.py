@@ -364,7 +364,8 @@ def test_bench_strong_scaling_mode_single_gpu():
     d = json.loads(r.stdout.decode().strip().splitlines()[-1])
     assert d["scaling"] == "strong" and d["n_gpus"] == 1 and d["config"]["total_pairs"] == 24
     # (at 160x96 a launch lasts a few microseconds: the ratio of two such timings scatters widely — 0.9 … 1.5 seen)
-    assert d["roofline"]["bound"] == "valu" and 0 < d["roofline"]["valu"]["valu_issue_frac"] <= 2.0
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["limited_by"] == "valu" and 0 < d["roofline"]["valu"]["valu_issue_frac"] <= 2.0
+    assert set(d["arith_sets"]) >= {"opencv", "legacy"} and d["arith_sets"]["legacy"]["value"] > 0
     assert d["roofline"]["valu"]["shader_clock_GHz"] > 0.5
 
 
@@ -536,3 +537,44 @@ def test_two_contexts_driven_from_two_host_threads_concurrently(capi, O, synth):
             assert np.array_equal(b.view(np.uint32), b0.view(np.uint32)) and np.array_equal(s1.view(np.uint32), s0.view(np.uint32))
             assert np.array_equal(g, g0)
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_every_tuning_switch_changes_no_bit(capi, O, synth):
+    """uwt_tuning chooses HOW launches are laid out, never WHAT is computed: a batch and a lone pair under the defaults and with
+    every switch flipped one at a time — parts, tail update, slicing target, coarse forms, gradient overlap, first look,
+    chained flow, speculation, fused stages, batch pyramids, typed loads, streamed planes — through the whole per-frame path
+    (pyramids, gradients, alignment): the same poses bit for bit, the oracle's.  Fixed and early-exit schedules."""
+    import torch
+    w, h, n = 320, 240, 20
+    intr = (262.5, 262.5, 159.5, 119.5)
+    settings = [dict(), dict(split=1), dict(split=3, split_min=2), dict(split_min_px=1), dict(tail_update=0), dict(tail_update=2),
+                dict(target_blocks=64), dict(target_blocks=5000), dict(coarse=0), dict(coarse_batch_px=0), dict(coarse_batch_px=30000),
+                dict(overlap_gradients=0), dict(first_poll=1), dict(first_poll=7), dict(chained=0), dict(chained=1), dict(speculation=0),
+                dict(fused_stages=0), dict(pyramid_batch=0), dict(typed_loads=0), dict(stream_bytes=0), dict(stream_bytes=0, typed_loads=0),
+                dict(split_min_px=1, typed_loads=0, tail_update=2)]
+    for over in (dict(n_levels=4, first_level=3, last_level=0, max_iters=5, early_exit=0, has_depth=1), dict(has_depth=1)):
+        pairs = [synth.render_pair(w, h, *intr, seed=9700 + s, with_depth=True, max_t=0.012, max_deg=0.6)[:3] for s in range(4)]
+        po = O.default_params(w, h, *intr, **over)
+        want = [O.align_pair(po, *p)[1] for p in pairs]
+        frames = np.stack([f for i in range(n) for f in pairs[i % 4][:2]])
+        depth = np.stack([pairs[i % 4][2] for i in range(n) for _ in (0, 1)])
+        ref = np.arange(n, dtype=np.int32) * 2
+        first = None
+        for t in settings:
+            ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over), tuning=t or None)
+            ctx.upload_frames(0, frames, depth)
+            buf = torch.zeros((n, 7), dtype=torch.float32, device="cuda")
+            ctx.track_batch_async(0, 2 * n, ref, ref + 1, buf.data_ptr())
+            ctx.sync()
+            batch = buf.cpu().numpy()
+            lone, _ = ctx.estimate_pose_batch([2], [3], raise_on_pair_failure=True)
+            few, _ = ctx.estimate_pose_batch(ref[:5], ref[:5] + 1, raise_on_pair_failure=True)
+            ctx.close()
+            if first is None:
+                first = batch
+                for i in range(n):
+                    assert np.array_equal(batch[i].view(np.uint32), want[i % 4].view(np.uint32)), (over, i)
+            assert np.array_equal(batch.view(np.uint32), first.view(np.uint32)), (over, t)
+            assert np.array_equal(lone[0].view(np.uint32), first[1].view(np.uint32)), (over, t)
+            assert np.array_equal(few.view(np.uint32), first[:5].view(np.uint32)), (over, t)
