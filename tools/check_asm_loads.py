@@ -35,7 +35,7 @@ bad = 0
 loads = 0
 for k, (i, text) in enumerate(ins):
     # the hand-written ones: the typed plane loads, the byte gathers, and the intensities' dword load in front of a typed load
-    mine = re.match(r"(tbuffer_load|global_load_ubyte)", text) or (
+    mine = re.match(r"(tbuffer_load|global_load_ubyte|buffer_load_ubyte)", text) or (
         re.match(r"global_load_dword v\d+, v\d+, s\[", text) and any(t.startswith("tbuffer_load") for _, t in ins[k + 1:k + 4]))
     if not mine:
         continue
