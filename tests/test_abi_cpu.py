@@ -3,6 +3,7 @@ and refuses to run without a gfx950 device (no CPU fallback).  No compute calls 
 import importlib
 import os
 import re
+import sys
 
 ARITH_INDEPENDENT = True   # nothing here depends on the arithmetic set (tests/conftest.py): run once
 
@@ -106,3 +107,22 @@ def test_product_never_touches_the_oracle():
                             if re.search(r"import .*oracle|from oracle|uwt_oracle|libuwt_oracle|oracle/", line):
                                 bad.append((f, line.strip()))
     assert not bad, bad
+
+
+def test_hand_written_loads_of_the_typed_kernels_are_released_before_use():
+    """The typed instantiations of k_residual (uwt_kernels.h: load_group_typed) issue every vector-memory operation of their loop
+    from asm statements, which the compiler's s_waitcnt bookkeeping does not see: between such a load and the written-out wait
+    that releases it, no instruction of the SHIPPED assembly may touch the load's destination registers.  Compiles the
+    dispatcher unit to assembly (the library's own `make asm` recipe) and scans every typed instantiation
+    (tools/check_asm_loads.py)."""
+    import subprocess
+    csrc = os.path.join(ROOT, "uw-slam_amd", "csrc")
+    r = subprocess.run(["make", "-C", csrc, "asm", "UNIT=uwt_launch_residual"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = os.path.join(csrc, "uwt_launch_residual.gfx950.s")
+    names = sorted(set(re.findall(r"^(_ZN3uwt10k_residualI\w+?ELi[23]EEEvNS_12ResidualArgsE):", open(asm).read(), re.M)))
+    assert len(names) >= 8, names            # production + EUROC forms x depth x streamed, both arithmetic sets
+    for n in names:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_loads.py"), asm, n], capture_output=True, text=True)
+        assert out.returncode == 0 and " 0 violations" in out.stdout, (n, out.stdout[-1500:])
+        assert int(out.stdout.split()[0]) >= 16, out.stdout          # the loop's loads were found (two register sets)
