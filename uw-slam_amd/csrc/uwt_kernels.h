@@ -18,6 +18,10 @@
 //   k_grad_mag*, k_candidates_batch, k_scan_counts, k_patch_points, k_add_patch_points, k_remap_crop, k_trajectory*   the rows
 //                  next to the path
 //   masked_sums_*  a pixel's 28 f64 sums under an EXEC mask of the valid lanes (no select anywhere in the loop)
+//   load_group_typed   the production loop's plane loads as typed buffer loads (the texture path converts int16 -> f32), every
+//                  vector-memory operation of that loop hand-written with its waits (tools/check_asm_loads.py)
+// The heavy templates are instantiated by the dispatchers of uwt_launch_{residual,general,flow}.hip (uwt_launch.h); the kernels
+// that are not templates are `static`: each translation unit that launches one carries its own copy.
 //
 // Stencil + gather + reduction work with a 6-wide contraction: no MFMA.  Wave = 64 lanes, blocks of 256.
 // Build with -ffp-contract=off: the per-pixel float sequence is part of the contract (every FMA is explicit).

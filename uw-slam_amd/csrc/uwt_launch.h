@@ -1,5 +1,5 @@
 // uwt_launch.h — internal: the launch dispatchers of the heavy kernel templates, one translation unit per family so that the
-// library builds in parallel (uwt_launch_residual.hip, uwt_launch_general.hip, uwt_launch_flow.hip, uwt_launch_align.hip).
+// library builds in parallel (uwt_launch_residual.hip, uwt_launch_general.hip, uwt_launch_flow.hip).
 // A dispatcher picks the instantiation from run-time facts (arithmetic set, depth plane, level width, intrinsics, factors) and
 // enqueues it; it reports nothing — the caller checks hipGetLastError().
 #pragma once
