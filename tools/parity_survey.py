@@ -79,8 +79,10 @@ def rot_angle(qa, qb):
 dr = np.array([rot_angle(poses[i][:4], cpu[i][1][:4]) for i in range(n)])
 dt = np.array([np.linalg.norm(poses[i][4:].astype(np.float64) - cpu[i][1][4:]) for i in range(n)])
 bit = sum(np.array_equal(poses[i].view(np.uint32), cpu[i][1].view(np.uint32)) for i in range(n))
-it_eq = sum(stats[i]["iterations"] == cpu[i][2] for i in range(n))
-print("arith %s%s%s mode %s%s weights=%d sampler=%d %dx%d depth=%d n=%d: bit-identical %d, iterations equal %d, status!=0 %d" % (a.arith, " fx!=fy" if intr[0] != intr[1] else "", " [%s]" % a.tuning if a.tuning else "", a.mode, " (one pair per call)" if a.single else " (one batch)", a.weights, a.sampler, w, h, a.depth, n, bit, it_eq, sum(s["status"] != 0 for s in stats)))
+it_eq = sum(stats[i]["iterations"] == cpu[i][2] for i in range(n) if cpu[i][0] == 0)   # the count is defined for status 0 only
+st_eq = sum(stats[i]["status"] == cpu[i][0] for i in range(n))
+n_ok = sum(c[0] == 0 for c in cpu)
+print("arith %s%s%s mode %s%s weights=%d sampler=%d %dx%d depth=%d n=%d: bit-identical %d, status equal %d, status 0: %d, iterations equal %d" % (a.arith, " fx!=fy" if intr[0] != intr[1] else "", " [%s]" % a.tuning if a.tuning else "", a.mode, " (one pair per call)" if a.single else " (one batch)", a.weights, a.sampler, w, h, a.depth, n, bit, st_eq, n_ok, it_eq))
 print("  rot  diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dr), np.percentile(dr, 90), dr.max(), (dr > 1e-4).sum()))
 print("  trans diff: median %.2e  p90 %.2e  max %.2e  (>1e-4: %d)" % (np.median(dt), np.percentile(dt, 90), dt.max(), (dt > 1e-4).sum()))
 print("  |t| median %.2e ; cpu time/pair %.3fs" % (np.median([np.linalg.norm(c[1][4:]) for c in cpu]), t_cpu / n))
