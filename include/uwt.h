@@ -297,7 +297,9 @@ int uwt_solve_delta(uwt_ctx* ctx, const float A[36], const float b[6], float del
 /* Tracker::EstimatePose / EstimatePoseFeatures over explicit per-level point tables (src/Tracker.cpp:401, 669): tables[l]
  * is an n_points[l] x 4 host array [x y z w] for every level l in [last_level, first_level] (other entries ignored).
  * With the EstimatePoseFeatures constants (first = last = 0, max_iters 10, gain 1, z_factor 0.002, handoff_scale_t 1;
- * src/Tracker.cpp:634-640, 834, 856) this is the reference's live tracking call. */
+ * src/Tracker.cpp:634-640, 834, 856) this is the reference's live tracking call.  uwt_params::weights and ::sampler apply as in
+ * the dense call.  A row whose reference position ((int)y, (int)x) lies outside the level is dropped (the reference's
+ * Mat::at would read outside the image, :474-477). */
 int uwt_estimate_pose_points(uwt_ctx* ctx, int32_t ref_slot, int32_t tgt_slot, const float* const* tables,
                              const int32_t* n_points, float pose_out[7], uwt_stats* stats_out_or_null);
 /* Tracker::MedianMat (src/Tracker.cpp:1571-1594), MedianAbsoluteDeviation (:1607-1619), IdentityWeights (:1621-1624) and

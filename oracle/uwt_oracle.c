@@ -412,6 +412,10 @@ int uwo_residual_jacobian_ex(const uint8_t* img1, const uint8_t* img2, const int
     float iz = 1.0f / z2; /* :447 */
     if (y2 > 0.0f && y2 < (float)h && x2 > 0.0f && x2 < (float)w) { /* :450 */
       if (z2 != 0.0f) {                                              /* :451 */
+        /* A table row whose reference position lies outside the level: Mat::at(y1, x1) (:474-477) would read outside the
+         * image there — undefined in the reference (its own producers never emit such a row).  Defined here: the row is
+         * dropped, like a row that fails :450-451 (the HIP path does the same; INTEGRATION.md "deviations"). */
+        if ((int)x1 < 0 || (int)x1 >= w || (int)y1 < 0 || (int)y1 >= h) continue;
         if (iz < 0.0f) iz = 0.0f;                                    /* :452-453 */
         float Jw[2][6];
         Jw[0][0] = fx * iz;                               /* :455 */

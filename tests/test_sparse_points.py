@@ -67,6 +67,23 @@ def capi():
     return m
 
 
+def test_oracle_drops_table_rows_outside_the_level(O, synth):
+    """The oracle's own definition of the undefined case: a row whose reference position is outside the level (the reference's
+    Mat::at would read outside the image, src/Tracker.cpp:474-477) is dropped — a table with such rows aligns like the table
+    without them, and a table of nothing else has no valid point."""
+    w, h = 160, 96
+    ref, tgt, _, _, _ = synth.render_pair(w, h, *MID, seed=66, z=1.1)
+    p = O.default_params(w, h, *MID, n_levels=4, first_level=0, last_level=0, max_iters=4, early_exit=0)
+    rng = np.random.default_rng(12)
+    inside = np.empty((2000, 4), np.float32)
+    inside[:, 0] = rng.uniform(0, w - 0.01, 2000); inside[:, 1] = rng.uniform(0, h - 0.01, 2000); inside[:, 2:] = 1.0
+    outside = np.array([[-1.5, 4, 1, 1], [w, 4, 1, 1], [5, -1.0, 1, 1], [5, h, 1, 1], [-2, h + 9, 1, 1]], np.float32)
+    s0, p0, t0 = O.align_pair_points(p, ref, tgt, {0: inside}, want_trace=True)
+    s1, p1, t1 = O.align_pair_points(p, ref, tgt, {0: np.concatenate([outside, inside])}, want_trace=True)
+    assert s0 == 0 and s1 == 0 and np.array_equal(p0, p1) and [q["n_valid"] for q in t0] == [q["n_valid"] for q in t1]
+    assert O.align_pair_points(p, ref, tgt, {0: outside})[0] != 0
+
+
 def _ctx_pair(capi, synth, w, h, seed, depth=False, **over):
     ref, tgt, dep, _, _ = synth.render_pair(w, h, *MID, seed=seed, with_depth=depth, z=1.1)
     if depth:
@@ -128,6 +145,54 @@ def test_gpu_point_table_alignment_matches_dense_and_oracle(capi, O, synth):
     empty[4] = np.zeros((0, 4), np.float32)
     pose, st = ctx.estimate_pose_points(0, 1, empty)
     assert st["status"] == capi.ERR_NO_VALID_POINTS
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("weights,sampler", [(1, 0), (2, 0), (0, 1), (2, 1)])
+def test_gpu_point_tables_on_the_general_path(capi, O, synth, weights, sampler):
+    """uwt_params::weights / ::sampler apply to explicit tables as to the dense call (k_points_hist, k_scale_stage,
+    k_points_general): candidate tables on three levels and a 20 000-row table of arbitrary rows, poses bit-identical."""
+    w, h = 160, 96
+    over = dict(n_levels=4, first_level=2, last_level=0, max_iters=6, early_exit=0, weights=weights, sampler=sampler)
+    ctx, ref, tgt, _ = _ctx_pair(capi, synth, w, h, 65, **over)
+    p = O.default_params(w, h, *MID, **over)
+    rng = np.random.default_rng(11)
+    for factors in ({}, dict(z_factor=0.5, angle_factor=1.5)):
+        if factors:
+            ctx.update_params(**factors)
+            for k, v in factors.items():
+                setattr(p, k, v)
+        cand = {l: ctx.obtain_candidate_points(0, l, 20.0)[0] for l in range(3)}
+        rows = np.empty((20000, 4), np.float32)
+        rows[:, 0] = rng.uniform(-3, w + 3, 20000); rows[:, 1] = rng.uniform(-3, h + 3, 20000)
+        rows[:, 2] = rng.choice([0.0, -0.5, 0.4, 1.0, 2.0], 20000); rows[:, 3] = rng.choice([1.0, 0.0, 0.5], 20000, p=[0.9, 0.05, 0.05])
+        for tables in (cand, {0: rows, 1: cand[1], 2: cand[2]}):
+            pose, st = ctx.estimate_pose_points(0, 1, tables)
+            so, pose_cpu, tr = O.align_pair_points(p, ref, tgt, tables, want_trace=True)
+            assert so == 0 and st["status"] == 0 and st["iterations"] == len(tr)
+            assert np.array_equal(pose, pose_cpu), (weights, sampler, factors)
+
+
+@pytest.mark.gpu
+def test_gpu_point_table_rows_outside_the_level_are_dropped(capi, O, synth):
+    """A row whose reference position ((int)y, (int)x) is outside the level: the reference's Mat::at would read outside the
+    image (src/Tracker.cpp:474-477); both sides drop the row.  The table with such rows aligns like the table without them."""
+    w, h = 160, 96
+    over = dict(n_levels=4, first_level=0, last_level=0, max_iters=5, early_exit=0)
+    ctx, ref, tgt, _ = _ctx_pair(capi, synth, w, h, 66, **over)
+    p = O.default_params(w, h, *MID, **over)
+    rng = np.random.default_rng(12)
+    inside = np.empty((3000, 4), np.float32)
+    inside[:, 0] = rng.uniform(0, w - 0.01, 3000); inside[:, 1] = rng.uniform(0, h - 0.01, 3000); inside[:, 2] = 1.0; inside[:, 3] = 1.0
+    outside = np.array([[-1.5, 4, 1, 1], [w, 4, 1, 1], [w + 2.5, 4, 1, 1], [5, -1.0, 1, 1], [5, h, 1, 1], [5, h + 7, 1, 1], [-2, -2, 1, 1]], np.float32)
+    mixed = np.concatenate([inside[:1000], outside, inside[1000:]])
+    a, sa = ctx.estimate_pose_points(0, 1, {0: inside})
+    b, sb = ctx.estimate_pose_points(0, 1, {0: mixed})
+    so, pose_cpu, tr = O.align_pair_points(p, ref, tgt, {0: mixed}, want_trace=True)
+    assert sa["status"] == 0 and sb["status"] == 0 and so == 0
+    assert np.array_equal(a, b) and np.array_equal(b, pose_cpu) and sb["n_valid"] == tr[-1]["n_valid"]
+    only_out, s_out = ctx.estimate_pose_points(0, 1, {0: outside})
+    assert s_out["status"] == capi.ERR_NO_VALID_POINTS and O.align_pair_points(p, ref, tgt, {0: outside})[0] == s_out["status"]
 
 
 @pytest.mark.gpu

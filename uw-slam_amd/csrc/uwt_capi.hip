@@ -1882,9 +1882,16 @@ int uwt_estimate_pose_points(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, con
     ra.slices = std::max(1, (pa.n_pts + per_block - 1) / per_block);
     UpdateArgs ua = update_args(c, lvl);
     ua.slices = ra.slices;
+    const bool general = p.sampler || p.weights;   // robust weights / bilinear sampler: the per-stage form over the table
+    if (general) ua.general = 1;
     int next_poll = 2;
     for (int k = 0; k < p.max_iters; k++) {
-      uwt::launch_points(c->stream, launch_sel(c), ra, pa);
+      if (general) {
+        if (p.weights) HIPCHK(c, hipMemsetAsync(c->hist + (size_t)ra.pair_base * kHistBins, 0, sizeof(unsigned int) * kHistBins, c->stream));
+        uwt::launch_points_general(c->stream, launch_sel(c), ra, pa, general_args(c));
+      } else {
+        uwt::launch_points(c->stream, launch_sel(c), ra, pa);
+      }
       HIPCHK(c, hipGetLastError());
       ua.k = k;
       const bool poll = p.early_exit && (k + 1 == next_poll) && (k + 1 < p.max_iters);

@@ -14,7 +14,8 @@
 //                  one block per pair
 //   k_resid_hist_v (scale pass with the scale stage in its tail) + k_residual<.., WEIGHTS>   robust weights in the alignment loop;
 //                  k_residual<.., SAMPLER = 1>: bilinear sampler
-//   k_residual_points, k_residual_general, k_resid_hist, k_scale_stage   explicit point tables; per-stage (dump) forms
+//   k_residual_points, k_points_hist, k_points_general                   explicit point tables (identity / general path)
+//   k_residual_general, k_resid_hist, k_scale_stage                      per-stage (dump) forms of the general path
 //   k_grad_mag*, k_candidates_batch, k_scan_counts, k_patch_points, k_add_patch_points, k_remap_crop, k_trajectory*   the rows
 //                  next to the path
 //   masked_sums_*  a pixel's 28 f64 sums under an EXEC mask of the valid lanes (no select anywhere in the loop)
@@ -3020,6 +3021,113 @@ __global__ __launch_bounds__(kBlock) void k_residual_points(const ResidualArgs a
     }
   }
   block_reduce_store<AccT>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + blockIdx.x) * kRecWords);
+}
+
+// The same tables on the general path (robust weights and / or the bilinear sampler: uwt_params::weights, ::sampler): the
+// per-stage form of the dense path — k_points_hist, k_scale_stage, k_points_general per evaluation — over table rows.
+// One row: WarpFunction with the table's own w, the validity tests of k_residual_points, the residual of either sampler.
+template <int AR>
+__device__ __forceinline__ bool general_point(const LevelK& L, const float* T, int sampler, const uint8_t* __restrict__ I1,
+                                              const uint8_t* __restrict__ I2, const float4 P, float& x2, float& y2, float& iz, float& rf,
+                                              uint32_t& i1x) {
+  float o[3], wq;
+  warp_table_point<AR>(L, T, P, o, wq);
+  x2 = o[0] * L.fx; x2 = x2 / o[2]; x2 = x2 + L.cx; x2 = x2 * wq;
+  y2 = o[1] * L.fy; y2 = y2 / o[2]; y2 = y2 + L.cy; y2 = y2 * wq;
+  const float z2 = o[2];
+  iz = 1.0f / z2;
+  bool ok = (y2 > 0.f) && (y2 < (float)L.h) && (x2 > 0.f) && (x2 < (float)L.w) && (z2 != 0.f);
+  const int ix1 = (int)P.x, iy1 = (int)P.y;
+  ok = ok && ix1 >= 0 && ix1 < L.w && iy1 >= 0 && iy1 < L.h;  // the reference would read out of bounds
+  rf = 0.f;
+  i1x = 0;
+  if (!ok) return false;
+  if (iz < 0.f) iz = 0.f;
+  i1x = (uint32_t)(iy1 * L.w + ix1);
+  const int i1 = I1[i1x];
+  if (sampler) {
+    rf = sample_bilinear(I2, L, x2, y2) - (float)i1;
+  } else {
+    int ix2 = round_pos(x2), iy2 = round_pos(y2);
+    ix2 = min(ix2, L.w - 1);
+    iy2 = min(iy2, L.h - 1);
+    rf = (float)((int)I2[iy2 * L.w + ix2] - i1);
+  }
+  return true;
+}
+
+// the scale pass: every valid row's rounded residual into the pair's signed bins (k_resid_hist over a table)
+template <int AR>
+__global__ __launch_bounds__(kBlock) void k_points_hist(const ResidualArgs a, const PointsArgs pa, const GeneralArgs ga) {
+  const int pair = a.pair_base;
+  const PairState st = a.state[pair];
+  if (st.level_done || st.status) return;
+  __shared__ unsigned int h[kHistBins];
+  for (int i = threadIdx.x; i < kHistBins; i += kBlock) h[i] = 0;
+  __syncthreads();
+  float T[12];
+  pose_to_T12(st.pose, T);
+  const LevelK L = a.L;
+  const uint8_t* __restrict__ I1 = a.img + (size_t)a.ref_slots[pair] * L.n;
+  const uint8_t* __restrict__ I2 = a.img + (size_t)a.tgt_slots[pair] * L.n;
+  const int p_begin = blockIdx.x * pa.pts_per_block, p_end = min(p_begin + pa.pts_per_block, pa.n_pts);
+  for (int q = p_begin + (int)threadIdx.x; q < p_end; q += kBlock) {
+    float x2, y2, iz, rf;
+    uint32_t i1x;
+    if (!general_point<AR>(L, T, ga.sampler, I1, I2, pa.pts[q], x2, y2, iz, rf, i1x)) continue;
+    atomicAdd(&h[(int)rintf(rf) + 255], 1u);
+  }
+  __syncthreads();
+  unsigned int* gh = ga.hist + (size_t)pair * kHistBins;
+  for (int i = threadIdx.x; i < kHistBins; i += kBlock)
+    if (h[i]) atomicAdd(&gh[i], h[i]);
+}
+
+// the weighted / bilinear accumulation of k_residual_general over a table (records of the `general` kind)
+template <int AR, bool UNIT_FACTORS>
+__global__ __launch_bounds__(kBlock) void k_points_general(const ResidualArgs a, const PointsArgs pa, const GeneralArgs ga) {
+  const int pair = a.pair_base;
+  const PairState st = a.state[pair];
+  if (st.level_done || st.status) return;
+  float T[12];
+  pose_to_T12(st.pose, T);
+  const LevelK L = a.L;
+  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n;
+  const uint8_t* __restrict__ I1 = a.img + ref_off;
+  const uint8_t* __restrict__ I2 = a.img + (size_t)a.tgt_slots[pair] * L.n;
+  const int16_t* __restrict__ GX = a.gx + ref_off;
+  const int16_t* __restrict__ GY = a.gy + ref_off;
+  const float inv_mad = ga.weights ? ga.scale[pair].inv_mad : 1.f;
+  double acc[kAccFloats];
+#pragma unroll
+  for (int i = 0; i < kAccFloats; i++) acc[i] = 0.0;
+  double err = 0.0;
+  uint32_t sum_r2 = 0, n_valid = 0;
+  const int p_begin = blockIdx.x * pa.pts_per_block, p_end = min(p_begin + pa.pts_per_block, pa.n_pts);
+  for (int q = p_begin + (int)threadIdx.x; q < p_end; q += kBlock) {
+    float x2, y2, iz, rf;
+    uint32_t i1x;
+    if (!general_point<AR>(L, T, ga.sampler, I1, I2, pa.pts[q], x2, y2, iz, rf, i1x)) continue;
+    float J[6];
+    pixel_jacobian<AR, UNIT_FACTORS, false, true>(L, a.zf, a.af, x2, y2, iz, (float)GX[i1x], (float)GY[i1x], J);
+    const float w = robust_weight(ga.weights, rf, inv_mad);
+    err += (double)rf * (double)(rf * w);         // Residuals.mul(W) for the error (src/Tracker.cpp:500)
+    const float rw = (rf * ga.gain) * w;           // :559, :561
+    double Jd[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) Jd[k] = (double)(w * J[k]);   // :556
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = i; j < 6; j++, s++) acc[s] = __builtin_fma(Jd[i], Jd[j], acc[s]);
+#pragma unroll
+    for (int i = 0; i < 6; i++) acc[21 + i] = __builtin_fma(Jd[i], (double)rw, acc[21 + i]);
+    const int qr = (int)rintf(rf);
+    sum_r2 += (uint32_t)(qr * qr);
+    n_valid += 1;
+  }
+  block_reduce_store<double, true>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + blockIdx.x) * kRecWords, err);
 }
 
 // ------------------------------------------------------------------------------------------------------------

@@ -29,6 +29,8 @@ void launch_general(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, 
 void launch_general_dump(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const GeneralArgs& ga, int n_pairs);
 // explicit point tables (k_residual_points)
 void launch_points(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const PointsArgs& pa);
+// the same on the general path: k_points_hist + k_scale_stage (weights != 0; the caller cleared the pair's bins), k_points_general
+void launch_points_general(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const PointsArgs& pa, const GeneralArgs& ga);
 
 // the chained flow of a few pairs: k_iterate, k_coarse (up to kCoarseMaxLevels levels in one launch), k_finish
 void launch_iterate(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const IterArgs& ia, int n_pairs);

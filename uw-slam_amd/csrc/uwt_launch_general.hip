@@ -103,4 +103,16 @@ void launch_general_dump(hipStream_t s, const LaunchSel& sel, const ResidualArgs
     else hipLaunchKernelGGL((k_residual_general<AR, false, false>), grid, blk, 0, s, a, ga));
 }
 
+void launch_points_general(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const PointsArgs& pa, const GeneralArgs& ga) {
+  const bool unit = (a.zf == 1.0f && a.af == 1.0f);
+  const dim3 grid(a.slices), blk(kBlock);
+  if (ga.weights) {
+    UWT_WITH_AR(sel.arith, hipLaunchKernelGGL((k_points_hist<AR>), grid, blk, 0, s, a, pa, ga));
+    hipLaunchKernelGGL(k_scale_stage, dim3(1), dim3(256), 0, s, ga, a.state, 1, a.pair_base);
+  }
+  UWT_WITH_AR(sel.arith,
+    if (unit) hipLaunchKernelGGL((k_points_general<AR, true>), grid, blk, 0, s, a, pa, ga);
+    else hipLaunchKernelGGL((k_points_general<AR, false>), grid, blk, 0, s, a, pa, ga));
+}
+
 }  // namespace uwt
