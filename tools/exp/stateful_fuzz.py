@@ -15,7 +15,7 @@ from concurrent.futures import ThreadPoolExecutor
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-GEOM = [(160, 96, 4), (208, 112, 5), (112, 80, 5), (320, 240, 4)]
+GEOM = [(160, 96, 4), (208, 112, 5), (112, 80, 5), (320, 240, 4), (384, 256, 8), (256, 192, 7)] if os.environ.get('FUZZ_DEEP') else [(160, 96, 4), (208, 112, 5), (112, 80, 5), (320, 240, 4)]
 U, NP = 12, 64          # distinct pairs, resident pairs
 total = bad = 0
 t0 = time.time()
@@ -39,7 +39,7 @@ for g, (w, h, nl) in enumerate(GEOM):
     h_poses = capi.pinned_empty((NP, 7), np.float32); h_stats = capi.pinned_empty((NP, 4), np.int32)
     for step in range(steps):
         first = int(rng.integers(0, nl)); last = int(rng.integers(0, first + 1))
-        over = dict(first_level=first, last_level=last, max_iters=int(rng.integers(1, 11)), early_exit=int(rng.random() < 0.5),
+        over = dict(first_level=first, last_level=last, max_iters=int(rng.integers(1, 11)) if rng.random() < 0.93 else int(rng.choice([17, 25, 60])), early_exit=int(rng.random() < 0.5),
                     gain=float(np.float32(rng.choice([1.0, 10.0, 50.0]))), epsilon=float(np.float32(10.0 ** rng.uniform(-5, -2))),
                     handoff_scale_t=int(rng.random() < 0.8), arith=int(rng.random() < 0.3), weights=0, sampler=0,
                     z_factor=1.0, angle_factor=1.0)
