@@ -169,7 +169,7 @@ int ensure_scratch(uwt_ctx* c, size_t bytes) {
   return UWT_OK;
 }
 
-bool slot_range_ok(const uwt_ctx* c, int first, int n) { return first >= 0 && n >= 0 && first + n <= c->p.max_frames; }
+bool slot_range_ok(const uwt_ctx* c, int first, int n) { return first >= 0 && n >= 0 && (long long)first + n <= c->p.max_frames; }
 
 // Tracker::InitializePyramid (src/Tracker.cpp:297-340): fx halves in double then narrows (:317);
 // cx_l = (cx0 + 0.5) / 2^l - 0.5 evaluated in double (:319); invfx = 1 / fx in float (:328).
