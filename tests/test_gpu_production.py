@@ -578,3 +578,39 @@ def test_every_tuning_switch_changes_no_bit(capi, O, synth):
             assert np.array_equal(batch.view(np.uint32), first.view(np.uint32)), (over, t)
             assert np.array_equal(lone[0].view(np.uint32), first[1].view(np.uint32)), (over, t)
             assert np.array_equal(few.view(np.uint32), first[:5].view(np.uint32)), (over, t)
+
+
+@pytest.mark.gpu
+def test_bad_arguments_return_a_status_and_touch_nothing(capi, synth):
+    """Slot ranges, levels, counts and pointers out of range come back as UWT_ERR_INVALID_ARG / UWT_ERR_CAPACITY (a range whose
+    end overflows 32 bits included) and the context keeps working."""
+    import ctypes as C
+    w, h, intr = 64, 48, (64.0, 64.0, 31.5, 23.5)
+    ctx = capi.Context(capi.default_params(w, h, *intr, n_levels=3, first_level=2, last_level=0, max_frames=4, max_pairs=2))
+    L, H = capi.lib(), ctx._h
+    ref, tgt, _, _, _ = synth.render_pair(w, h, *intr, seed=3)
+    ctx.upload_frames(0, np.stack([ref, tgt])); ctx.build_pyramids(0, 2); ctx.apply_gradient(0, 2)
+    good, _ = ctx.estimate_pose_batch([0], [1], raise_on_pair_failure=True)
+    big = 2 ** 31 - 1
+    gray = np.zeros((h, w), np.uint8)
+    gp = gray.ctypes.data_as(C.POINTER(C.c_uint8))
+    one = (C.c_int32 * 1)(0); far = (C.c_int32 * 1)(7); neg = (C.c_int32 * 1)(-1)
+    pose = np.zeros(7, np.float32); pp = pose.ctypes.data_as(C.POINTER(C.c_float))
+    st3 = (capi.Stats * 3)()
+    for rc in (L.uwt_build_pyramids(H, big, 1), L.uwt_build_pyramids(H, big, big), L.uwt_build_pyramids(H, 3, 2), L.uwt_build_pyramids(H, -1, 1),
+               L.uwt_apply_gradient(H, 0, -1), L.uwt_apply_gradient(H, big - 1, 2),
+               L.uwt_upload_frames(H, 4, 1, gp, None), L.uwt_upload_frames(H, big, 1, gp, None), L.uwt_upload_frames(H, 0, 1, None, None),
+               L.uwt_set_frame(H, 4, gp, C.c_size_t(w), None, C.c_size_t(0)), L.uwt_set_frame(H, 0, gp, C.c_size_t(w - 1), None, C.c_size_t(0)),
+               L.uwt_estimate_pose_batch(H, 1, one, far, pp, st3), L.uwt_estimate_pose_batch(H, 1, neg, one, pp, st3),
+               L.uwt_estimate_pose_batch(H, 0, one, one, pp, st3), L.uwt_estimate_pose_batch(H, 1, None, one, pp, st3)):
+        assert rc == capi.ERR_INVALID_ARG
+    three = (C.c_int32 * 3)(0, 0, 0)
+    assert L.uwt_estimate_pose_batch(H, 3, three, three, pp, st3) == capi.ERR_CAPACITY
+    lv = capi.Level()
+    assert L.uwt_level_info(H, 3, C.byref(lv)) == capi.ERR_INVALID_ARG and L.uwt_level_info(H, -1, C.byref(lv)) == capi.ERR_INVALID_ARG
+    out = C.c_void_p()
+    assert L.uwt_plane_device_ptr(H, 0, 0, 9, C.byref(out)) == capi.ERR_INVALID_ARG
+    assert L.uwt_plane_device_ptr(H, 0, 0, capi.PLANE_DEPTH, C.byref(out)) == capi.ERR_INVALID_ARG     # no depth plane in this context
+    again, _ = ctx.estimate_pose_batch([0], [1], raise_on_pair_failure=True)
+    assert np.array_equal(good, again)
+    ctx.close()
