@@ -27,13 +27,14 @@ class Params(C.Structure):
         ("epsilon", C.c_float), ("gain", C.c_float), ("z_factor", C.c_float), ("angle_factor", C.c_float),
         ("depth_scale", C.c_float), ("initial_error", C.c_float),
         ("early_exit", C.c_int32), ("has_depth", C.c_int32), ("handoff_scale_t", C.c_int32),
-        ("weights", C.c_int32), ("sampler", C.c_int32), ("arith", C.c_int32),
+        ("weights", C.c_int32), ("sampler", C.c_int32), ("arith", C.c_int32), ("gemm_fold", C.c_int32),
     ]
 
 
 class Level(C.Structure):
     _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
-                ("cx", C.c_float), ("cy", C.c_float), ("invfx", C.c_float), ("invfy", C.c_float)]
+                ("cx", C.c_float), ("cy", C.c_float), ("invfx", C.c_float), ("invfy", C.c_float),
+                ("iw", C.c_int32), ("ih", C.c_int32)]   # w, h: the point grid (size >> lvl); iw, ih: the level's image (resize chain)
 
 
 class Trace(C.Structure):
@@ -117,6 +118,38 @@ def halve_u16(img):
     return out
 
 
+def half_size(n):
+    """cvRound(n * 0.5): the output size of cv::resize(.., Size(), 0.5, 0.5) (half to even: 733 -> 366, 735 -> 368)."""
+    return int(lib().uwo_half_size(int(n)))
+
+
+def resize_half_u8(img):
+    """cv::resize(img, Size(), 0.5, 0.5) on any size (partial last column / row included)."""
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.empty((half_size(h), half_size(w)), np.uint8)
+    lib().uwo_resize_half_u8(_p(img, C.c_uint8), w, h, _p(out, C.c_uint8))
+    return out
+
+
+def resize_half_u16(img):
+    img = np.ascontiguousarray(img, np.uint16)
+    h, w = img.shape
+    out = np.empty((half_size(h), half_size(w)), np.uint16)
+    lib().uwo_resize_half_u16(_p(img, C.c_uint16), w, h, _p(out, C.c_uint16))
+    return out
+
+
+def pyramid(img, n_levels):
+    """images_[0..n_levels) / depths_[0..n_levels) of System::AddFrame (System.cpp:246-251) for a u8 or u16 level-0 image."""
+    img = np.ascontiguousarray(img)
+    f = resize_half_u16 if img.dtype == np.uint16 else resize_half_u8
+    out = [img]
+    for _ in range(1, n_levels):
+        out.append(f(out[-1]))
+    return out
+
+
 def scharr3(img):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
@@ -135,13 +168,18 @@ def gradient_mag(gx, gy):
 
 
 def dense_points(depth, w, h, lvl, depth_scale=0.0002):
+    """The w x h point grid; a depth image wider than the grid (an odd-sized level) is read with its own row length."""
     pts = np.empty((w * h, 4), np.float32)
+    stride = w
     if depth is not None:
         depth = np.ascontiguousarray(depth, np.uint16)
+        assert depth.ndim == 1 or (depth.shape[1] >= w and depth.shape[0] >= h), (depth.shape, w, h)
+        if depth.ndim == 2:
+            stride = depth.shape[1]
         dp = _p(depth, C.c_uint16)
     else:
         dp = None
-    lib().uwo_dense_points(dp, w, h, lvl, C.c_float(depth_scale), _p(pts, C.c_float))
+    lib().uwo_dense_points_ex(dp, stride, w, h, lvl, C.c_float(depth_scale), _p(pts, C.c_float))
     return pts
 
 
@@ -381,15 +419,17 @@ def add_patch_points(pts, w, h, patch_size=5, cap=None):
     return out[:min(n, cap)].copy(), n
 
 
-def candidate_points(mag, depth=None, threshold=20.0):
+def candidate_points(mag, depth=None, threshold=20.0, grid=None):
+    """grid = (w, h): the level's point grid where it is smaller than the image (mag.shape)."""
     mag = np.ascontiguousarray(mag, np.uint8)
-    h, w = mag.shape
+    ih, iw = mag.shape
+    w, h = grid if grid is not None else (iw, ih)
     pts = np.empty((w * h, 4), np.float32)
     dp = None
     if depth is not None:
         depth = np.ascontiguousarray(depth, np.uint16)
         dp = _p(depth, C.c_uint16)
-    n = lib().uwo_candidate_points(_p(mag, C.c_uint8), dp, w, h, C.c_double(threshold), _p(pts, C.c_float), w * h)
+    n = lib().uwo_candidate_points_ex(_p(mag, C.c_uint8), dp, iw, ih, w, h, C.c_double(threshold), _p(pts, C.c_float), w * h)
     return pts[:n].copy(), n
 
 

@@ -48,8 +48,15 @@ int uwo_level_intrinsics(const uwo_params* p, int lvl, uwo_level* out) {
     fx = (float)((double)fx * 0.5);
     fy = (float)((double)fy * 0.5);
   }
-  out->w = p->width >> lvl;
+  out->w = p->width >> lvl;   /* :312-313 "_width >> lvl": the POINT GRID of ObtainAllPoints (:1267-1268) */
   out->h = p->height >> lvl;
+  /* the size of images_[lvl] itself: the cv::resize(.., Size(), 0.5, 0.5) chain of System.cpp:246-251 */
+  out->iw = p->width;
+  out->ih = p->height;
+  for (int l = 1; l <= lvl; l++) {
+    out->iw = uwo_half_size(out->iw);
+    out->ih = uwo_half_size(out->ih);
+  }
   out->fx = fx;
   out->fy = fy;
   if (lvl == 0) {
@@ -68,8 +75,51 @@ int uwo_level_intrinsics(const uwo_params* p, int lvl, uwo_level* out) {
 /* pyramid + gradients                                                                          */
 /* ------------------------------------------------------------------------------------------ */
 
-/* System.cpp:247 cv::resize(src, dst, Size(), 0.5, 0.5) — INTER_LINEAR at exactly 1/2 takes
- * OpenCV's area fast path: (a+b+c+d+2)>>2. */
+/* System.cpp:247 cv::resize(src, dst, Size(), 0.5, 0.5).  OpenCV 3.x imgproc/imgwarp.cpp (restated from memory of the published
+ * source; to be confirmed by tools/ref_dump or by someone holding the 3.2 tree):
+ *   dsize = Size(saturate_cast<int>(ssize.width * inv_scale_x), ...) — saturate_cast<int>(double) = cvRound = round half to even
+ *   (733 -> 366, 735 -> 368);
+ *   scale_x = 1 / inv_scale_x = 2 exactly, so is_area_fast holds whatever the parity of the source size, and INTER_LINEAR with
+ *   iscale 2 x 2 is switched to INTER_AREA -> resizeAreaFast_Invoker<T, WT, ResizeAreaFastVec<..>>:
+ *     dwidth1 = ssize.width / 2 (integer): the columns with a whole 2 x 2 cell;
+ *     a row with sy0 + 2 <= ssize.height: columns dx < dwidth1 take the vector op's fast mode (scale 2 x 2, cn == 1)
+ *       D[dx] = (S[2dx] + S[2dx+1] + nextS[2dx] + nextS[2dx+1] + 2) >> 2                      (u8 and u16 alike, in int);
+ *     every other cell — the partial last column of such a row (2 dsize.width > ssize.width) and EVERY column of a partial last
+ *     row (w = 0 there: the vector op is not called) — goes through the generic tail: the sum of the source pixels of the cell
+ *     that exist, count of them, D[dx] = saturate_cast<T>((float)sum / count) — cvRound(float): round half to even
+ *     (a + b = 5 -> 2, = 7 -> 4), where the fast mode rounds half up.
+ * Even sizes: every cell is whole, the 2 x 2 mean (a+b+c+d+2)>>2 of rounds 1-5. */
+int uwo_half_size(int n) {
+  double v = (double)n * 0.5;
+  return (int)lrint(v); /* cvRound(double): SSE2 cvtsd2si / lrint, round half to even */
+}
+
+#define UWO_RESIZE_HALF(NAME, T)                                                                  \
+  void NAME(const T* src, int sw, int sh, T* dst) {                                              \
+    const int dw = uwo_half_size(sw), dh = uwo_half_size(sh), dwidth1 = sw / 2;                  \
+    for (int dy = 0; dy < dh; dy++) {                                                            \
+      const int sy0 = 2 * dy;                                                                    \
+      const int wfast = sy0 + 2 <= sh ? dwidth1 : 0;                                             \
+      T* D = dst + (size_t)dy * dw;                                                              \
+      int dx = 0;                                                                                \
+      for (; dx < wfast; dx++) {                                                                 \
+        const T* S = src + (size_t)sy0 * sw + 2 * dx;                                            \
+        D[dx] = (T)(((int)S[0] + (int)S[1] + (int)S[sw] + (int)S[sw + 1] + 2) >> 2);             \
+      }                                                                                          \
+      for (; dx < dw; dx++) {                                                                    \
+        const int sx0 = 2 * dx;                                                                  \
+        float sum = 0.0f; /* WT = int (u8) / float (u16): the same value, sums stay below 2^24 */ \
+        int count = 0;                                                                           \
+        for (int sy = 0; sy < 2 && sy0 + sy < sh; sy++)                                          \
+          for (int sx = 0; sx < 2 && sx0 + sx < sw; sx++) { sum += (float)src[(size_t)(sy0 + sy) * sw + sx0 + sx]; count++; } \
+        D[dx] = count ? (T)lrintf(sum / (float)count) : (T)0;                                    \
+      }                                                                                          \
+    }                                                                                            \
+  }
+UWO_RESIZE_HALF(uwo_resize_half_u8, uint8_t)
+UWO_RESIZE_HALF(uwo_resize_half_u16, uint16_t)
+
+/* The whole-cell part alone, dst (w >> 1) x (h >> 1): what rounds 1-5 called the pyramid step (sizes divisible by 2). */
 void uwo_halve_u8(const uint8_t* src, int w, int h, uint8_t* dst) {
   int w2 = w >> 1, h2 = h >> 1;
   for (int y = 0; y < h2; y++) {
@@ -141,12 +191,18 @@ void uwo_gradient_mag(const int16_t* gx, const int16_t* gy, int n, uint8_t* out)
 
 /* Tracker::ObtainAllPoints, Tracker.cpp:1259-1310.  Depth is read through at<short> (signed). */
 void uwo_dense_points(const uint16_t* depth, int w, int h, int lvl, float depth_scale, float* pts) {
+  uwo_dense_points_ex(depth, w, w, h, lvl, depth_scale, pts);
+}
+
+/* the same loop over the w x h grid (w_[lvl] x h_[lvl], :1267-1268) of a depth image whose rows are `stride` elements long
+ * (depths_[lvl].cols — the resize chain's size, >= w) */
+void uwo_dense_points_ex(const uint16_t* depth, int stride, int w, int h, int lvl, float depth_scale, float* pts) {
   float factor_lvl = (float)((double)depth_scale / pow(2.0, (double)lvl)); /* :1266 */
   for (int y = 0; y < h; y++) {
     for (int x = 0; x < w; x++) {
       float* p = pts + 4 * ((size_t)y * w + x);
       if (depth) {
-        int16_t d = (int16_t)depth[(size_t)y * w + x];
+        int16_t d = (int16_t)depth[(size_t)y * stride + x];
         if (d > 0) {
           p[0] = (float)x; p[1] = (float)y; p[2] = (float)d * factor_lvl; p[3] = 1.0f; /* :1276-1278 */
         } else {
@@ -297,10 +353,15 @@ int uwo_se3_handoff(float pose[7], int scale_t) {
 /* warp + per-point terms                                                                       */
 /* ------------------------------------------------------------------------------------------ */
 
-static int g_arith = UWO_ARITH_OPENCV;
+/* The arithmetic set and the gemm fold travel WITH THE CALL (uwo_ar): uwo_estimate_pose* take them from uwo_params and hand them
+ * down, so that a thread pool may run alignments of different sets side by side.  The per-stage entry points that have no
+ * parameter block (uwo_warp, uwo_residual_jacobian*, uwo_error, uwo_normal_equations, uwo_solve_delta) read the CALLING THREAD's
+ * defaults, which uwo_set_arith / uwo_set_gemm_fold change for that thread alone (thread-local: nothing process-wide is left). */
+typedef struct uwo_ar { int arith, fold; } uwo_ar;
+static _Thread_local uwo_ar t_ar = {UWO_ARITH_OPENCV, 0};
 int uwo_set_arith(int arith) {
-  int prev = g_arith;
-  g_arith = arith == UWO_ARITH_LEGACY ? UWO_ARITH_LEGACY : UWO_ARITH_OPENCV;
+  int prev = t_ar.arith;
+  t_ar.arith = arith == UWO_ARITH_LEGACY ? UWO_ARITH_LEGACY : UWO_ARITH_OPENCV;
   return prev;
 }
 
@@ -310,14 +371,13 @@ int uwo_set_arith(int arith) {
  * selectable so that a dump of a real build (tools/ref_dump) can say which of the two it follows.  The two differ only where
  * the double-precision sums round differently AND the float rounding of the result falls between them: about one stored
  * value in 10^9. */
-static int g_gemm_fold = 0;
 int uwo_set_gemm_fold(int fold) {
-  int prev = g_gemm_fold;
-  g_gemm_fold = fold ? 1 : 0;
+  int prev = t_ar.fold;
+  t_ar.fold = fold ? 1 : 0;
   return prev;
 }
-static inline double fold4(double s0, double s1, double s2, double s3) {
-  if (g_gemm_fold) return ((s0 + s1) + s2) + s3;
+static inline double fold4(uwo_ar ar, double s0, double s1, double s2, double s3) {
+  if (ar.fold) return ((s0 + s1) + s2) + s3;
   double t = s1 + s2;
   t = t + s3;
   return s0 + t;
@@ -329,8 +389,8 @@ static inline double fold4(double s0, double s1, double s2, double s3) {
  * |alpha| != 1  ->  a.convertTo(m, type, alpha, s)  ->  cvtScale32f: x * (float)alpha + (float)s;
  * alpha == 1 -> cv::add(a, s); alpha == -1 -> cv::subtract(s, a) (scalar narrowed to f32 by arithm_op).
  * Legacy: the expression as written. */
-static inline float unproject_scaled(float x, float c, float inv) {
-  if (g_arith == UWO_ARITH_LEGACY) return (x - c) * inv;
+static inline float unproject_scaled(uwo_ar ar, float x, float c, float inv) {
+  if (ar.arith == UWO_ARITH_LEGACY) return (x - c) * inv;
   double alpha = (double)inv;
   double sc = -(double)c * (double)inv;
   if (alpha == 1.0) return x + (float)sc;
@@ -340,26 +400,26 @@ static inline float unproject_scaled(float x, float c, float inv) {
 }
 
 /* Tracker::WarpFunction, Tracker.cpp:1417-1471.  The 4x4·4xN product follows G1 (legacy: S1). */
-void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, float* warped) {
+static void warp_ar(uwo_ar ar, const float* pts, int n, const float pose[7], const uwo_level* L, float* warped) {
   float T[16];
   uwo_se3_matrix(pose, T);
   float fx = L->fx, fy = L->fy, cx = L->cx, cy = L->cy, invfx = L->invfx, invfy = L->invfy;
   for (int i = 0; i < n; i++) {
     const float* p = pts + 4 * (size_t)i;
     float z = p[2], w = p[3];
-    float X = unproject_scaled(p[0], cx, invfx); /* :1439 */
+    float X = unproject_scaled(ar, p[0], cx, invfx); /* :1439 */
     X = X * z;                                   /* :1440 cv::multiply */
-    float Y = unproject_scaled(p[1], cy, invfy); /* :1443 */
+    float Y = unproject_scaled(ar, p[1], cy, invfy); /* :1443 */
     Y = Y * z;                                   /* :1444 */
     float o[4];
     for (int k = 0; k < 4; k++) {  /* :1450 rigid * P^T */
-      if (g_arith != UWO_ARITH_LEGACY) {
+      if (ar.arith != UWO_ARITH_LEGACY) {
         /* G1: gemm(rigid, P, 1, GEMM_2_T) -> GEMMSingleMul<float,double>, "A * Bt" branch, n = 4: the unrolled loop
          * runs once, s0 = a0*b0, s1 = a1*b1, s2 = a2*b2, s3 = a3*b3 (exact in double), "s0 += s1 + s2 + s3" (fold4),
          * d = T(s0*alpha), alpha = 1 */
         double s0 = (double)T[4 * k] * (double)X, s1 = (double)T[4 * k + 1] * (double)Y;
         double s2 = (double)T[4 * k + 2] * (double)z, s3 = (double)T[4 * k + 3] * (double)w;
-        o[k] = (float)fold4(s0, s1, s2, s3);
+        o[k] = (float)fold4(ar, s0, s1, s2, s3);
         continue;
       }
       float s = T[4 * k] * X;
@@ -377,6 +437,8 @@ void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, 
   }
 }
 
+void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, float* warped) { warp_ar(t_ar, pts, n, pose, L, warped); }
+
 /* EXTENSION (north star; the reference samples nearest-neighbour only): bilinear interpolation, f32, fixed order. */
 float uwo_bilinear_u8(const uint8_t* img, int w, int h, float x, float y) {
   float x0 = floorf(x), y0 = floorf(y);
@@ -393,17 +455,29 @@ float uwo_bilinear_u8(const uint8_t* img, int w, int h, float x, float y) {
   return fmaf(ay, bot - top, top);
 }
 
+static int residual_jacobian_ar(uwo_ar ar, const uint8_t* img1, const uint8_t* img2, const int16_t* gx1, const int16_t* gy1,
+                                const float* pts, const float* warped, int n, const uwo_level* L,
+                                float zf, float af, int sampler, float* J, float* r, int32_t* idx);
+
 int uwo_residual_jacobian(const uint8_t* img1, const uint8_t* img2, const int16_t* gx1, const int16_t* gy1,
                           const float* pts, const float* warped, int n, const uwo_level* L,
                           float zf, float af, float* J, float* r, int32_t* idx) {
-  return uwo_residual_jacobian_ex(img1, img2, gx1, gy1, pts, warped, n, L, zf, af, UWO_SAMPLER_NEAREST, J, r, idx);
+  return residual_jacobian_ar(t_ar, img1, img2, gx1, gy1, pts, warped, n, L, zf, af, UWO_SAMPLER_NEAREST, J, r, idx);
 }
 
-/* Tracker.cpp:432-490. Returns the number of valid rows written. */
 int uwo_residual_jacobian_ex(const uint8_t* img1, const uint8_t* img2, const int16_t* gx1, const int16_t* gy1,
                              const float* pts, const float* warped, int n, const uwo_level* L,
                              float zf, float af, int sampler, float* J, float* r, int32_t* idx) {
-  int w = L->w, h = L->h;
+  return residual_jacobian_ar(t_ar, img1, img2, gx1, gy1, pts, warped, n, L, zf, af, sampler, J, r, idx);
+}
+
+/* Tracker.cpp:432-490. Returns the number of valid rows written.  The planes are the level's IMAGES (L->iw x L->ih, tight rows):
+ * the bounds test reads "image2.rows / image2.cols" (:450) and Mat::at indexes the Mat — the size of the resize chain, which is
+ * larger than the point grid (L->w x L->h = w_[lvl] x h_[lvl]) where a level-0 size is not divisible by 2^lvl. */
+static int residual_jacobian_ar(uwo_ar ar, const uint8_t* img1, const uint8_t* img2, const int16_t* gx1, const int16_t* gy1,
+                                const float* pts, const float* warped, int n, const uwo_level* L,
+                                float zf, float af, int sampler, float* J, float* r, int32_t* idx) {
+  int w = L->iw, h = L->ih;
   float fx = L->fx, fy = L->fy;
   int nv = 0;
   for (int i = 0; i < n; i++) {
@@ -443,7 +517,7 @@ int uwo_residual_jacobian_ex(const uint8_t* img1, const uint8_t* img2, const int
         float jl1 = (float)gy1[(size_t)iy1 * w + ix1]; /* :477 */
         float* Jr = J + 6 * (size_t)nv;
         for (int k = 0; k < 6; k++) { /* :479 Jl * Jw */
-          if (g_arith != UWO_ARITH_LEGACY) {
+          if (ar.arith != UWO_ARITH_LEGACY) {
             /* G1: gemm(Jl 1x2, Jw 2x6): flags 0, len 2, d_size 6x1 -> no inline special case (needs len == width|height);
              * GEMMSingleMul<float,double>, "d_size.width * sizeof <= 1600" branch: WT s(0); for k: s += WT(a[k]) * WT(b[k][j]);
              * d[j] = T(s * alpha) */
@@ -569,8 +643,8 @@ void uwo_huber_weights(const float* r, int n, float* w) {
  *    into s0, d_buf = s0 + s1; a block absorbs the remainder when "k + dk >= len || 8*(k + dk) + dk > 8*len";
  *    GEMMStore: alpha * d_buf.
  * Returns the double before the final (float) store.  Legacy set: one sequential sum. */
-static double gemm_dot_width1(const float* a, size_t sa, const float* b, int n, int rows, double alpha) {
-  if (g_arith == UWO_ARITH_LEGACY) {
+static double gemm_dot_width1(uwo_ar ar, const float* a, size_t sa, const float* b, int n, int rows, double alpha) {
+  if (ar.arith == UWO_ARITH_LEGACY) {
     double s = 0.0;
     for (int k = 0; k < n; k++) s += (double)a[sa * (size_t)k] * (double)b[k];
     return s * alpha;
@@ -585,7 +659,7 @@ static double gemm_dot_width1(const float* a, size_t sa, const float* b, int n, 
       s3 += (double)a[sa * (size_t)(k + 3)] * (double)b[k + 3];
     }
     for (; k < n; k++) s0 += (double)a[sa * (size_t)k] * (double)b[k];
-    return fold4(s0, s1, s2, s3) * alpha;
+    return fold4(ar, s0, s1, s2, s3) * alpha;
   }
   const int block_size = 128 * 128;
   int dm0 = rows < 128 ? rows : 128;
@@ -612,7 +686,7 @@ static double gemm_dot_width1(const float* a, size_t sa, const float* b, int n, 
 /* Tracker.cpp:499-502 (S2, S8): errorMat = inv_num_residuals * Residuals.t() * ResidualsW — MatOp_T::multiply folds the
  * scalar into the transpose's alpha, MatOp::matmul makes one gemm(R, RW, alpha = inv_n, GEMM_1_T) with a 1x1 result.
  * w may be NULL (identity). */
-float uwo_error(const float* r, const float* w, int n, int64_t* sum_r2_out) {
+static float error_ar(uwo_ar ar, const float* r, const float* w, int n, int64_t* sum_r2_out) {
   int64_t si = 0;
   float* rw = (float*)malloc(sizeof(float) * (size_t)(n > 0 ? n : 1));
   for (int i = 0; i < n; i++) {
@@ -621,17 +695,18 @@ float uwo_error(const float* r, const float* w, int n, int64_t* sum_r2_out) {
   }
   if (sum_r2_out) *sum_r2_out = si;
   float inv_n = (float)(1.0 / (double)n); /* :499 */
-  float e = (float)gemm_dot_width1(r, 1, rw, n, 1, (double)inv_n);
+  float e = (float)gemm_dot_width1(ar, r, 1, rw, n, 1, (double)inv_n);
   free(rw);
   return e;
 }
+float uwo_error(const float* r, const float* w, int n, int64_t* sum_r2_out) { return error_ar(t_ar, r, w, n, sum_r2_out); }
 
 /* Tracker.cpp:554-561 (S2).  J <- w∘J ; r <- gain·r ; A = JᵀJ ; b = -Jᵀ(r∘w).
  * A: gemm(J, J, 1, GEMM_1_T), 6x6, len N — GEMMSingleMul's "d_size.width * sizeof <= 1600" branch (N <= 10000) and
  * GEMMBlockMul's non-transposed branch (N > 10000, do_acc carrying d_buf) both add the N products of an entry one after
  * the other in double.  b: "-Jacobians.t()" is MatOp::subtract(Scalar(0), T) = the materialised transpose scaled by -1,
  * times the materialised Residuals.mul(W): gemm(Jt, RW, alpha = -1) with a 6x1 result — gemm_dot_width1. */
-void uwo_normal_equations(const float* J, const float* r, const float* w, int n, float gain, float A[36], float b[6]) {
+static void normal_equations_ar(uwo_ar ar, const float* J, const float* r, const float* w, int n, float gain, float A[36], float b[6]) {
   double Ad[36];
   memset(Ad, 0, sizeof(Ad));
   float* Jw = (float*)malloc(sizeof(float) * 6 * (size_t)(n > 0 ? n : 1));
@@ -646,8 +721,11 @@ void uwo_normal_equations(const float* J, const float* r, const float* w, int n,
       for (int c = 0; c < 6; c++) Ad[6 * a + c] += (double)Jr[a] * (double)Jr[c];
   }
   for (int k = 0; k < 36; k++) A[k] = (float)Ad[k];
-  for (int k = 0; k < 6; k++) b[k] = (float)gemm_dot_width1(Jw + k, 6, rw, n, 6, -1.0);
+  for (int k = 0; k < 6; k++) b[k] = (float)gemm_dot_width1(ar, Jw + k, 6, rw, n, 6, -1.0);
   free(Jw); free(rw);
+}
+void uwo_normal_equations(const float* J, const float* r, const float* w, int n, float gain, float A[36], float b[6]) {
+  normal_equations_ar(t_ar, J, r, w, n, gain, A, b);
 }
 
 /* cv::Mat::inv() default DECOMP_LU on CV_32F (Tracker.cpp:564; S3): OpenCV 3.x hal LU —
@@ -731,8 +809,8 @@ int uwo_solve6(const float Ain[36], const float bin[6], float x[6]) {
 /* Tracker.cpp:564 deltaMat = A.inv() * b.  G2: MatOp_Invert::matmul turns "A.inv() * b" into MatOp_Solve — cv::solve, no
  * inverse, no product (the MatExpr class documentation lists it: "A.inv([method]) * B (~ X: AX = B)").
  * Legacy (S3 + S4): the inverse formed first, then the 6x6·6x1 product accumulated in double. */
-void uwo_solve_delta(const float A[36], const float b[6], float delta[6]) {
-  if (g_arith != UWO_ARITH_LEGACY) {
+static void solve_delta_ar(uwo_ar ar, const float A[36], const float b[6], float delta[6]) {
+  if (ar.arith != UWO_ARITH_LEGACY) {
     uwo_solve6(A, b, delta);
     return;
   }
@@ -744,6 +822,7 @@ void uwo_solve_delta(const float A[36], const float b[6], float delta[6]) {
     delta[i] = (float)s;
   }
 }
+void uwo_solve_delta(const float A[36], const float b[6], float delta[6]) { solve_delta_ar(t_ar, A, b, delta); }
 
 /* ------------------------------------------------------------------------------------------ */
 /* Tracker::EstimatePose, Tracker.cpp:362-597                                                   */
@@ -760,7 +839,8 @@ int uwo_estimate_pose(const uwo_params* p, const uwo_frame* prev, const uwo_fram
 int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const uwo_frame* cur,
                              const float* const* tables, const int32_t* n_points,
                              float pose_out[7], uwo_trace* trace, int32_t* n_trace) {
-  uwo_set_arith(p->arith);
+  /* the call's arithmetic: the set from the parameters; the gemm fold from the parameters, or the calling thread's default */
+  const uwo_ar ar = {p->arith == UWO_ARITH_LEGACY ? UWO_ARITH_LEGACY : UWO_ARITH_OPENCV, (p->gemm_fold || t_ar.fold) ? 1 : 0};
   if (p->first_level >= p->n_levels || p->last_level < 0 || p->last_level > p->first_level) return UWO_ERR_INVALID_ARG;
   int cap = (trace && n_trace) ? *n_trace : 0;
   int nt = 0;
@@ -790,19 +870,19 @@ int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const u
       n = n_points[lvl];
       if (n > 0) memcpy(pts, tables[lvl], sizeof(float) * 4 * (size_t)n); /* :401 candidatePoints_[lvl].clone() */
     } else {
-      uwo_dense_points(p->has_depth ? prev->depth[lvl] : NULL, L.w, L.h, lvl, p->depth_scale, pts); /* :401 */
+      uwo_dense_points_ex(p->has_depth ? prev->depth[lvl] : NULL, L.iw, L.w, L.h, lvl, p->depth_scale, pts); /* :401 */
     }
 
     for (int k = 0; k < p->max_iters; k++) { /* :414 */
-      uwo_warp(pts, n, pose, &L, warped); /* :422 */
-      int nv = uwo_residual_jacobian_ex(prev->img[lvl], cur->img[lvl], prev->gx[lvl], prev->gy[lvl], pts, warped, n, &L,
+      warp_ar(ar, pts, n, pose, &L, warped); /* :422 */
+      int nv = residual_jacobian_ar(ar, prev->img[lvl], cur->img[lvl], prev->gx[lvl], prev->gy[lvl], pts, warped, n, &L,
                                         p->z_factor, p->angle_factor, p->sampler, J, r, NULL);
       if (nv == 0) { status = UWO_ERR_NO_VALID_POINTS; break; } /* reference: cv::Exception on empty Mat product */
       const float* W = NULL;
       if (p->weights == UWO_WEIGHTS_TUKEY_REFERENCE) { uwo_tukey_weights(r, nv, wts); W = wts; } /* :495-496 */
       else if (p->weights == UWO_WEIGHTS_HUBER) { uwo_huber_weights(r, nv, wts); W = wts; }        /* extension */
       int64_t sr2 = 0;
-      float error = uwo_error(r, W, nv, &sr2); /* :499-502 */
+      float error = error_ar(ar, r, W, nv, &sr2); /* :499-502 */
 
       uwo_trace* tr = (nt < cap) ? &trace[nt] : NULL;
       if (tr) {
@@ -821,8 +901,8 @@ int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const u
       last_error = error; /* :529 */
 
       float A[36], b[6], delta[6];
-      uwo_normal_equations(J, r, W, nv, p->gain, A, b); /* :554-561 */
-      uwo_solve_delta(A, b, delta);                    /* :564 */
+      normal_equations_ar(ar, J, r, W, nv, p->gain, A, b); /* :554-561 */
+      solve_delta_ar(ar, A, b, delta);                 /* :564 */
       float dT[7], np[7];
       uwo_se3_exp(delta, dT);                          /* :574 */
       uwo_se3_mul(pose, dT, np);
@@ -856,7 +936,8 @@ int uwo_align_pair_points(const uwo_params* p, const uint8_t* ref_gray, const ui
                           const uint16_t* ref_depth, const float* const* tables, const int32_t* n_points,
                           float pose_out[7], uwo_trace* trace, int32_t* n_trace) {
   if (p->n_levels < 1 || p->n_levels > UWO_MAX_LEVELS) return UWO_ERR_INVALID_ARG;
-  if ((p->width % (1 << (p->n_levels - 1))) || (p->height % (1 << (p->n_levels - 1)))) return UWO_ERR_INVALID_ARG;
+  if (p->width < 1 || p->height < 1 || (p->width >> (p->n_levels - 1)) < 1 || (p->height >> (p->n_levels - 1)) < 1)
+    return UWO_ERR_INVALID_ARG; /* every level needs at least one grid point */
   uwo_frame fr[2];
   memset(fr, 0, sizeof(fr));
   void* owned[2][UWO_MAX_LEVELS][4];
@@ -864,18 +945,22 @@ int uwo_align_pair_points(const uwo_params* p, const uint8_t* ref_gray, const ui
   const uint8_t* gray[2] = {ref_gray, tgt_gray};
   for (int f = 0; f < 2; f++) {
     for (int l = 0; l < p->n_levels; l++) {
-      int w = p->width >> l, h = p->height >> l;
+      uwo_level Ll;
+      uwo_level_intrinsics(p, l, &Ll);
+      int w = Ll.iw, h = Ll.ih; /* images_[l].cols / rows: the resize chain (System.cpp:246-251) */
       size_t n = (size_t)w * h;
       if (l == 0) {
         fr[f].img[0] = gray[f];
         if (f == 0 && p->has_depth) fr[f].depth[0] = ref_depth;
       } else {
         uint8_t* im = (uint8_t*)malloc(n);
-        uwo_halve_u8(fr[f].img[l - 1], w * 2, h * 2, im);
+        uwo_level Lp;
+        uwo_level_intrinsics(p, l - 1, &Lp);
+        uwo_resize_half_u8(fr[f].img[l - 1], Lp.iw, Lp.ih, im);
         fr[f].img[l] = im; owned[f][l][0] = im;
         if (f == 0 && p->has_depth) {
           uint16_t* d = (uint16_t*)malloc(n * 2);
-          uwo_halve_u16(fr[f].depth[l - 1], w * 2, h * 2, d);
+          uwo_resize_half_u16(fr[f].depth[l - 1], Lp.iw, Lp.ih, d);
           fr[f].depth[l] = d; owned[f][l][1] = d;
         }
       }
@@ -946,16 +1031,23 @@ int uwo_add_patch_points(const float* pts_in, int n, int w, int h, int patch_siz
  * z = 1 without depth.  With depth the reference indexes the 16-bit image through at<uchar> (:1339, :1344): byte x of
  * row y, scaled by 0.0002 with no level factor — reproduced as is.  Returns the count (<= cap written). */
 int uwo_candidate_points(const uint8_t* mag, const uint16_t* depth, int w, int h, double threshold, float* pts, int cap) {
+  return uwo_candidate_points_ex(mag, depth, w, h, w, h, threshold, pts, cap);
+}
+
+/* the same with the level's image (iw x ih: gradient_[lvl] and depths_[lvl], whose mean cuda::meanStdDev takes over the whole
+ * Mat, :1324) and its point grid (w x h = w_[lvl] x h_[lvl], the loops of :1334-1335) apart */
+int uwo_candidate_points_ex(const uint8_t* mag, const uint16_t* depth, int iw, int ih, int w, int h, double threshold, float* pts,
+                            int cap) {
   double sum = 0.0;
-  for (int i = 0; i < w * h; i++) sum += mag[i];
-  const double thres = sum / (double)((size_t)w * h) + threshold;
+  for (size_t i = 0; i < (size_t)iw * ih; i++) sum += mag[i];
+  const double thres = sum / (double)((size_t)iw * ih) + threshold;
   int n = 0;
   for (int x = 0; x < w; x++)
     for (int y = 0; y < h; y++) {
-      if (!((double)mag[(size_t)y * w + x] > thres)) continue;
+      if (!((double)mag[(size_t)y * iw + x] > thres)) continue;
       float z = 1.0f;
       if (depth) {
-        const uint8_t b = ((const uint8_t*)(depth + (size_t)y * w))[x];
+        const uint8_t b = ((const uint8_t*)(depth + (size_t)y * iw))[x];
         if (b == 0) continue;
         z = (float)b * 0.0002f;
       }

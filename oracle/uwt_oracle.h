@@ -98,11 +98,14 @@ typedef struct uwo_params {
   int32_t weights;           /* UWO_WEIGHTS_* */
   int32_t sampler;           /* UWO_SAMPLER_* (bilinear is a north-star extension, not in the reference) */
   int32_t arith;             /* UWO_ARITH_OPENCV (0, default: G1..G4 above) or UWO_ARITH_LEGACY (1: S1, S3, S4) */
+  int32_t gemm_fold;         /* 0 (default): GEMMSingleMul's partial sums folded s0 + ((s1 + s2) + s3); 1: ((s0 + s1) + s2) + s3 */
 } uwo_params;
 
 typedef struct uwo_level {
-  int32_t w, h;
+  int32_t w, h;              /* w_[lvl], h_[lvl] = width >> lvl, height >> lvl (Tracker.cpp:312-313): the point grid of ObtainAllPoints */
   float fx, fy, cx, cy, invfx, invfy;
+  int32_t iw, ih;            /* images_[lvl].cols / rows: the cv::resize(.., 0.5, 0.5) chain (System.cpp:246-251), cvRound per level;
+                                equal to w, h when the level-0 size is divisible by 2^lvl, larger otherwise */
 } uwo_level;
 
 /* one row per GN iteration (fixtures / parity traces) */
@@ -124,6 +127,11 @@ int uwo_level_intrinsics(const uwo_params* p, int lvl, uwo_level* out);
 /* System::AddFrame pyramid loop, System.cpp:246-251 (cv::resize ½ == 2x2 mean, round half up) */
 void uwo_halve_u8(const uint8_t* src, int w, int h, uint8_t* dst);
 void uwo_halve_u16(const uint16_t* src, int w, int h, uint16_t* dst);
+/* the same call on ANY source size: dst is uwo_half_size(sw) x uwo_half_size(sh) (cvRound: half to even), whole cells as
+ * above, the partial last column / row by resizeAreaFast's generic tail (mean of the existing pixels, cvRound) */
+int  uwo_half_size(int n);
+void uwo_resize_half_u8(const uint8_t* src, int sw, int sh, uint8_t* dst);
+void uwo_resize_half_u16(const uint16_t* src, int sw, int sh, uint16_t* dst);
 
 /* Tracker::ApplyGradient, Tracker.cpp:1133-1134: cv::Scharr(.., CV_16S, dx, dy, scale=3, delta=0, BORDER_REFLECT_101) */
 void uwo_scharr3(const uint8_t* src, int w, int h, int16_t* gx, int16_t* gy);
@@ -132,6 +140,8 @@ void uwo_gradient_mag(const int16_t* gx, const int16_t* gy, int n, uint8_t* out)
 
 /* Tracker::ObtainAllPoints, Tracker.cpp:1259-1310: dense N x 4 table [x y z w] */
 void uwo_dense_points(const uint16_t* depth_or_null, int w, int h, int lvl, float depth_scale, float* pts);
+/* the w x h grid over a depth image with rows of `stride` elements (the level's image is wider than its grid) */
+void uwo_dense_points_ex(const uint16_t* depth_or_null, int stride, int w, int h, int lvl, float depth_scale, float* pts);
 
 /* SE3 helpers; pose = qx qy qz qw tx ty tz */
 void uwo_se3_identity(float pose[7]);
@@ -142,10 +152,13 @@ int  uwo_se3_handoff(float pose[7], int scale_t);                   /* Tracker.c
 
 /* Tracker::WarpFunction, Tracker.cpp:1417-1471 */
 void uwo_warp(const float* pts, int n, const float pose[7], const uwo_level* L, float* warped);
-/* Process-wide arithmetic set of the per-stage functions (uwo_warp, uwo_residual_jacobian*, uwo_normal_equations,
- * uwo_error, uwo_solve_delta); uwo_estimate_pose* set it from uwo_params::arith on entry.  Returns the previous one. */
+/* Arithmetic set of the per-stage functions that take no parameter block (uwo_warp, uwo_residual_jacobian*,
+ * uwo_normal_equations, uwo_error, uwo_solve_delta) FOR THE CALLING THREAD (thread-local; nothing process-wide).
+ * uwo_estimate_pose* / uwo_align_pair* do not read it: they take the set from uwo_params::arith and hand it down with the call,
+ * so alignments of different sets may run side by side in a thread pool.  Returns the thread's previous one. */
 int uwo_set_arith(int arith);
-/* fold of GEMMSingleMul's four partial sums: 0 (default) s0 + ((s1 + s2) + s3), 1 ((s0 + s1) + s2) + s3; returns the previous */
+/* fold of GEMMSingleMul's four partial sums for the calling thread: 0 (default) s0 + ((s1 + s2) + s3), 1 ((s0 + s1) + s2) + s3;
+ * returns the previous.  uwo_estimate_pose* use fold 1 when uwo_params::gemm_fold or the calling thread's default says so. */
 int uwo_set_gemm_fold(int fold);
 
 /* per-point loop of Tracker::EstimatePose, Tracker.cpp:432-490.
@@ -195,6 +208,8 @@ int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const u
 int uwo_patch_points(const float* kp, int n_kp, const uint16_t* depth0_or_null, int w, int h, float* pts, int cap);
 int uwo_add_patch_points(const float* pts_in, int n, int w, int h, int patch_size, float* pts, int cap);  /* Tracker.cpp:599-629 */
 int uwo_candidate_points(const uint8_t* mag, const uint16_t* depth_or_null, int w, int h, double threshold, float* pts, int cap);
+int uwo_candidate_points_ex(const uint8_t* mag, const uint16_t* depth_or_null, int iw, int ih, int w, int h, double threshold,
+                            float* pts, int cap);
 
 /* convenience: level-0 images in, pyramid + gradients + EstimatePose; (the CPU-baseline unit of work) */
 int uwo_align_pair(const uwo_params* p, const uint8_t* ref_gray, const uint8_t* tgt_gray,

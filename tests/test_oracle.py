@@ -420,3 +420,127 @@ def test_gemm_fold_follows_the_published_statement(O):
     finally:
         O.set_gemm_fold(prev)
     assert O.warp(pts, pose, L)[0][2] == lo
+
+
+# ---------------------------------------------------------------- frame sizes the resize chain does not divide
+# (System.cpp:148-191 crops to a data-dependent ROI; :246-251 halves with cv::resize(.., 0.5, 0.5); Tracker.cpp:312-313 sizes
+#  the point grid with ">> lvl")
+
+def _np_resize_half(img):
+    """Independent restatement of resizeAreaFast for scale 2 x 2: whole cells (a+b+c+d+2)>>2; the partial last column of whole
+    rows and EVERY cell of a partial last row: mean of the pixels that exist, rounded half to even."""
+    img = np.asarray(img)
+    sh, sw = img.shape
+    dh, dw = int(np.rint(sh * 0.5)), int(np.rint(sw * 0.5))    # np.rint: half to even, like cvRound
+    a = img.astype(np.int64)
+    out = np.zeros((dh, dw), np.int64)
+    fh, fw = sh // 2, sw // 2
+    c = a[:2 * fh, :2 * fw]
+    out[:fh, :fw] = (c[0::2, 0::2] + c[0::2, 1::2] + c[1::2, 0::2] + c[1::2, 1::2] + 2) >> 2
+    if dw > fw:   # partial last column: two pixels of column sw - 1
+        col = a[:2 * fh, sw - 1]
+        out[:fh, fw] = np.rint((col[0::2] + col[1::2]) / 2.0)
+    if dh > fh:   # partial last row: every cell by the generic tail
+        row = a[sh - 1]
+        out[fh, :fw] = np.rint((row[0:2 * fw:2] + row[1:2 * fw:2]) / 2.0)
+        if dw > fw:
+            out[fh, fw] = row[sw - 1]
+    return out.astype(img.dtype)
+
+
+@pytest.mark.one_arith
+def test_half_size_is_cvround(O):
+    # saturate_cast<int>(ssize * 0.5) = cvRound: half to even
+    assert [O.half_size(n) for n in (733, 735, 725, 465, 471, 479, 640, 1, 2, 3, 5, 7)] == [366, 368, 362, 232, 236, 240, 320, 0, 1, 2, 2, 4]
+
+
+@pytest.mark.one_arith
+def test_resize_half_any_size(O):
+    rng = np.random.default_rng(77)
+    for (h, w) in ((480, 640), (471, 733), (479, 735), (465, 725), (7, 9), (5, 6), (6, 5), (3, 3), (2, 7), (7, 2), (9, 11), (10, 13)):
+        im = rng.integers(0, 256, (h, w)).astype(np.uint8)
+        d16 = rng.integers(0, 65536, (h, w)).astype(np.uint16)
+        assert np.array_equal(O.resize_half_u8(im), _np_resize_half(im)), (h, w)
+        assert np.array_equal(O.resize_half_u16(d16), _np_resize_half(d16)), (h, w)
+        if h % 2 == 0 and w % 2 == 0:
+            assert np.array_equal(O.resize_half_u8(im), O.halve_u8(im))
+            assert np.array_equal(O.resize_half_u16(d16), O.halve_u16(d16))
+    # the two roundings apart: a whole cell rounds half up, a partial cell half to even
+    im = np.array([[1, 2, 2], [1, 2, 3], [2, 3, 0]], np.uint8)        # 3 x 3 -> 2 x 2
+    assert O.resize_half_u8(im).tolist() == [[2, 2], [2, 0]]           # (6+2)>>2 = 2; rint(2.5) = 2; rint(2.5) = 2; the corner itself
+
+
+@pytest.mark.one_arith
+def test_level_geometry_of_odd_sizes(O):
+    for (w, h, n) in ((733, 471, 5), (735, 479, 5), (725, 465, 5), (752, 480, 5), (640, 480, 4), (163, 99, 4)):
+        p = O.default_params(w, h, 400.0, 400.0, w / 2, h / 2, n_levels=n, first_level=n - 1)
+        iw, ih = w, h
+        for l in range(n):
+            L = O.level_intrinsics(p, l)
+            assert (L.w, L.h) == (w >> l, h >> l)                      # Tracker.cpp:312-313
+            assert (L.iw, L.ih) == (iw, ih)                            # the resize chain
+            assert L.iw >= L.w and L.ih >= L.h                         # the grid never leaves the image
+            iw, ih = int(np.rint(iw * 0.5)), int(np.rint(ih * 0.5))
+    L3 = O.level_intrinsics(O.default_params(733, 471, 1, 1, 0, 0), 3)
+    assert (L3.w, L3.h, L3.iw, L3.ih) == (91, 58, 92, 59)
+
+
+def test_odd_size_alignment_equals_the_cropped_one_above_level_0(O, synth):
+    """161 x 97 halves to 80 x 48 with the last column and row DROPPED (161 * 0.5 = 80.5 -> 80, 97 * 0.5 = 48.5 -> 48: both
+    to even), so every level >= 1 — image and grid — is that of the 160 x 96 crop: an alignment that stops at level 1 must
+    give the crop's pose bit for bit.  (Ties the odd-size path to the sizes the goldens pin.)"""
+    w, h, f = 161, 97, 131.25
+    ref, tgt, dep, _, _ = synth.render_pair(w, h, f, f, 79.5, 47.5, seed=31, with_depth=True)
+    for depth in (False, True):
+        over = dict(n_levels=4, first_level=3, last_level=1, max_iters=6, early_exit=0, has_depth=int(depth))
+        st, pose, tr = O.align_pair(O.default_params(w, h, f, f, 79.5, 47.5, **over), ref, tgt, dep if depth else None, want_trace=True)
+        st2, pose2, tr2 = O.align_pair(O.default_params(160, 96, f, f, 79.5, 47.5, **over), ref[:96, :160], tgt[:96, :160],
+                                       dep[:96, :160] if depth else None, want_trace=True)
+        assert st == 0 and st2 == 0
+        assert np.array_equal(pose, pose2)
+        assert [t["n_valid"] for t in tr] == [t["n_valid"] for t in tr2]
+
+
+def test_odd_size_alignment_recovers_the_motion(O, synth):
+    """Whole alignments at sizes with partial cells (163 -> 82, 99 -> 50), dropped columns (165 -> 82) and grids smaller than
+    their images: the pose lands where the even-sized alignments of the same scene land.  (The fixed 4 x 10 schedule is not
+    contractive — DESIGN.md §2 — so crops of one scene, even-sized ones too (164 x 100, 168 x 104), end up to 2.5e-3 m apart; the
+    bound below is that spread, not an accuracy claim.)"""
+    f = 131.25
+    big_ref, big_tgt, big_dep, R, t = synth.render_pair(168, 104, f, f, 83.5, 51.5, seed=37, with_depth=True)
+    over = dict(n_levels=4, first_level=3, last_level=0, max_iters=10, early_exit=0)
+    base = O.align_pair(O.default_params(160, 96, f, f, 83.5, 51.5, **over), big_ref[:96, :160], big_tgt[:96, :160])[1]
+    for (w, h) in ((163, 99), (165, 101), (167, 103), (161, 97), (166, 98)):
+        p = O.default_params(w, h, f, f, 83.5, 51.5, **over)
+        st, pose, tr = O.align_pair(p, big_ref[:h, :w], big_tgt[:h, :w], want_trace=True)
+        assert st == 0
+        assert np.linalg.norm(pose[4:] - base[4:]) < 5e-3 and np.linalg.norm(pose[:3] - base[:3]) < 2.5e-3, (w, h, pose, base)
+        for tt in tr:   # never more valid points than the level's grid holds
+            L = O.level_intrinsics(p, tt["level"])
+            assert 0 < tt["n_valid"] <= L.w * L.h
+        pd = O.default_params(w, h, f, f, 83.5, 51.5, has_depth=1, **over)
+        assert O.align_pair(pd, big_ref[:h, :w], big_tgt[:h, :w], big_dep[:h, :w])[0] == 0
+
+
+def test_two_threads_with_different_arithmetic_sets(O, synth):
+    """The arithmetic set travels with the call (uwo_params::arith): two threads aligning under different sets at the same
+    time get what each gets alone.  (Rounds 1-5 kept the set in a process-wide variable that every call overwrote.)"""
+    import threading
+    w, h, f = 160, 96, 131.25
+    ref, tgt, _, _, _ = synth.render_pair(w, h, f, f, 79.5, 47.5, seed=41)
+    over = dict(n_levels=4, first_level=3, last_level=0, max_iters=10, early_exit=0)
+    alone = {a: O.align_pair(O.default_params(w, h, f, f, 79.5, 47.5, arith=a, **over), ref, tgt)[1] for a in (0, 1)}
+    assert not np.array_equal(alone[0], alone[1])
+    out = {0: [], 1: []}
+
+    def work(a):
+        for _ in range(12):
+            out[a].append(O.align_pair(O.default_params(w, h, f, f, 79.5, 47.5, arith=a, **over), ref, tgt)[1])
+
+    th = [threading.Thread(target=work, args=(a,)) for a in (0, 1)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    for a in (0, 1):
+        assert len(out[a]) == 12 and all(np.array_equal(p, alone[a]) for p in out[a])
