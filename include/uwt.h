@@ -20,7 +20,8 @@ extern "C" {
 #endif
 
 #define UWT_MAX_LEVELS 8
-#define UWT_ABI_VERSION 3   /* 2: uwt_params::arith; 3: uwt_tuning (no environment variables are read any more) */
+#define UWT_ABI_VERSION 4   /* 2: uwt_params::arith; 3: uwt_tuning (no environment variables are read any more); 4: any frame size
+                               (uwt_level::img_w / img_h / pitch, uwt_resize_half_*) */
 
 enum uwt_status_code {
   UWT_OK = 0,
@@ -51,7 +52,8 @@ enum uwt_arith { UWT_ARITH_OPENCV = 0, UWT_ARITH_LEGACY = 1 };
 /* All solver constants the reference hard-codes as locals of Tracker::EstimatePose* (src/Tracker.cpp:364-372,
  * 634-640) and as link-time globals (src/Options.cpp:26-28), as one POD. */
 typedef struct uwt_params {
-  int32_t width, height;     /* level-0 size; must be divisible by 2^(n_levels-1)                       */
+  int32_t width, height;     /* level-0 size (w_, h_ of src/System.cpp:123: the ROI size of :186-190 when the camera is
+                                distorted — any size, as long as (size >> (n_levels-1)) >= 1)                             */
   float fx, fy, cx, cy;      /* level-0 intrinsics = K passed to Tracker::InitializePyramid              */
   int32_t n_levels;          /* PYRAMID_LEVELS, src/Options.cpp:26 (5)                                   */
   int32_t first_level;       /* coarsest level iterated, src/Tracker.cpp:368 (4)                         */
@@ -77,10 +79,21 @@ typedef struct uwt_params {
   int32_t arith;             /* uwt_arith: UWT_ARITH_OPENCV (default) or UWT_ARITH_LEGACY                */
 } uwt_params;
 
-/* per-level camera model = the vectors Tracker::InitializePyramid fills (include/Tracker.h:516-528) */
+/* per-level camera model = the vectors Tracker::InitializePyramid fills (include/Tracker.h:516-528), and the size of the
+ * level's images.  The two sizes differ where the level-0 size is not divisible by 2^lvl (the reference's EUROC path crops to a
+ * data-dependent ROI, src/System.cpp:148-191):
+ *   w, h          w_[lvl], h_[lvl] = size >> lvl (src/Tracker.cpp:312-313): the point grid ObtainAllPoints walks (:1267-1268);
+ *   img_w, img_h  images_[lvl].cols / rows: the chain of cv::resize(.., Size(), 0.5, 0.5) (src/System.cpp:246-251), each step
+ *                 cvRound(size * 0.5) — half to even: 733 -> 366, 735 -> 368; what the bounds test of src/Tracker.cpp:450 reads
+ *                 and what uwt_get_plane returns; img_w >= w, img_h >= h;
+ *   pitch         elements per row of the level's planes in device memory (img_w rounded up to a multiple of 4): what a producer
+ *                 that writes frames in place through uwt_plane_device_ptr must honour — a slot is pitch * img_h elements.  Equal to
+ *                 the width for every width that is a multiple of 4. */
 typedef struct uwt_level {
   int32_t w, h;
   float fx, fy, cx, cy, invfx, invfy;
+  int32_t img_w, img_h;
+  int32_t pitch;
 } uwt_level;
 
 typedef struct uwt_stats {
@@ -179,9 +192,10 @@ int uwt_upload_frames_async(uwt_ctx* ctx, int32_t first_slot, int32_t n, const u
 /* page-locked host memory for uwt_upload_frames_async (hipHostMalloc / hipHostFree) */
 int uwt_host_alloc(size_t bytes, void** out);
 int uwt_host_free(void* p);
-/* device pointer of a plane of a slot (so a producer can write level-0 frames in place, inputs resident in HBM) */
+/* device pointer of a plane of a slot (so a producer can write level-0 frames in place, inputs resident in HBM): img_h rows of
+ * uwt_level::pitch elements, the first img_w of each row the image (tight rows whenever the width is a multiple of 4) */
 int uwt_plane_device_ptr(uwt_ctx* ctx, int32_t slot, int32_t lvl, int32_t plane, void** out);
-/* copy one plane of one slot back to the host (tight rows) */
+/* copy one plane of one slot back to the host: img_h x img_w elements, tight rows */
 int uwt_get_plane(uwt_ctx* ctx, int32_t slot, int32_t lvl, int32_t plane, void* host_out);
 
 /* the resize loop of System::AddFrame for levels 1..n_levels-1 (src/System.cpp:246-251), n frames at once */
@@ -254,15 +268,21 @@ int uwt_profile_clock(uwt_ctx* ctx, double* shader_ghz);
 
 /* ---- per-stage entry points (each kernel parity-testable alone; host buffers, synchronous) ------------------ */
 
-/* cv::resize(src, dst, Size(), 0.5, 0.5) as used at src/System.cpp:247 / :249 */
+/* cv::resize(src, dst, Size(), 0.5, 0.5) as used at src/System.cpp:247 / :249, even sizes (dst: w/2 x h/2) */
 int uwt_halve_u8(uwt_ctx* ctx, const uint8_t* src, int32_t w, int32_t h, uint8_t* dst);
 int uwt_halve_u16(uwt_ctx* ctx, const uint16_t* src, int32_t w, int32_t h, uint16_t* dst);
+/* the same call on ANY size: dst is uwt_half_size(w) x uwt_half_size(h) = cvRound(size * 0.5) (half to even); whole 2 x 2 cells
+ * (a + b + c + d + 2) >> 2, the half cells of a partial last column and every cell of a partial last row by resizeAreaFast's
+ * generic tail: the mean of the pixels that exist, rounded half to even */
+int uwt_half_size(int32_t n);
+int uwt_resize_half_u8(uwt_ctx* ctx, const uint8_t* src, int32_t w, int32_t h, uint8_t* dst);
+int uwt_resize_half_u16(uwt_ctx* ctx, const uint16_t* src, int32_t w, int32_t h, uint16_t* dst);
 /* cv::Scharr(src, dst, CV_16S, 1|0, 0|1, scale=3, 0, BORDER_DEFAULT) as used at src/Tracker.cpp:1133-1134 */
 int uwt_scharr3(uwt_ctx* ctx, const uint8_t* src, int32_t w, int32_t h, int16_t* gx, int16_t* gy);
 /* Tracker::WarpFunction(points, T, lvl) (src/Tracker.cpp:1417-1471): n x 4 in, n x 4 out */
 int uwt_warp(uwt_ctx* ctx, int32_t lvl, const float* pts, int32_t n, const float pose[7], float* warped_out);
 /* one pass of the per-point loop of EstimatePose (src/Tracker.cpp:432-490) + the reduction, for one pair at one
- * level under `pose`.  Optional per-pixel dumps (level w*h entries, row-major): J_out (x6), r_out, valid_out. */
+ * level under `pose`.  Optional per-point dumps (the level's w x h point grid, row-major): J_out (x6), r_out, valid_out. */
 int uwt_residual_jacobian(uwt_ctx* ctx, int32_t ref_slot, int32_t tgt_slot, int32_t lvl, const float pose[7],
                           uwt_accum* acc_out, float* J_out_or_null, float* r_out_or_null, uint8_t* valid_out_or_null);
 /* Same under the context's sampler / weights (general path): additionally returns the per-pixel robust weights

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(capi):
     for name in declared:
         assert hasattr(lib, name), name
     assert sorted(capi.SYMBOLS) == declared
-    assert lib.uwt_abi_version() == 3   # 3: uwt_tuning
+    assert lib.uwt_abi_version() == 4   # 3: uwt_tuning; 4: any frame size (uwt_level::img_w / img_h / pitch, uwt_resize_half_*)
 
 
 def test_source_id_is_the_hash_of_sources_and_flags(capi):
@@ -57,7 +57,7 @@ def test_source_id_is_the_hash_of_sources_and_flags(capi):
 def test_struct_layouts_match_header(capi):
     import ctypes as C
     assert C.sizeof(capi.Params) == 26 * 4
-    assert C.sizeof(capi.Level) == 8 * 4
+    assert C.sizeof(capi.Level) == 11 * 4
     assert C.sizeof(capi.Stats) == 16
     assert C.sizeof(capi.Accum) == 21 * 8 + 6 * 8 + 8 + 8
     assert C.sizeof(capi.Tuning) == 2 * 4 + 2 * 8 + 12 * 4 + 4 * 4

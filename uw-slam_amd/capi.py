@@ -42,7 +42,8 @@ class Tuning(C.Structure):
 
 class Level(C.Structure):
     _fields_ = [("w", C.c_int32), ("h", C.c_int32), ("fx", C.c_float), ("fy", C.c_float),
-                ("cx", C.c_float), ("cy", C.c_float), ("invfx", C.c_float), ("invfy", C.c_float)]
+                ("cx", C.c_float), ("cy", C.c_float), ("invfx", C.c_float), ("invfy", C.c_float),
+                ("img_w", C.c_int32), ("img_h", C.c_int32), ("pitch", C.c_int32)]   # w, h: point grid; img_*: the level's image
 
 
 class Stats(C.Structure):
@@ -60,6 +61,7 @@ SYMBOLS = [
     "uwt_level_info", "uwt_set_frame", "uwt_upload_frames", "uwt_upload_frames_async", "uwt_host_alloc", "uwt_host_free", "uwt_plane_device_ptr", "uwt_get_plane",
     "uwt_build_pyramids", "uwt_apply_gradient", "uwt_estimate_pose_batch", "uwt_track_batch_async", "uwt_track_batch_host_async", "uwt_wait_ticket", "uwt_sync", "uwt_set_deferred",
     "uwt_stream", "uwt_profile_enable", "uwt_profile_read", "uwt_profile_read_levels", "uwt_profile_clock", "uwt_halve_u8", "uwt_halve_u16", "uwt_scharr3",
+    "uwt_half_size", "uwt_resize_half_u8", "uwt_resize_half_u16",
     "uwt_warp", "uwt_residual_jacobian", "uwt_ls_accumulate", "uwt_se3_exp", "uwt_se3_mul", "uwt_se3_matrix",
     "uwt_se3_handoff", "uwt_solve_delta", "uwt_accumulate_trajectory", "uwt_accumulate_trajectory_scan",
     "uwt_residual_jacobian_weighted", "uwt_estimate_pose_points", "uwt_gradient_magnitude",
@@ -274,7 +276,7 @@ class Context:
     def get_plane(self, slot, lvl, plane):
         L = self.level_info(lvl)
         dt = {PLANE_IMAGE: np.uint8, PLANE_DEPTH: np.uint16, PLANE_GRADX: np.int16, PLANE_GRADY: np.int16}[plane]
-        out = np.empty((L.h, L.w), dt)
+        out = np.empty((L.img_h, L.img_w), dt)   # the level's image (larger than its point grid at odd sizes)
         self._chk(lib().uwt_get_plane(self._h, slot, lvl, plane, out.ctypes.data_as(C.c_void_p)))
         return out
 
@@ -363,6 +365,21 @@ class Context:
         h, w = img.shape
         out = np.empty((h // 2, w // 2), np.uint16)
         self._chk(lib().uwt_halve_u16(self._h, _p(img, C.c_uint16), w, h, _p(out, C.c_uint16)))
+        return out
+
+    def resize_half_u8(self, img):
+        """cv::resize(img, Size(), 0.5, 0.5) on any size."""
+        img = np.ascontiguousarray(img, np.uint8)
+        h, w = img.shape
+        out = np.empty((lib().uwt_half_size(h), lib().uwt_half_size(w)), np.uint8)
+        self._chk(lib().uwt_resize_half_u8(self._h, _p(img, C.c_uint8), w, h, _p(out, C.c_uint8)))
+        return out
+
+    def resize_half_u16(self, img):
+        img = np.ascontiguousarray(img, np.uint16)
+        h, w = img.shape
+        out = np.empty((lib().uwt_half_size(h), lib().uwt_half_size(w)), np.uint16)
+        self._chk(lib().uwt_resize_half_u16(self._h, _p(img, C.c_uint16), w, h, _p(out, C.c_uint16)))
         return out
 
     def scharr3(self, img):
@@ -500,7 +517,7 @@ class Context:
 
     def gradient_magnitude(self, slot, lvl):
         L = self.level_info(lvl)
-        out = np.empty((L.h, L.w), np.uint8)
+        out = np.empty((L.img_h, L.img_w), np.uint8)   # gradient_[lvl]: the level's image
         self._chk(lib().uwt_gradient_magnitude(self._h, slot, lvl, _p(out, C.c_uint8)))
         return out
 

@@ -23,7 +23,9 @@ struct uwt_ctx {
   uwt_params p;
   uwt_level info[UWT_MAX_LEVELS];
   LevelK lv[UWT_MAX_LEVELS];
-  int vecl[UWT_MAX_LEVELS];             // pixels per vector group at each level (level_vec: 4 where the width is a multiple of 4, else 1)
+  int vecl[UWT_MAX_LEVELS];             // pixels per vector group at each level (level_vec: 4 where the grid's rows are whole groups of four, else 1)
+  bool whole = true;                    // the level-0 size is divisible by 2^(n_levels-1): every level's image is its grid, every cell of
+                                        // the resize chain whole (the one-launch pyramid forms apply)
   int slices[UWT_MAX_LEVELS];
   int groups_per_block[UWT_MAX_LEVELS];
   hipStream_t stream = nullptr;
@@ -182,8 +184,12 @@ void init_levels(uwt_ctx* c) {
       fy = (float)((double)fy * 0.5);
     }
     uwt_level& I = c->info[l];
-    I.w = p.width >> l;
+    I.w = p.width >> l;    // the point grid: w_[lvl], h_[lvl] (src/Tracker.cpp:312-313)
     I.h = p.height >> l;
+    // the level's image: the cv::resize(.., Size(), 0.5, 0.5) chain of src/System.cpp:246-251, dsize = cvRound(ssize * 0.5)
+    I.img_w = l == 0 ? p.width : (int32_t)std::lrint((double)c->info[l - 1].img_w * 0.5);   // (lrint: half to even, as cvRound)
+    I.img_h = l == 0 ? p.height : (int32_t)std::lrint((double)c->info[l - 1].img_h * 0.5);
+    I.pitch = (I.img_w + 3) & ~3;
     I.fx = fx;
     I.fy = fy;
     I.cx = l == 0 ? p.cx : (float)(((double)p.cx + 0.5) / (double)(1 << l) - 0.5);
@@ -191,31 +197,54 @@ void init_levels(uwt_ctx* c) {
     I.invfx = 1.0f / fx;
     I.invfy = 1.0f / fy;
     LevelK& L = c->lv[l];
-    L.w = I.w; L.h = I.h; L.n = I.w * I.h;
+    L.pitch = I.pitch; L.iw = I.img_w; L.ih = I.img_h; L.gw = I.w; L.gh = I.h;
+    L.n = I.pitch * I.img_h;
+    L.ng = I.pitch * I.h;
     L.fx = I.fx; L.fy = I.fy; L.cx = I.cx; L.cy = I.cy; L.invfx = I.invfx; L.invfy = I.invfy;
     // "(col - cx) * invfx" (src/Tracker.cpp:1439): MatOp_AddEx::multiply scales s = -cx by invfx in double, convertTo narrows
     L.bx = (float)(-(double)I.cx * (double)I.invfx);
     L.by = (float)(-(double)I.cy * (double)I.invfy);
     L.zscale = (float)((double)p.depth_scale / std::pow(2.0, (double)l));  // src/Tracker.cpp:1266
-    L.magic = (uint32_t)((0x100000000ull + (uint64_t)I.w - 1) / (uint64_t)I.w);
+    L.magic = (uint32_t)((0x100000000ull + (uint64_t)I.pitch - 1) / (uint64_t)I.pitch);
   }
+  const int div = 1 << (p.n_levels - 1);
+  c->whole = p.width % div == 0 && p.height % div == 0;
 }
 
-// src/dst point at slot 0 of the level planes; the frames processed are slots[0..n) if given, else first_slot..+n
+// One step of the resize chain: level plane `src` (sw x sh, rows of src_pitch) -> `dst` (dw x dh = cvRound halves, rows of
+// dst_pitch).  src/dst point at slot 0 of the level planes; the frames processed are slots[0..n) if given, else first_slot..+n.
+// Whole cells in tight rows of whole groups of four: k_halve; every other size: k_resize_half.
 template <typename T>
-int launch_halve(uwt_ctx* c, const T* src, T* dst, int w_out, int h_out, size_t sfs, size_t dfs, int n_frames,
-                 const int* d_slots = nullptr, int first_slot = 0) {
+int launch_resize(uwt_ctx* c, const T* src, T* dst, int sw, int sh, int src_pitch, int dw, int dh, int dst_pitch, size_t sfs,
+                  size_t dfs, int n_frames, const int* d_slots = nullptr, int first_slot = 0) {
   if (n_frames == 0) return UWT_OK;
-  if (w_out % 4 == 0) {
-    const int groups = (w_out / 4) * h_out;
+  if (sw == 2 * dw && sh == 2 * dh && dw % 4 == 0) {
+    const int groups = (dw / 4) * dh;
     hipLaunchKernelGGL((k_halve<T, 4>), dim3((groups + kBlock - 1) / kBlock, n_frames), dim3(kBlock), 0, c->stream, src,
-                       dst, w_out, h_out, sfs, dfs, d_slots, first_slot);
+                       dst, dw, dh, src_pitch, dst_pitch, sfs, dfs, d_slots, first_slot);
   } else {
-    const int groups = w_out * h_out;
-    hipLaunchKernelGGL((k_halve<T, 1>), dim3((groups + kBlock - 1) / kBlock, n_frames), dim3(kBlock), 0, c->stream, src,
-                       dst, w_out, h_out, sfs, dfs, d_slots, first_slot);
+    const int groups = (dst_pitch / 4) * dh;
+    hipLaunchKernelGGL((k_resize_half<T>), dim3((groups + kBlock - 1) / kBlock, n_frames), dim3(kBlock), 0, c->stream, src,
+                       dst, sw, sh, src_pitch, dw, dh, dst_pitch, sfs, dfs, d_slots, first_slot);
   }
   HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
+// cv::resize(src, dst, Size(), 0.5, 0.5) of one host image of any size through pitched scratch planes (rows padded to whole
+// groups of four, as the context's level planes are); dst is dw x dh
+template <typename T>
+int resize_half_host(uwt_ctx* c, const T* src, int sw, int sh, T* dst, int dw, int dh) {
+  const size_t sp = ((size_t)sw + 3) & ~(size_t)3, dp = ((size_t)dw + 3) & ~(size_t)3, es = sizeof(T);
+  const size_t off = (sp * sh * es + 255) & ~(size_t)255;
+  int st = ensure_scratch(c, off + dp * dh * es + 64);
+  if (st) return st;
+  unsigned char* d = (unsigned char*)c->scratch;
+  HIPCHK(c, hipMemcpy2DAsync(d, sp * es, src, (size_t)sw * es, (size_t)sw * es, sh, hipMemcpyHostToDevice, c->stream));
+  st = launch_resize<T>(c, (const T*)d, (T*)(d + off), sw, sh, (int)sp, dw, dh, (int)dp, sp * sh, dp * dh, 1);
+  if (st) return st;
+  HIPCHK(c, hipMemcpy2DAsync(dst, (size_t)dw * es, d + off, dp * es, (size_t)dw * es, dh, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
 }
 
@@ -229,9 +258,10 @@ void launch_pyramid_all(uwt_ctx* c, T* const* planes_in, T* const* planes, int n
   for (int l = 0; l < c->p.n_levels; l++) {
     a.dst[l] = planes[l];
     a.stride[l] = c->lv[l].n;
+    a.pitch[l] = c->lv[l].pitch;
   }
-  a.w = c->lv[0].w;
-  a.h = c->lv[0].h;
+  a.w = c->lv[0].iw;
+  a.h = c->lv[0].ih;
   a.n_levels = c->p.n_levels;
   a.slots = d_slots;
   a.first_slot = first_slot;
@@ -240,23 +270,23 @@ void launch_pyramid_all(uwt_ctx* c, T* const* planes_in, T* const* planes, int n
 }
 
 // src/gx/gy point at slot 0 of the level planes; the frames processed are slots[0..n) if given, else first_slot..+n
-int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int w, int h, size_t fs, int n_frames,
+int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int w, int h, int pitch, size_t fs, int n_frames,
                   const int* d_slots = nullptr, int first_slot = 0, hipStream_t on = nullptr) {
   if (n_frames == 0) return UWT_OK;
   hipStream_t stream = on ? on : c->stream;
   if (w % 4 == 0) {
     if (h >= 8 * kGradVRows) {  // four rows per thread on the tall levels
       const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + 4 * kGradVRows - 1) / (4 * kGradVRows));
-      hipLaunchKernelGGL(k_scharr3_v4<4>, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, fs, d_slots,
+      hipLaunchKernelGGL(k_scharr3_v4<4>, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, pitch, fs, d_slots,
                          first_slot);
     } else {
       const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + kGradVRows - 1) / kGradVRows);
-      hipLaunchKernelGGL(k_scharr3_v4<1>, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, fs, d_slots,
+      hipLaunchKernelGGL(k_scharr3_v4<1>, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, pitch, fs, d_slots,
                          first_slot);
     }
   } else {
     const int tiles = ((w + kGradTW - 1) / kGradTW) * ((h + kGradTH - 1) / kGradTH);
-    hipLaunchKernelGGL(k_scharr3, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, fs, d_slots, first_slot);
+    hipLaunchKernelGGL(k_scharr3, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, pitch, fs, d_slots, first_slot);
   }
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
@@ -355,9 +385,9 @@ int launch_general_dump(uwt_ctx* c, ResidualArgs ra, int n_pairs, int* slices_ou
   // coarser than that — very large levels, where init raises the groups per thread to stay under kMaxSlices
   int lvl = 0;
   while (lvl + 1 < c->p.n_levels && c->lv[lvl].n != ra.L.n) lvl++;
-  const int per_slice = (ra.L.n + c->slices[lvl] - 1) / c->slices[lvl];
+  const int per_slice = (ra.L.ng + c->slices[lvl] - 1) / c->slices[lvl];
   ra.groups_per_block = std::max(kBlock * 32, (per_slice + kBlock - 1) / kBlock * kBlock);
-  ra.slices = (ra.L.n + ra.groups_per_block - 1) / ra.groups_per_block;
+  ra.slices = (ra.L.ng + ra.groups_per_block - 1) / ra.groups_per_block;
   if ((size_t)ra.slices * n_pairs > c->partial_records) return fail(c, UWT_ERR_CAPACITY, "per-stage dump needs more partial records than the context holds");
   if (slices_out) *slices_out = ra.slices;
   if (ga.weights)
@@ -438,7 +468,7 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
   bool after_coarse = false;
   {
     int nc = 0;
-    while (nc < kCoarseMaxLevels && start_lvl - nc > p.last_level && c->lv[start_lvl - nc].n <= kCoarseMaxPixels) nc++;
+    while (nc < kCoarseMaxLevels && start_lvl - nc > p.last_level && c->lv[start_lvl - nc].ng <= kCoarseMaxPixels) nc++;
     if (nc > 0 && c->tn.coarse && !c->profiling && !c->compute_only) {
       CoarseArgs ca;
       std::memset(&ca, 0, sizeof(ca));
@@ -467,7 +497,7 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
     ResidualArgs ra = residual_args(c, lvl);
     ra.state = nullptr;
     {  // slicing follows the batch, as in enqueue_estimate
-      const int n_groups = c->lv[lvl].n / c->vecl[lvl];
+      const int n_groups = c->lv[lvl].ng / c->vecl[lvl];
       int want = ((c->tn.target_blocks ? c->tn.target_blocks : 4096) + n_pairs - 1) / n_pairs;
       want = std::max(1, std::min(want, c->slices[lvl]));
       const int gpt = (n_groups + want * kBlock - 1) / (want * kBlock);
@@ -504,7 +534,7 @@ int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* 
       if (c->profiling) {
         HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
         c->prof_launches += 1;
-        c->prof_pixels += (long long)n_pairs * c->lv[lvl].n;
+        c->prof_pixels += (long long)n_pairs * c->lv[lvl].gw * c->lv[lvl].gh;
       }
       first = false;
       prev_slices = ra.slices;
@@ -555,11 +585,11 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   // over the chip; a batch that fills it alone runs fewer, longer blocks (less reduction overhead per pixel, fewer
   // records to fold), still at least target_blocks per launch.
   // (early-exit schedules stay on one stream: interleaving the two halves' read-backs was built and gave +1.7 %)
-  const int parts = (p.early_exit || c->profiling || (long long)n_pairs * c->lv[0].n < c->tn.split_min_px)
+  const int parts = (p.early_exit || c->profiling || (long long)n_pairs * c->lv[0].ng < c->tn.split_min_px)
                         ? 1 : std::min(c->tn.split, n_pairs / std::max(1, c->tn.split_min));
   const int target_blocks = c->tn.target_blocks ? c->tn.target_blocks : (parts >= 2 ? 1024 : 4096);
   auto slicing = [&](int lvl, int& groups_per_block, int& slices) {
-    const int n_groups = c->lv[lvl].n / c->vecl[lvl];
+    const int n_groups = c->lv[lvl].ng / c->vecl[lvl];
     int want = (target_blocks + n_pairs - 1) / n_pairs;
     want = std::max(1, std::min(want, c->slices[lvl]));
     // Fixed schedules (every pair stays to the level's end): a block should also be long enough to carry its fixed costs — the
@@ -601,7 +631,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
   if (p.accumulate_f64 != 0 && (!general || (p.sampler == 0 && p.weights != 0 && c->tn.coarse_weighted)) && c->tn.coarse_batch_px > 0 &&
       !c->compute_only && !(c->profiling && p.early_exit))
     for (int lvl = p.first_level; lvl >= p.last_level; lvl--)
-      coarse_lvl[lvl] = c->lv[lvl].n <= c->tn.coarse_batch_px;
+      coarse_lvl[lvl] = c->lv[lvl].ng <= c->tn.coarse_batch_px;
   // one coarse level of pairs [base, base + cnt) on stream s; resume: the pairs' states exist (a level ran before this one)
   auto run_coarse = [&](int base, int cnt, hipStream_t s, int lvl, bool resume) -> int {
     CoarseArgs ca;
@@ -627,7 +657,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
     if (c->profiling) {   // (fixed schedules only: the level runs max_iters evaluations; the launch stands for that many)
       HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], s));
       c->prof_launches += p.max_iters;
-      c->prof_pixels += (long long)cnt * c->lv[lvl].n * p.max_iters;
+      c->prof_pixels += (long long)cnt * c->lv[lvl].gw * c->lv[lvl].gh * p.max_iters;
     }
     return UWT_OK;
   };
@@ -689,7 +719,7 @@ int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats,
         if (c->profiling) {
           HIPCHK(c, hipEventRecord(c->ev_pool[ev + 1], c->stream));
           c->prof_launches += 1;
-          c->prof_pixels += (long long)cnt * c->lv[lvl].n;
+          c->prof_pixels += (long long)cnt * c->lv[lvl].gw * c->lv[lvl].gh;
         }
         if (!tail) {
           hipLaunchKernelGGL(k_gn_update, dim3(cnt), dim3(kUpdateBlock), 0, c->stream, ua);
@@ -944,11 +974,14 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   if (!p || !out) return UWT_ERR_INVALID_ARG;
   *out = nullptr;
   if (p->n_levels < 1 || p->n_levels > UWT_MAX_LEVELS || p->width < 1 || p->height < 1) return UWT_ERR_INVALID_ARG;
-  const int div = 1 << (p->n_levels - 1);
-  if (p->width % div || p->height % div) return UWT_ERR_INVALID_ARG;
+  // any size whose coarsest level still has a point grid (w_[lvl] = width >> lvl >= 1, src/Tracker.cpp:312-313)
+  if ((p->width >> (p->n_levels - 1)) < 1 || (p->height >> (p->n_levels - 1)) < 1) return UWT_ERR_INVALID_ARG;
   if (p->first_level >= p->n_levels || p->last_level < 0 || p->last_level > p->first_level) return UWT_ERR_INVALID_ARG;
   if (p->max_iters < 1 || p->max_frames < 1 || p->max_pairs < 1) return UWT_ERR_INVALID_ARG;
-  if ((uint64_t)p->width * p->height * p->width >= 0x100000000ull) return UWT_ERR_INVALID_ARG;
+  {   // the kernels divide a level's linear index by its row pitch with one multiply (LevelK::magic): index * pitch < 2^32
+    const uint64_t pitch0 = ((uint64_t)p->width + 3) & ~3ull;
+    if (pitch0 * p->height * pitch0 >= 0x100000000ull) return UWT_ERR_INVALID_ARG;
+  }
   if (p->sampler < 0 || p->sampler > 1 || p->weights < 0 || p->weights > 2) return UWT_ERR_INVALID_ARG;
   if (p->sampler == 1 && p->weights == 1) return UWT_ERR_INVALID_ARG;  // the reference's Tukey medians are defined on integer residuals
   if (p->arith != UWT_ARITH_OPENCV && p->arith != UWT_ARITH_LEGACY) return UWT_ERR_INVALID_ARG;
@@ -966,7 +999,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   size_t max_slices = 1;
   for (int l = 0; l < p->n_levels; l++) {
     c->vecl[l] = level_vec(c->lv[l]);   // per level: only the levels whose rows are not whole groups of four go pixel by pixel
-    const int n_groups = c->lv[l].n / c->vecl[l];
+    const int n_groups = c->lv[l].ng / c->vecl[l];
     const int gpt = std::max(kGroupsPerThread, (n_groups + kMaxSlices * kBlock - 1) / (kMaxSlices * kBlock));
     c->groups_per_block[l] = kBlock * gpt;
     c->slices[l] = (n_groups + c->groups_per_block[l] - 1) / c->groups_per_block[l];
@@ -1006,6 +1039,12 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
     CREATE_CHK(hipMalloc((void**)&c->gx[l], n * 2));
     CREATE_CHK(hipMalloc((void**)&c->gy[l], n * 2));
     if (p->has_depth) CREATE_CHK(hipMalloc((void**)&c->depth[l], n * 2));
+    if (c->lv[l].pitch != c->lv[l].iw) {   // the pad columns of pitched rows: never part of a result, defined all the same
+      CREATE_CHK(hipMemset(c->img[l], 0, n + 4096));
+      CREATE_CHK(hipMemset(c->gx[l], 0, n * 2));
+      CREATE_CHK(hipMemset(c->gy[l], 0, n * 2));
+      if (p->has_depth) CREATE_CHK(hipMemset(c->depth[l], 0, n * 2));
+    }
   }
   CREATE_CHK(hipMalloc((void**)&c->state, sizeof(PairState) * p->max_pairs));
   CREATE_CHK(hipMalloc((void**)&c->d_ref, sizeof(int) * p->max_pairs));
@@ -1155,10 +1194,11 @@ int uwt_set_frame(uwt_ctx* c, int32_t slot, const uint8_t* gray, size_t row_stri
   if (row_stride < (size_t)w) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: row stride < width");
   int st0 = compute_begin(c, slot, 1);
   if (st0) return st0;
-  HIPCHK(c, hipMemcpy2DAsync(c->img[0] + (size_t)slot * w * h, w, gray, row_stride, w, h, hipMemcpyHostToDevice, c->stream));
+  const size_t pitch = c->lv[0].pitch, n0 = c->lv[0].n;
+  HIPCHK(c, hipMemcpy2DAsync(c->img[0] + (size_t)slot * n0, pitch, gray, row_stride, w, h, hipMemcpyHostToDevice, c->stream));
   if (c->p.has_depth) {
     if (!depth || depth_row_stride < (size_t)w * 2) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: depth required");
-    HIPCHK(c, hipMemcpy2DAsync(c->depth[0] + (size_t)slot * w * h, (size_t)w * 2, depth, depth_row_stride, (size_t)w * 2, h,
+    HIPCHK(c, hipMemcpy2DAsync(c->depth[0] + (size_t)slot * n0, pitch * 2, depth, depth_row_stride, (size_t)w * 2, h,
                                hipMemcpyHostToDevice, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1173,6 +1213,15 @@ int uwt_host_alloc(size_t bytes, void** out) {
 
 int uwt_host_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? UWT_OK : UWT_ERR_HIP; }
 
+// n tightly packed level-0 frames (width x height) into slots first_slot.. of a level-0 plane: one linear copy where the rows
+// are tight (width a multiple of 4), one 2-D copy of n * height rows into the pitched rows otherwise (a slot is pitch * height)
+static hipError_t copy_frames_in(uwt_ctx* c, void* plane0, const void* host, size_t elem, int first_slot, int n, hipStream_t s) {
+  const size_t w = c->p.width, h = c->p.height, pitch = c->lv[0].pitch;
+  unsigned char* dst = (unsigned char*)plane0 + (size_t)first_slot * c->lv[0].n * elem;
+  if (pitch == w) return hipMemcpyAsync(dst, host, w * h * elem * n, hipMemcpyHostToDevice, s);
+  return hipMemcpy2DAsync(dst, pitch * elem, host, w * elem, w * elem, h * (size_t)n, hipMemcpyHostToDevice, s);
+}
+
 int uwt_upload_frames_async(uwt_ctx* c, int32_t first_slot, int32_t n, const uint8_t* gray, const uint16_t* depth) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !gray || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_upload_frames_async: bad range");
@@ -1180,10 +1229,8 @@ int uwt_upload_frames_async(uwt_ctx* c, int32_t first_slot, int32_t n, const uin
   // behind the compute work that still reads or writes these slots, beside everything else on the context stream
   int st = dep_wait(c, c->busy, c->busy_next, c->busy_dropped, c->copy, first_slot, n);
   if (st) return st;
-  const size_t px = (size_t)c->p.width * c->p.height;
-  HIPCHK(c, hipMemcpyAsync(c->img[0] + first_slot * px, gray, px * n, hipMemcpyHostToDevice, c->copy));
-  if (c->p.has_depth && depth)
-    HIPCHK(c, hipMemcpyAsync(c->depth[0] + first_slot * px, depth, px * n * 2, hipMemcpyHostToDevice, c->copy));
+  HIPCHK(c, copy_frames_in(c, c->img[0], gray, 1, first_slot, n, c->copy));
+  if (c->p.has_depth && depth) HIPCHK(c, copy_frames_in(c, c->depth[0], depth, 2, first_slot, n, c->copy));
   return dep_note(c, c->fresh, c->fresh_next, c->fresh_dropped, c->copy, first_slot, n);
 }
 
@@ -1192,44 +1239,44 @@ int uwt_upload_frames(uwt_ctx* c, int32_t first_slot, int32_t n, const uint8_t* 
   if (!c || !gray || !slot_range_ok(c, first_slot, n)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_upload_frames: bad range");
   int st0 = compute_begin(c, first_slot, n);   // on the context stream: behind asynchronous uploads into the same slots
   if (st0) return st0;
-  const size_t px = (size_t)c->p.width * c->p.height;
-  HIPCHK(c, hipMemcpyAsync(c->img[0] + first_slot * px, gray, px * n, hipMemcpyHostToDevice, c->stream));
+  if (n) HIPCHK(c, copy_frames_in(c, c->img[0], gray, 1, first_slot, n, c->stream));
   if (c->p.has_depth) {
     if (!depth) return fail(c, UWT_ERR_INVALID_ARG, "uwt_upload_frames: depth required");
-    HIPCHK(c, hipMemcpyAsync(c->depth[0] + first_slot * px, depth, px * n * 2, hipMemcpyHostToDevice, c->stream));
+    if (n) HIPCHK(c, copy_frames_in(c, c->depth[0], depth, 2, first_slot, n, c->stream));
   }
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
 }
 
-static int plane_ptr(uwt_ctx* c, int slot, int lvl, int plane, void** out, size_t* bytes) {
+static int plane_ptr(uwt_ctx* c, int slot, int lvl, int plane, void** out, size_t* elem) {
   if (!c || !out || !slot_range_ok(c, slot, 1) || lvl < 0 || lvl >= c->p.n_levels) return UWT_ERR_INVALID_ARG;
   const size_t n = c->lv[lvl].n;
   switch (plane) {
-    case UWT_PLANE_IMAGE: *out = c->img[lvl] + slot * n; *bytes = n; break;
+    case UWT_PLANE_IMAGE: *out = c->img[lvl] + slot * n; *elem = 1; break;
     case UWT_PLANE_DEPTH:
       if (!c->p.has_depth) return UWT_ERR_INVALID_ARG;
-      *out = c->depth[lvl] + slot * n; *bytes = n * 2; break;
-    case UWT_PLANE_GRADX: *out = c->gx[lvl] + slot * n; *bytes = n * 2; break;
-    case UWT_PLANE_GRADY: *out = c->gy[lvl] + slot * n; *bytes = n * 2; break;
+      *out = c->depth[lvl] + slot * n; *elem = 2; break;
+    case UWT_PLANE_GRADX: *out = c->gx[lvl] + slot * n; *elem = 2; break;
+    case UWT_PLANE_GRADY: *out = c->gy[lvl] + slot * n; *elem = 2; break;
     default: return UWT_ERR_INVALID_ARG;
   }
   return UWT_OK;
 }
 
 int uwt_plane_device_ptr(uwt_ctx* c, int32_t slot, int32_t lvl, int32_t plane, void** out) {
-  size_t bytes;
-  int st = plane_ptr(c, slot, lvl, plane, out, &bytes);
+  size_t elem;
+  int st = plane_ptr(c, slot, lvl, plane, out, &elem);
   return st ? fail(c, st, "uwt_plane_device_ptr: bad slot/level/plane") : UWT_OK;
 }
 
 int uwt_get_plane(uwt_ctx* c, int32_t slot, int32_t lvl, int32_t plane, void* host_out) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   void* d;
-  size_t bytes;
-  int st = plane_ptr(c, slot, lvl, plane, &d, &bytes);
+  size_t elem;
+  int st = plane_ptr(c, slot, lvl, plane, &d, &elem);
   if (st || !host_out) return fail(c, UWT_ERR_INVALID_ARG, "uwt_get_plane: bad slot/level/plane");
-  HIPCHK(c, hipMemcpyAsync(host_out, d, bytes, hipMemcpyDeviceToHost, c->stream));
+  const LevelK& L = c->lv[lvl];   // the level's image, img_w x img_h, without the pad columns of its rows
+  HIPCHK(c, hipMemcpy2DAsync(host_out, (size_t)L.iw * elem, d, (size_t)L.pitch * elem, (size_t)L.iw * elem, L.ih, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
 }
@@ -1238,8 +1285,8 @@ int uwt_get_plane(uwt_ctx* c, int32_t slot, int32_t lvl, int32_t plane, void* ho
 // restricts the depth pyramids to those slots: only a pair's reference frame is ever read through its depth
 // (src/Tracker.cpp:1266-1272).
 static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n, const int* depth_slots = nullptr, int n_depth = 0) {
-  const bool fused = n <= kFewFrames && c->p.n_levels >= 3 && c->p.n_levels <= kPyrMaxLevels && c->lv[0].w % 4 == 0 &&
-                     c->lv[0].h % 4 == 0 && c->tn.fused_stages;
+  const bool fused = n <= kFewFrames && c->p.n_levels >= 3 && c->p.n_levels <= kPyrMaxLevels && c->whole && c->lv[0].iw % 4 == 0 &&
+                     c->lv[0].ih % 4 == 0 && c->tn.fused_stages;
   if (fused) {   // the whole pyramid of each plane in one launch
     if (n) launch_pyramid_all<uint8_t>(c, c->img, c->img, n, nullptr, first_slot);
     if (c->p.has_depth) {
@@ -1251,33 +1298,34 @@ static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n, const int* depth_
   }
   // batches: levels 1..3 in one pass over level 0 (k_pyramid_batch), the levels beyond by the per-level chain
   int l0 = 1;
-  if (c->p.n_levels >= 4 && c->lv[0].w % 16 == 0 && c->lv[0].h % 8 == 0 && c->tn.pyramid_batch) {
-    const int tiles = ((c->lv[0].w + 127) / 128) * ((c->lv[0].h + 63) / 64);
+  if (c->p.n_levels >= 4 && c->lv[0].iw % 16 == 0 && c->lv[0].ih % 8 == 0 && c->tn.pyramid_batch) {
+    const int tiles = ((c->lv[0].iw + 127) / 128) * ((c->lv[0].ih + 63) / 64);
     if (n) {
       PyramidBatchArgs<uint8_t> a;
       a.src = c->img[0];
-      for (int l = 0; l < 4; l++) { a.stride[l] = c->lv[l].n; if (l) a.dst[l - 1] = c->img[l]; }
-      a.w = c->lv[0].w; a.h = c->lv[0].h; a.slots = nullptr; a.first_slot = first_slot;
+      for (int l = 0; l < 4; l++) { a.stride[l] = c->lv[l].n; a.pitch[l] = c->lv[l].pitch; if (l) a.dst[l - 1] = c->img[l]; }
+      a.w = c->lv[0].iw; a.h = c->lv[0].ih; a.slots = nullptr; a.first_slot = first_slot;
       hipLaunchKernelGGL(k_pyramid_batch<uint8_t>, dim3(tiles, n), dim3(kBlock), 0, c->stream, a);
     }
     const int nd16 = !c->p.has_depth ? 0 : (depth_slots ? n_depth : n);
     if (nd16) {
       PyramidBatchArgs<uint16_t> a;
       a.src = c->depth[0];
-      for (int l = 0; l < 4; l++) { a.stride[l] = c->lv[l].n; if (l) a.dst[l - 1] = c->depth[l]; }
-      a.w = c->lv[0].w; a.h = c->lv[0].h; a.slots = depth_slots; a.first_slot = depth_slots ? 0 : first_slot;
+      for (int l = 0; l < 4; l++) { a.stride[l] = c->lv[l].n; a.pitch[l] = c->lv[l].pitch; if (l) a.dst[l - 1] = c->depth[l]; }
+      a.w = c->lv[0].iw; a.h = c->lv[0].ih; a.slots = depth_slots; a.first_slot = depth_slots ? 0 : first_slot;
       hipLaunchKernelGGL(k_pyramid_batch<uint16_t>, dim3(tiles, nd16), dim3(kBlock), 0, c->stream, a);
     }
     HIPCHK(c, hipGetLastError());
     l0 = 4;
   }
   for (int l = l0; l < c->p.n_levels; l++) {
-    const size_t ns = c->lv[l - 1].n, nd = c->lv[l].n;
-    int st = launch_halve<uint8_t>(c, c->img[l - 1], c->img[l], c->lv[l].w, c->lv[l].h, ns, nd, n, nullptr, first_slot);
+    const LevelK& S = c->lv[l - 1];
+    const LevelK& D = c->lv[l];
+    int st = launch_resize<uint8_t>(c, c->img[l - 1], c->img[l], S.iw, S.ih, S.pitch, D.iw, D.ih, D.pitch, S.n, D.n, n, nullptr, first_slot);
     if (st) return st;
     if (c->p.has_depth) {
-      st = depth_slots ? launch_halve<uint16_t>(c, c->depth[l - 1], c->depth[l], c->lv[l].w, c->lv[l].h, ns, nd, n_depth, depth_slots)
-                       : launch_halve<uint16_t>(c, c->depth[l - 1], c->depth[l], c->lv[l].w, c->lv[l].h, ns, nd, n, nullptr, first_slot);
+      st = depth_slots ? launch_resize<uint16_t>(c, c->depth[l - 1], c->depth[l], S.iw, S.ih, S.pitch, D.iw, D.ih, D.pitch, S.n, D.n, n_depth, depth_slots)
+                       : launch_resize<uint16_t>(c, c->depth[l - 1], c->depth[l], S.iw, S.ih, S.pitch, D.iw, D.ih, D.pitch, S.n, D.n, n, nullptr, first_slot);
       if (st) return st;
     }
   }
@@ -1285,7 +1333,7 @@ static int enqueue_pyramids(uwt_ctx* c, int first_slot, int n, const int* depth_
 }
 
 static int enqueue_gradient_level(uwt_ctx* c, int l, int first_slot, int n, const int* d_slots, hipStream_t on = nullptr) {
-  return launch_scharr(c, c->img[l], c->gx[l], c->gy[l], c->lv[l].w, c->lv[l].h, c->lv[l].n, n, d_slots, first_slot, on);
+  return launch_scharr(c, c->img[l], c->gx[l], c->gy[l], c->lv[l].iw, c->lv[l].ih, c->lv[l].pitch, c->lv[l].n, n, d_slots, first_slot, on);
 }
 
 static int enqueue_gradients(uwt_ctx* c, int first_slot, int n, const int* d_slots = nullptr) {
@@ -1295,7 +1343,7 @@ static int enqueue_gradients(uwt_ctx* c, int first_slot, int n, const int* d_slo
     int tiles = 0;
     for (int l = 0; l < c->p.n_levels; l++) {
       a.src[l] = c->img[l]; a.gx[l] = c->gx[l]; a.gy[l] = c->gy[l];
-      a.w[l] = c->lv[l].w; a.h[l] = c->lv[l].h; a.stride[l] = c->lv[l].n;
+      a.w[l] = c->lv[l].iw; a.h[l] = c->lv[l].ih; a.pitch[l] = c->lv[l].pitch; a.stride[l] = c->lv[l].n;
       tiles += a.w[l] % 4 == 0 ? ((a.w[l] + kGradVW - 1) / kGradVW) * ((a.h[l] + kGradVRows - 1) / kGradVRows)
                                : ((a.w[l] + kGradTW - 1) / kGradTW) * ((a.h[l] + kGradTH - 1) / kGradTH);
       a.tile_end[l] = tiles;
@@ -1585,47 +1633,44 @@ int uwt_profile_clock(uwt_ctx* c, double* shader_ghz) {
 int uwt_halve_u8(uwt_ctx* c, const uint8_t* src, int32_t w, int32_t h, uint8_t* dst) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !src || !dst || w < 2 || h < 2 || (w & 1) || (h & 1)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_halve_u8");
-  const size_t ns = (size_t)w * h, nd = ns / 4, off = (ns + 255) & ~(size_t)255;
-  int st = ensure_scratch(c, off + nd);
-  if (st) return st;
-  uint8_t* d = (uint8_t*)c->scratch;
-  HIPCHK(c, hipMemcpyAsync(d, src, ns, hipMemcpyHostToDevice, c->stream));
-  st = launch_halve<uint8_t>(c, d, d + off, w / 2, h / 2, ns, nd, 1);
-  if (st) return st;
-  HIPCHK(c, hipMemcpyAsync(dst, d + off, nd, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return UWT_OK;
+  return resize_half_host<uint8_t>(c, src, w, h, dst, w / 2, h / 2);
 }
 
 int uwt_halve_u16(uwt_ctx* c, const uint16_t* src, int32_t w, int32_t h, uint16_t* dst) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !src || !dst || w < 2 || h < 2 || (w & 1) || (h & 1)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_halve_u16");
-  const size_t ns = (size_t)w * h, nd = ns / 4, off = (ns * 2 + 255) & ~(size_t)255;
-  int st = ensure_scratch(c, off + nd * 2);
-  if (st) return st;
-  uint8_t* d = (uint8_t*)c->scratch;
-  HIPCHK(c, hipMemcpyAsync(d, src, ns * 2, hipMemcpyHostToDevice, c->stream));
-  st = launch_halve<uint16_t>(c, (uint16_t*)d, (uint16_t*)(d + off), w / 2, h / 2, ns, nd, 1);
-  if (st) return st;
-  HIPCHK(c, hipMemcpyAsync(dst, d + off, nd * 2, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return UWT_OK;
+  return resize_half_host<uint16_t>(c, src, w, h, dst, w / 2, h / 2);
+}
+
+int uwt_half_size(int32_t n) { return (int)std::lrint((double)n * 0.5); }   // cvRound(n * 0.5): half to even
+
+int uwt_resize_half_u8(uwt_ctx* c, const uint8_t* src, int32_t w, int32_t h, uint8_t* dst) {
+  if (c) (void)hipSetDevice(c->p.device);
+  if (!c || !src || !dst || w < 1 || h < 1 || uwt_half_size(w) < 1 || uwt_half_size(h) < 1) return fail(c, UWT_ERR_INVALID_ARG, "uwt_resize_half_u8");
+  return resize_half_host<uint8_t>(c, src, w, h, dst, uwt_half_size(w), uwt_half_size(h));
+}
+
+int uwt_resize_half_u16(uwt_ctx* c, const uint16_t* src, int32_t w, int32_t h, uint16_t* dst) {
+  if (c) (void)hipSetDevice(c->p.device);
+  if (!c || !src || !dst || w < 1 || h < 1 || uwt_half_size(w) < 1 || uwt_half_size(h) < 1) return fail(c, UWT_ERR_INVALID_ARG, "uwt_resize_half_u16");
+  return resize_half_host<uint16_t>(c, src, w, h, dst, uwt_half_size(w), uwt_half_size(h));
 }
 
 int uwt_scharr3(uwt_ctx* c, const uint8_t* src, int32_t w, int32_t h, int16_t* gx, int16_t* gy) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !src || !gx || !gy || w < 1 || h < 1) return fail(c, UWT_ERR_INVALID_ARG, "uwt_scharr3");
-  const size_t n = (size_t)w * h, off = (n + 255) & ~(size_t)255;
+  const size_t pitch = ((size_t)w + 3) & ~(size_t)3;   // rows padded to whole groups of four, as the context's level planes are
+  const size_t n = pitch * h, off = (n + 255) & ~(size_t)255;
   int st = ensure_scratch(c, off + n * 4);
   if (st) return st;
   uint8_t* d = (uint8_t*)c->scratch;
   int16_t* dgx = (int16_t*)(d + off);
   int16_t* dgy = dgx + n;
-  HIPCHK(c, hipMemcpyAsync(d, src, n, hipMemcpyHostToDevice, c->stream));
-  st = launch_scharr(c, d, dgx, dgy, w, h, n, 1);
+  HIPCHK(c, hipMemcpy2DAsync(d, pitch, src, w, w, h, hipMemcpyHostToDevice, c->stream));
+  st = launch_scharr(c, d, dgx, dgy, w, h, (int)pitch, n, 1);
   if (st) return st;
-  HIPCHK(c, hipMemcpyAsync(gx, dgx, n * 2, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipMemcpyAsync(gy, dgy, n * 2, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(gx, (size_t)w * 2, dgx, pitch * 2, (size_t)w * 2, h, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipMemcpy2DAsync(gy, (size_t)w * 2, dgy, pitch * 2, (size_t)w * 2, h, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
 }
@@ -1657,7 +1702,8 @@ int uwt_residual_jacobian(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, int32_
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_residual_jacobian");
   int st = upload_pairs(c, 1, &ref_slot, &tgt_slot);
   if (st) return st;
-  const size_t n = c->lv[lvl].n;
+  const LevelK& L = c->lv[lvl];
+  const size_t n = L.ng;   // device dumps are indexed like the planes (pitch x gh positions); the host receives the gw x gh grid
   const bool dump = J_out || r_out || valid_out;
   if (dump) {
     st = ensure_scratch(c, n * (6 * 4 + 4 + 1) + 512);
@@ -1676,9 +1722,9 @@ int uwt_residual_jacobian(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slot, int32_
   if (st) return st;
   std::vector<uint32_t> recs((size_t)a.slices * kRecWords);
   HIPCHK(c, hipMemcpyAsync(recs.data(), c->partials, recs.size() * 4, hipMemcpyDeviceToHost, c->stream));
-  if (J_out) HIPCHK(c, hipMemcpyAsync(J_out, a.dumpJ, n * 24, hipMemcpyDeviceToHost, c->stream));
-  if (r_out) HIPCHK(c, hipMemcpyAsync(r_out, a.dumpR, n * 4, hipMemcpyDeviceToHost, c->stream));
-  if (valid_out) HIPCHK(c, hipMemcpyAsync(valid_out, a.dumpV, n, hipMemcpyDeviceToHost, c->stream));
+  if (J_out) HIPCHK(c, hipMemcpy2DAsync(J_out, (size_t)L.gw * 24, a.dumpJ, (size_t)L.pitch * 24, (size_t)L.gw * 24, L.gh, hipMemcpyDeviceToHost, c->stream));
+  if (r_out) HIPCHK(c, hipMemcpy2DAsync(r_out, (size_t)L.gw * 4, a.dumpR, (size_t)L.pitch * 4, (size_t)L.gw * 4, L.gh, hipMemcpyDeviceToHost, c->stream));
+  if (valid_out) HIPCHK(c, hipMemcpy2DAsync(valid_out, (size_t)L.gw, a.dumpV, (size_t)L.pitch, (size_t)L.gw, L.gh, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memset(acc_out, 0, sizeof(*acc_out));
   for (int s = 0; s < a.slices; s++) {  // same slice-ordered f64 fold as k_gn_update
@@ -1705,7 +1751,8 @@ int uwt_residual_jacobian_weighted(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slo
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_residual_jacobian_weighted: context uses the nearest/identity fast path");
   int st = upload_pairs(c, 1, &ref_slot, &tgt_slot);
   if (st) return st;
-  const size_t n = c->lv[lvl].n;
+  const LevelK& L = c->lv[lvl];
+  const size_t n = L.ng;   // see uwt_residual_jacobian
   st = ensure_scratch(c, n * (6 * 4 + 4 + 4 + 1) + 512);
   if (st) return st;
   Pose P;
@@ -1727,10 +1774,10 @@ int uwt_residual_jacobian_weighted(uwt_ctx* c, int32_t ref_slot, int32_t tgt_slo
   std::memset(&sc, 0, sizeof(sc));
   sc.inv_mad = 1.f;
   if (c->p.weights) HIPCHK(c, hipMemcpyAsync(&sc, c->scale, sizeof(sc), hipMemcpyDeviceToHost, c->stream));
-  if (J_out) HIPCHK(c, hipMemcpyAsync(J_out, a.dumpJ, n * 24, hipMemcpyDeviceToHost, c->stream));
-  if (r_out) HIPCHK(c, hipMemcpyAsync(r_out, a.dumpR, n * 4, hipMemcpyDeviceToHost, c->stream));
-  if (w_out) HIPCHK(c, hipMemcpyAsync(w_out, a.dumpW, n * 4, hipMemcpyDeviceToHost, c->stream));
-  if (valid_out) HIPCHK(c, hipMemcpyAsync(valid_out, a.dumpV, n, hipMemcpyDeviceToHost, c->stream));
+  if (J_out) HIPCHK(c, hipMemcpy2DAsync(J_out, (size_t)L.gw * 24, a.dumpJ, (size_t)L.pitch * 24, (size_t)L.gw * 24, L.gh, hipMemcpyDeviceToHost, c->stream));
+  if (r_out) HIPCHK(c, hipMemcpy2DAsync(r_out, (size_t)L.gw * 4, a.dumpR, (size_t)L.pitch * 4, (size_t)L.gw * 4, L.gh, hipMemcpyDeviceToHost, c->stream));
+  if (w_out) HIPCHK(c, hipMemcpy2DAsync(w_out, (size_t)L.gw * 4, a.dumpW, (size_t)L.pitch * 4, (size_t)L.gw * 4, L.gh, hipMemcpyDeviceToHost, c->stream));
+  if (valid_out) HIPCHK(c, hipMemcpy2DAsync(valid_out, (size_t)L.gw, a.dumpV, (size_t)L.pitch, (size_t)L.gw, L.gh, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   std::memset(acc_out, 0, sizeof(*acc_out));
   double err = 0.0;
@@ -1930,7 +1977,7 @@ static int mag_to_scratch(uwt_ctx* c, int slot, int lvl, uint8_t** d_mag, unsign
   HIPCHK(c, hipMemsetAsync(*d_sum, 0, 8, c->stream));
   const int blocks = (int)std::min<size_t>(1024, (n + kBlock - 1) / kBlock);
   hipLaunchKernelGGL(k_grad_mag, dim3(blocks), dim3(kBlock), 0, c->stream, c->gx[lvl] + slot * n, c->gy[lvl] + slot * n, (int)n,
-                     *d_mag, *d_sum);
+                     c->lv[lvl].pitch, c->lv[lvl].iw, *d_mag, *d_sum);
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
 }
@@ -1966,7 +2013,8 @@ int uwt_gradient_magnitude(uwt_ctx* c, int32_t slot, int32_t lvl, uint8_t* mag_o
   unsigned long long* d_sum;
   int st = mag_to_scratch(c, slot, lvl, &d_mag, &d_sum);
   if (st) return st;
-  HIPCHK(c, hipMemcpyAsync(mag_out, d_mag, c->lv[lvl].n, hipMemcpyDeviceToHost, c->stream));
+  const LevelK& L = c->lv[lvl];   // gradient_[lvl]: the level's image, img_w x img_h
+  HIPCHK(c, hipMemcpy2DAsync(mag_out, L.iw, d_mag, L.pitch, L.iw, L.ih, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
 }
@@ -1977,9 +2025,10 @@ int uwt_obtain_candidate_points_batch(uwt_ctx* c, int32_t first_slot, int32_t n_
   if (!c || !counts_out || cap < 0 || (cap > 0 && !pts_out) || n_frames < 1 || !slot_range_ok(c, first_slot, n_frames) || lvl < 0 ||
       lvl >= c->p.n_levels)
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_obtain_candidate_points_batch");
-  const int w = c->lv[lvl].w, h = c->lv[lvl].h;
-  const size_t n = c->lv[lvl].n;
-  const int kcap = (int)std::min<size_t>((size_t)cap, n);
+  const LevelK& L = c->lv[lvl];
+  const int w = L.gw, h = L.gh;   // the point grid the reference's loops walk (src/Tracker.cpp:1334-1335)
+  const size_t n = L.n;
+  const int kcap = (int)std::min<size_t>((size_t)cap, (size_t)w * h);
   // row bands: enough blocks for a lone frame to spread over the chip, a few rows per thread at least
   const int col_blocks = (w + kBlock - 1) / kBlock;
   int bands = std::max(1, std::min(h / 8, 512 / std::max(1, col_blocks * n_frames)));
@@ -2002,14 +2051,14 @@ int uwt_obtain_candidate_points_batch(uwt_ctx* c, int32_t first_slot, int32_t n_
   const uint16_t* d_depth = c->p.has_depth ? c->depth[lvl] : nullptr;
   HIPCHK(c, hipMemsetAsync(d_sums, 0, 8 * (size_t)n_frames, c->stream));
   const int mag_blocks = (int)std::min<size_t>(256, (n + kBlock - 1) / kBlock);
-  hipLaunchKernelGGL(k_grad_mag_batch, dim3(mag_blocks, n_frames), dim3(kBlock), 0, c->stream, c->gx[lvl], c->gy[lvl], (int)n, first_slot,
-                     d_mag, d_sums);
+  hipLaunchKernelGGL(k_grad_mag_batch, dim3(mag_blocks, n_frames), dim3(kBlock), 0, c->stream, c->gx[lvl], c->gy[lvl], (int)n, L.pitch,
+                     L.iw, first_slot, d_mag, d_sums);
   const dim3 grid(col_blocks, bands, n_frames);
-  hipLaunchKernelGGL(k_candidates_batch<false>, grid, dim3(kBlock), 0, c->stream, d_mag, d_depth, first_slot, w, h, bands, d_sums, threshold,
-                     d_cnt, (const int*)nullptr, (float4*)nullptr, 0);
+  hipLaunchKernelGGL(k_candidates_batch<false>, grid, dim3(kBlock), 0, c->stream, d_mag, d_depth, first_slot, L.pitch, L.iw, L.ih, w, h, bands,
+                     d_sums, threshold, d_cnt, (const int*)nullptr, (float4*)nullptr, 0);
   hipLaunchKernelGGL(k_scan_counts, dim3(n_frames), dim3(1024), 0, c->stream, d_cnt, (int)m, d_off, d_tot);
-  hipLaunchKernelGGL(k_candidates_batch<true>, grid, dim3(kBlock), 0, c->stream, d_mag, d_depth, first_slot, w, h, bands, d_sums, threshold,
-                     (int*)nullptr, d_off, d_out, kcap);
+  hipLaunchKernelGGL(k_candidates_batch<true>, grid, dim3(kBlock), 0, c->stream, d_mag, d_depth, first_slot, L.pitch, L.iw, L.ih, w, h, bands,
+                     d_sums, threshold, (int*)nullptr, d_off, d_out, kcap);
   HIPCHK(c, hipGetLastError());
   HIPCHK(c, hipMemcpyAsync(counts_out, d_tot, 4 * (size_t)n_frames, hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -2033,7 +2082,7 @@ int uwt_obtain_patch_points(uwt_ctx* c, int32_t slot, const float* kp, int32_t n
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !count_out || n_kp < 0 || (n_kp > 0 && !kp) || cap < 0 || (cap > 0 && !pts_out) || !slot_range_ok(c, slot, 1))
     return fail(c, UWT_ERR_INVALID_ARG, "uwt_obtain_patch_points");
-  const int w = c->lv[0].w, h = c->lv[0].h;
+  const int w = c->lv[0].gw, h = c->lv[0].gh;   // level 0: grid = image
   for (int i = 0; i < std::min(n_kp, 200); i++)
     if (!(kp[2 * i] >= 0.f && kp[2 * i] < (float)w && kp[2 * i + 1] >= 0.f && kp[2 * i + 1] < (float)h))
       return fail(c, UWT_ERR_INVALID_ARG, "uwt_obtain_patch_points: key point outside the image");
@@ -2046,7 +2095,7 @@ int uwt_obtain_patch_points(uwt_ctx* c, int32_t slot, const float* kp, int32_t n
   int* d_cnt = (int*)c->scratch;
   if (nk) HIPCHK(c, hipMemcpyAsync(d_kp, kp, (size_t)nk * 8, hipMemcpyHostToDevice, c->stream));
   hipLaunchKernelGGL(k_patch_points, dim3(1), dim3(256), 0, c->stream, d_kp, nk,
-                     c->p.has_depth ? c->depth[0] + (size_t)slot * c->lv[0].n : nullptr, w, h, d_out, kcap, d_cnt);
+                     c->p.has_depth ? c->depth[0] + (size_t)slot * c->lv[0].n : nullptr, c->lv[0].pitch, w, h, d_out, kcap, d_cnt);
   HIPCHK(c, hipGetLastError());
   int cnt = 0;
   HIPCHK(c, hipMemcpyAsync(&cnt, d_cnt, 4, hipMemcpyDeviceToHost, c->stream));
@@ -2074,7 +2123,7 @@ int uwt_add_patch_points(uwt_ctx* c, int32_t lvl, const float* pts, int32_t n_pt
   float4* d_in = (float4*)((uint8_t*)c->scratch + 4096);
   float4* d_out = (float4*)((uint8_t*)c->scratch + 4096 + in_bytes);
   if (n_pts) HIPCHK(c, hipMemcpyAsync(d_in, pts, in_bytes, hipMemcpyHostToDevice, c->stream));
-  hipLaunchKernelGGL(k_add_patch_points, dim3(1), dim3(256), 0, c->stream, d_in, n_pts, c->lv[lvl].w, c->lv[lvl].h, start, d_out, cap,
+  hipLaunchKernelGGL(k_add_patch_points, dim3(1), dim3(256), 0, c->stream, d_in, n_pts, c->lv[lvl].gw, c->lv[lvl].gh, start, d_out, cap,
                      d_cnt);
   HIPCHK(c, hipGetLastError());
   int cnt = 0;
@@ -2178,11 +2227,11 @@ void init_undistort_maps(const double K[4], const double k[4], const double newK
     if ((expr) != hipSuccess) return UWT_ERR_HIP;  \
   } while (0)
 
-int ingest_remap(uwt_ingest* g, const uint8_t* raw, size_t stride, int x0, int y0, int cw, int ch, uint8_t* d_dst) {
+int ingest_remap(uwt_ingest* g, const uint8_t* raw, size_t stride, int x0, int y0, int cw, int ch, uint8_t* d_dst, int dst_pitch) {
   ING_CHK(hipSetDevice(g->device));
   ING_CHK(hipMemcpy2DAsync(g->d_raw, g->in_w, raw, stride, g->in_w, g->in_h, hipMemcpyHostToDevice, g->stream));
   hipLaunchKernelGGL(k_remap_crop, dim3((cw * ch + kBlock - 1) / kBlock), dim3(kBlock), 0, g->stream, g->d_raw, g->in_w,
-                     g->in_h, (size_t)g->in_w, g->d_map1, g->d_map2, g->out_w, x0, y0, d_dst, cw, ch);
+                     g->in_h, (size_t)g->in_w, g->d_map1, g->d_map2, g->out_w, x0, y0, d_dst, cw, ch, dst_pitch);
   ING_CHK(hipGetLastError());
   return UWT_OK;
 }
@@ -2242,7 +2291,7 @@ int uwt_ingest_maps(uwt_ingest* g, int16_t* map1_out, uint16_t* map2_out) {
 
 int uwt_ingest_undistort(uwt_ingest* g, const uint8_t* raw, size_t stride, uint8_t* und_out) {
   if (!g || !raw || !und_out || stride < (size_t)g->in_w) return UWT_ERR_INVALID_ARG;
-  int st = ingest_remap(g, raw, stride, 0, 0, g->out_w, g->out_h, g->d_und);
+  int st = ingest_remap(g, raw, stride, 0, 0, g->out_w, g->out_h, g->d_und, g->out_w);
   if (st) return st;
   ING_CHK(hipMemcpyAsync(und_out, g->d_und, (size_t)g->out_w * g->out_h, hipMemcpyDeviceToHost, g->stream));
   ING_CHK(hipStreamSynchronize(g->stream));
@@ -2280,7 +2329,7 @@ int uwt_ingest_frame(uwt_ingest* g, uwt_ctx* c, int32_t slot, const uint8_t* raw
   if (st) return st;
   st = dep_wait(c, c->fresh, c->fresh_next, c->fresh_dropped, g->stream, slot, 1);
   if (st) return st;
-  st = ingest_remap(g, raw, stride, x0, y0, cw, ch, c->img[0] + (size_t)slot * cw * ch);
+  st = ingest_remap(g, raw, stride, x0, y0, cw, ch, c->img[0] + (size_t)slot * c->lv[0].n, c->lv[0].pitch);
   if (st) return st;
   ING_CHK(hipStreamSynchronize(g->stream));
   return UWT_OK;

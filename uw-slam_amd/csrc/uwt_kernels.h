@@ -52,12 +52,25 @@ constexpr int kMaxSlices = 160;  // slices per pair and level at most (a 1280x96
 //                 formed and multiplied.  Cheaper, and not what OpenCV computes; kept selectable.
 constexpr int kArithOpenCV = 0, kArithLegacy = 1;
 
+// One pyramid level.  Three sizes (equal whenever the level-0 size is divisible by 2^lvl and the row is whole groups of four):
+//   image   iw x ih   images_[lvl].cols / rows: the cv::resize(.., 0.5, 0.5) chain of src/System.cpp:246-251 (cvRound per level).
+//                     What the bounds test of src/Tracker.cpp:450 reads ("image2.rows / .cols"), what Scharr runs over, what a
+//                     sample index is clamped to.
+//   grid    gw x gh   w_[lvl] x h_[lvl] = size >> lvl (src/Tracker.cpp:312-313): the points ObtainAllPoints walks (:1267-1268).
+//                     gw <= iw, gh <= ih (733 wide: level 3 is 92 wide, its grid 91).
+//   pitch             elements per plane row in memory: iw rounded up to a multiple of 4, so that every row starts on a vector
+//                     boundary whatever the size.  A level's pixels are walked by ONE linear index over pitch x gh positions
+//                     (index = y * pitch + x = the plane offset); positions with x >= gw carry no point and are masked out.
 struct LevelK {
-  int w, h, n;
+  int pitch;
+  int iw, ih;
+  int gw, gh;
+  int n;            // elements per frame slot of a level plane: pitch * ih
+  int ng;           // length of the linear walk: pitch * gh (a multiple of 4)
   float fx, fy, cx, cy, invfx, invfy;
   float bx, by;     // (float)(-(double)cx * (double)invfx), likewise y: beta of the folded unprojection (kArithOpenCV)
   float zscale;     // depth_scale / 2^lvl (src/Tracker.cpp:1266)
-  uint32_t magic;   // ceil(2^32 / w): idx / w == umulhi(idx, magic) for idx * w < 2^32
+  uint32_t magic;   // ceil(2^32 / pitch): idx / pitch == umulhi(idx, magic) for idx * pitch < 2^32
 };
 
 struct PairState {
@@ -72,10 +85,12 @@ struct PairState {
 
 // ------------------------------------------------------------------------------------------------------------
 // pyramid: 2x2 mean with round-half-up == cv::resize(.., 0.5, 0.5) on u8 / u16 (src/System.cpp:247, 249)
-// One thread produces VEC horizontally adjacent outputs from two 2·VEC-wide input row segments.
+// One thread produces VEC horizontally adjacent outputs from two 2·VEC-wide input row segments.  Whole cells only: a source of
+// 2 w_out x 2 h_out pixels (k_resize_half takes every other size).  Rows of src_pitch / dst_pitch elements.
 // ------------------------------------------------------------------------------------------------------------
 template <typename T, int VEC>
 __global__ __launch_bounds__(kBlock) void k_halve(const T* __restrict__ src, T* __restrict__ dst, int w_out, int h_out,
+                                                  int src_pitch, int dst_pitch,
                                                   size_t src_frame_stride, size_t dst_frame_stride,
                                                   const int* __restrict__ slots, int first_slot) {
   const size_t frame = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;  // src / dst point at slot 0
@@ -84,9 +99,9 @@ __global__ __launch_bounds__(kBlock) void k_halve(const T* __restrict__ src, T* 
   if (g >= groups_per_row * h_out) return;
   const int y = g / groups_per_row;
   const int x = (g - y * groups_per_row) * VEC;
-  const T* s0 = src + frame * src_frame_stride + (size_t)(2 * y) * (2 * w_out) + 2 * x;
-  const T* s1 = s0 + 2 * w_out;
-  T* d = dst + frame * dst_frame_stride + (size_t)y * w_out + x;
+  const T* s0 = src + frame * src_frame_stride + (size_t)(2 * y) * src_pitch + 2 * x;
+  const T* s1 = s0 + src_pitch;
+  T* d = dst + frame * dst_frame_stride + (size_t)y * dst_pitch + x;
   T a[2 * VEC], b[2 * VEC], o[VEC];
   if constexpr (VEC == 4 && sizeof(T) == 1) {
     *reinterpret_cast<uint2*>(a) = *reinterpret_cast<const uint2*>(s0);
@@ -111,16 +126,80 @@ __global__ __launch_bounds__(kBlock) void k_halve(const T* __restrict__ src, T* 
   }
 }
 
+// cv::resize(src, dst, Size(), 0.5, 0.5) for ANY source size (src/System.cpp:247, 249 on the ROI-cropped frames of :148-191,
+// :232-236): dst is cvRound(sw / 2) x cvRound(sh / 2) (half to even: 733 -> 366, 735 -> 368).  OpenCV's resizeAreaFast for
+// scale 2 x 2: whole cells (a + b + c + d + 2) >> 2; where 2 dw > sw the last column holds half cells, where 2 dh > sh the
+// last row does — and resizeAreaFast sends EVERY cell of such a row, and the half cells of the others, through its generic
+// tail: the mean of the source pixels that exist, saturate_cast<T>((float)sum / count) = round half to EVEN (a + b = 5 -> 2,
+// the whole cells' rule would give 3).  A thread makes four adjacent outputs; the pad columns of the pitched row get zeros.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_resize_half(const T* __restrict__ src, T* __restrict__ dst, int sw, int sh, int src_pitch,
+                                                        int dw, int dh, int dst_pitch, size_t src_frame_stride,
+                                                        size_t dst_frame_stride, const int* __restrict__ slots, int first_slot) {
+  const size_t frame = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;
+  const int groups_per_row = dst_pitch >> 2;
+  const int g = blockIdx.x * kBlock + threadIdx.x;
+  if (g >= groups_per_row * dh) return;
+  const int y = g / groups_per_row;
+  const int x = (g - y * groups_per_row) * 4;
+  const int fw = sw >> 1, fh = sh >> 1;   // columns / rows of whole cells
+  const int r0 = 2 * y, r1 = min(2 * y + 1, sh - 1);
+  const T* s0 = src + frame * src_frame_stride + (size_t)r0 * src_pitch;
+  const T* s1 = src + frame * src_frame_stride + (size_t)r1 * src_pitch;
+  uint32_t a[8], b[8];
+  if (2 * x + 8 <= src_pitch) {   // the eight source columns lie inside the pitched row (pad columns included: never used)
+    T va[8], vb[8];
+    if constexpr (sizeof(T) == 1) {
+      *reinterpret_cast<uint2*>(va) = *reinterpret_cast<const uint2*>(s0 + 2 * x);
+      *reinterpret_cast<uint2*>(vb) = *reinterpret_cast<const uint2*>(s1 + 2 * x);
+    } else {
+      *reinterpret_cast<uint4*>(va) = *reinterpret_cast<const uint4*>(s0 + 2 * x);
+      *reinterpret_cast<uint4*>(vb) = *reinterpret_cast<const uint4*>(s1 + 2 * x);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { a[i] = va[i]; b[i] = vb[i]; }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int cx = min(2 * x + i, sw - 1);
+      a[i] = s0[cx];
+      b[i] = s1[cx];
+    }
+  }
+  T o[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int xo = x + i;
+    uint32_t v = 0;
+    if (y < fh && xo < fw) {
+      v = (a[2 * i] + a[2 * i + 1] + b[2 * i] + b[2 * i + 1] + 2u) >> 2;
+    } else if (xo < dw) {   // a cell of the partial last row, or the half cell of the last column
+      const bool two_cols = 2 * xo + 1 < sw, two_rows = y < fh;
+      uint32_t sum = a[2 * i];
+      int count = 1;
+      if (two_cols) { sum += a[2 * i + 1]; count++; }
+      if (two_rows) { sum += b[2 * i]; count++; if (two_cols) { sum += b[2 * i + 1]; count++; } }
+      v = (uint32_t)(int)rintf((float)sum / (float)count);   // cvRound: half to even
+    }
+    o[i] = (T)v;
+  }
+  T* d = dst + frame * dst_frame_stride + (size_t)y * dst_pitch + x;
+  if constexpr (sizeof(T) == 1) *reinterpret_cast<uint32_t*>(d) = *reinterpret_cast<uint32_t*>(o);
+  else *reinterpret_cast<uint2*>(d) = *reinterpret_cast<uint2*>(o);
+}
+
 // The whole pyramid of a frame in one launch (a frame or a few on their own: the live per-frame sequence, where a launch
 // per level and plane is all latency).  The 2x2 mean is tile-local, so a block takes a 64x64 tile of level 0 down every
 // level: a thread reads its 4x4 patch, keeps levels 1 and 2 in registers, levels 3.. go through LDS (16x16 -> 8x8 -> ..).
-// Needs 3 <= n_levels <= 7 and level-0 sizes divisible by 4 (by 2^(n_levels-1) anyway); same integers as k_halve.
+// Needs 3 <= n_levels <= 7 and level-0 sizes divisible by 2^(n_levels-1) (whole cells on every level) and by 4; same integers
+// as k_halve.  Rows of pitch[l] elements.
 constexpr int kPyrMaxLevels = 7;
 template <typename T>
 struct PyramidArgs {
   const T* src;                 // level 0, slot 0
   T* dst[kPyrMaxLevels];        // dst[l]: level l, slot 0 (dst[0] unused)
-  size_t stride[kPyrMaxLevels]; // pixels per frame at level l
+  size_t stride[kPyrMaxLevels]; // elements per frame at level l
+  int pitch[kPyrMaxLevels];     // elements per row at level l
   int w, h;                     // level 0
   int n_levels;
   const int* slots;
@@ -138,12 +217,12 @@ __global__ __launch_bounds__(kBlock) void k_pyramid_all(const PyramidArgs<T> a) 
   uint32_t p2 = 0;
   if (x < a.w && y < a.h) {
     uint32_t px[4][4];
-    const T* s = a.src + frame * a.stride[0] + (size_t)y * a.w + x;
+    const T* s = a.src + frame * a.stride[0] + (size_t)y * a.pitch[0] + x;
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       T row[4];
-      if constexpr (sizeof(T) == 1) *reinterpret_cast<uint32_t*>(row) = *reinterpret_cast<const uint32_t*>(s + (size_t)r * a.w);
-      else *reinterpret_cast<uint2*>(row) = *reinterpret_cast<const uint2*>(s + (size_t)r * a.w);
+      if constexpr (sizeof(T) == 1) *reinterpret_cast<uint32_t*>(row) = *reinterpret_cast<const uint32_t*>(s + (size_t)r * a.pitch[0]);
+      else *reinterpret_cast<uint2*>(row) = *reinterpret_cast<const uint2*>(s + (size_t)r * a.pitch[0]);
 #pragma unroll
       for (int c = 0; c < 4; c++) px[r][c] = row[c];
     }
@@ -152,7 +231,7 @@ __global__ __launch_bounds__(kBlock) void k_pyramid_all(const PyramidArgs<T> a) 
     for (int r = 0; r < 2; r++)
 #pragma unroll
       for (int c = 0; c < 2; c++) p1[r][c] = (px[2 * r][2 * c] + px[2 * r][2 * c + 1] + px[2 * r + 1][2 * c] + px[2 * r + 1][2 * c + 1] + 2u) >> 2;
-    const int w1 = a.w >> 1;
+    const int w1 = a.pitch[1];
     T* d1 = a.dst[1] + frame * a.stride[1] + (size_t)(y >> 1) * w1 + (x >> 1);
 #pragma unroll
     for (int r = 0; r < 2; r++) {
@@ -161,7 +240,7 @@ __global__ __launch_bounds__(kBlock) void k_pyramid_all(const PyramidArgs<T> a) 
       else *reinterpret_cast<uint32_t*>(d1 + (size_t)r * w1) = *reinterpret_cast<uint32_t*>(o);
     }
     p2 = (p1[0][0] + p1[0][1] + p1[1][0] + p1[1][1] + 2u) >> 2;
-    a.dst[2][frame * a.stride[2] + (size_t)(y >> 2) * (a.w >> 2) + (x >> 2)] = (T)p2;
+    a.dst[2][frame * a.stride[2] + (size_t)(y >> 2) * a.pitch[2] + (x >> 2)] = (T)p2;
   }
   if (a.n_levels <= 3) return;   // block-uniform
   lv[0][ty][tx] = p2;
@@ -176,7 +255,7 @@ __global__ __launch_bounds__(kBlock) void k_pyramid_all(const PyramidArgs<T> a) 
       const uint32_t v = (lv[b][2 * ty][2 * tx] + lv[b][2 * ty][2 * tx + 1] + lv[b][2 * ty + 1][2 * tx] + lv[b][2 * ty + 1][2 * tx + 1] + 2u) >> 2;
       lv[b ^ 1][ty][tx] = v;
       const int ex = txb * side + tx, ey = tyb * side + ty, wl = a.w >> l, hl = a.h >> l;
-      if (ex < wl && ey < hl) a.dst[l][frame * a.stride[l] + (size_t)ey * wl + ex] = (T)v;
+      if (ex < wl && ey < hl) a.dst[l][frame * a.stride[l] + (size_t)ey * a.pitch[l] + ex] = (T)v;
     }
   }
 }
@@ -192,7 +271,8 @@ template <typename T>
 struct PyramidBatchArgs {
   const T* src;     // level 0, slot 0
   T* dst[3];        // levels 1, 2, 3, slot 0
-  size_t stride[4]; // pixels per frame at levels 0..3
+  size_t stride[4]; // elements per frame at levels 0..3
+  int pitch[4];     // elements per row at levels 0..3 (pitch[0] == w: the level-0 width is a multiple of 16)
   int w, h;         // level 0
   const int* slots;
   int first_slot;
@@ -224,7 +304,7 @@ __global__ __launch_bounds__(kBlock) void k_pyramid_batch(const PyramidBatchArgs
 #pragma unroll
     for (int i = 0; i < 8; i++) p1[i] = ((uint32_t)r0[2 * i] + (uint32_t)r0[2 * i + 1] + (uint32_t)r1[2 * i] + (uint32_t)r1[2 * i + 1] + 2u) >> 2;
   }
-  const int w1 = a.w >> 1, w2 = a.w >> 2, w3 = a.w >> 3;
+  const int w1 = a.pitch[1], w2 = a.pitch[2], w3 = a.pitch[3];
   if (in) {
     T o[8];
 #pragma unroll
@@ -279,7 +359,7 @@ __device__ inline int reflect101(int i, int n) {
 
 // one 64x16 output tile (`tile_id` of frame `frame`); lds: (kGradTH + 2) x (kGradTW + 4) bytes
 __device__ __forceinline__ void scharr_tile_scalar(unsigned char* __restrict__ lds, const uint8_t* __restrict__ src,
-                                                   int16_t* __restrict__ gx, int16_t* __restrict__ gy, int w, int h,
+                                                   int16_t* __restrict__ gx, int16_t* __restrict__ gy, int w, int h, int pitch,
                                                    size_t frame_stride, size_t frame, int tile_id) {
   uint8_t(*tile)[kGradTW + 4] = reinterpret_cast<uint8_t(*)[kGradTW + 4]>(lds);
   const int tiles_x = (w + kGradTW - 1) / kGradTW;
@@ -289,7 +369,7 @@ __device__ __forceinline__ void scharr_tile_scalar(unsigned char* __restrict__ l
   for (int i = threadIdx.x; i < (kGradTH + 2) * (kGradTW + 2); i += kBlock) {
     const int ly = i / (kGradTW + 2), lx = i - ly * (kGradTW + 2);
     const int sy = reflect101(min(y0 + ly - 1, h), h), sx = reflect101(min(x0 + lx - 1, w), w);
-    tile[ly][lx] = img[(size_t)sy * w + sx];
+    tile[ly][lx] = img[(size_t)sy * pitch + sx];
   }
   __syncthreads();
   const int lx = threadIdx.x & (kGradTW - 1);
@@ -303,7 +383,7 @@ __device__ __forceinline__ void scharr_tile_scalar(unsigned char* __restrict__ l
       const int g = tile[ly + 2][lx], hh = tile[ly + 2][lx + 1], k = tile[ly + 2][lx + 2];
       const int sx = 3 * (3 * (c - a) + 10 * (f - d) + 3 * (k - g));
       const int sy = 3 * (3 * (g - a) + 10 * (hh - b) + 3 * (k - c));
-      const size_t o = frame * frame_stride + (size_t)y * w + x;
+      const size_t o = frame * frame_stride + (size_t)y * pitch + x;
       gx[o] = (int16_t)sx;  // |s| <= 48*255*... = 12240 < 32767: never saturates
       gy[o] = (int16_t)sy;
     }
@@ -312,11 +392,11 @@ __device__ __forceinline__ void scharr_tile_scalar(unsigned char* __restrict__ l
 
 // (src / gx / gy point at slot 0; the frames processed are slots[0..gridDim.y) if given, else first_slot..)
 static __global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
-                                                           int16_t* __restrict__ gy, int w, int h, size_t frame_stride,
+                                                           int16_t* __restrict__ gy, int w, int h, int pitch, size_t frame_stride,
                                                            const int* __restrict__ slots, int first_slot) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[(kGradTH + 2) * (kGradTW + 4)];
   const size_t frame = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;
-  scharr_tile_scalar(lds, src, gx, gy, w, h, frame_stride, frame, (int)blockIdx.x);
+  scharr_tile_scalar(lds, src, gx, gy, w, h, pitch, frame_stride, frame, (int)blockIdx.x);
 }
 
 // Vector variant for level widths that are multiples of 4: a 128 x (8·RPT) output tile per block, the source patch (tile
@@ -331,7 +411,7 @@ constexpr int kGradVW = 128, kGradVRows = 8;  // columns per tile; thread rows p
 constexpr int scharr_v4_lds_rows(int rpt) { return (kGradVRows * rpt + 2 + kGradVRows - 1) / kGradVRows * kGradVRows; }
 template <int RPT>
 __device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, const uint8_t* __restrict__ src,
-                                               int16_t* __restrict__ gx, int16_t* __restrict__ gy, int w, int h,
+                                               int16_t* __restrict__ gx, int16_t* __restrict__ gy, int w, int h, int pitch,
                                                size_t frame_stride, int slot, int tile_id) {
   constexpr int TH = kGradVRows * RPT, WPR = kGradVW / 4;
   uint32_t(*tile)[WPR + 2] = reinterpret_cast<uint32_t(*)[WPR + 2]>(lds);  // word 0: left halo in its top byte; word 33: right halo in its low byte
@@ -355,11 +435,11 @@ __device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, 
 #pragma unroll
   for (int i = 0; i < kStage; i++) {
     const int r = min(ly + kGradVRows * i, rows - 1);
-    staged[i] = *reinterpret_cast<const uint32_t*>(img + (__umul24((unsigned)reflect_row(y0 + r - 1), (unsigned)w) + colb));
+    staged[i] = *reinterpret_cast<const uint32_t*>(img + (__umul24((unsigned)reflect_row(y0 + r - 1), (unsigned)pitch) + colb));
   }
   // the two halo bytes of a patch row (threads 0 .. 2·rows-1 keep theirs), requested behind the words
   const int hr = min((int)threadIdx.x >> 1, rows - 1), side = threadIdx.x & 1;
-  const uint32_t halo = img[__umul24((unsigned)reflect_row(y0 + hr - 1), (unsigned)w) + (unsigned)reflect101(side ? x0 + tw : x0 - 1, w)];
+  const uint32_t halo = img[__umul24((unsigned)reflect_row(y0 + hr - 1), (unsigned)pitch) + (unsigned)reflect101(side ? x0 + tw : x0 - 1, w)];
   if (4 * c < tw) {   // (rows past the patch hold a clamped row's words: never read)
 #pragma unroll
     for (int i = 0; i < kStage; i++) {
@@ -401,7 +481,7 @@ __device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, 
   };
   auto out_rows = [&](auto whole) {   // whole: every row of the tile is inside the image (no per-row test)
     RowTerms r0 = row_terms(ly * RPT), r1 = row_terms(ly * RPT + 1);
-    uint32_t o = 2u * (__umul24((unsigned)yb, (unsigned)w) + (unsigned)x);   // byte offset inside the frame's plane
+    uint32_t o = 2u * (__umul24((unsigned)yb, (unsigned)pitch) + (unsigned)x);   // byte offset inside the frame's plane
 #pragma unroll
     for (int k = 0; k < RPT; k++) {
       if (decltype(whole)::value || yb + k < h) {
@@ -412,7 +492,7 @@ __device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, 
         const s2v gy23 = (r2.s23 - r0.s23) * (short)3;
         *reinterpret_cast<uint2*>(gxf + o) = make_uint2(__builtin_bit_cast(uint32_t, gx01), __builtin_bit_cast(uint32_t, gx23));
         *reinterpret_cast<uint2*>(gyf + o) = make_uint2(__builtin_bit_cast(uint32_t, gy01), __builtin_bit_cast(uint32_t, gy23));
-        o += 2u * (unsigned)w;
+        o += 2u * (unsigned)pitch;
         r0 = r1;
         r1 = r2;
       }
@@ -424,7 +504,7 @@ __device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, 
 
 template <int RPT>
 __global__ __launch_bounds__(kBlock) void k_scharr3_v4(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
-                                                       int16_t* __restrict__ gy, int w, int h, size_t frame_stride,
+                                                       int16_t* __restrict__ gy, int w, int h, int pitch, size_t frame_stride,
                                                        const int* __restrict__ slots, int first_slot) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[scharr_v4_lds_rows(RPT) * (kGradVW / 4 + 2) * 4];
   // XCD-aware order of the tiles: blocks are dealt round-robin over the 8 XCDs (b and b + 8 share one, each XCD has its own
@@ -437,7 +517,7 @@ __global__ __launch_bounds__(kBlock) void k_scharr3_v4(const uint8_t* __restrict
   const unsigned t = xcd * q + min(xcd, r) + (b >> 3);   // XCD x owns q + (x < r) consecutive tiles
   const unsigned fy = t / gridDim.x, tile = t - fy * gridDim.x;
   const int slot = slots ? slots[fy] : first_slot + (int)fy;
-  scharr_tile_v4<RPT>(lds, src, gx, gy, w, h, frame_stride, slot, (int)tile);
+  scharr_tile_v4<RPT>(lds, src, gx, gy, w, h, pitch, frame_stride, slot, (int)tile);
 }
 
 // The gradients of every level of a frame (or a few) in one launch: block -> (level, tile) through the levels' tile
@@ -447,7 +527,7 @@ struct GradLevelsArgs {
   const uint8_t* src[kGradMaxLevels];
   int16_t* gx[kGradMaxLevels];
   int16_t* gy[kGradMaxLevels];
-  int w[kGradMaxLevels], h[kGradMaxLevels];
+  int w[kGradMaxLevels], h[kGradMaxLevels], pitch[kGradMaxLevels];   // the level's image size and its row pitch
   size_t stride[kGradMaxLevels];
   int tile_end[kGradMaxLevels];   // running sum of the levels' tile counts
   int n_levels;
@@ -463,15 +543,15 @@ static __global__ __launch_bounds__(kBlock) void k_scharr3_levels(const GradLeve
   // the level's parameters by selects over the (by-value) table: an indexed read would go through scratch memory
   const uint8_t* src = a.src[0];
   int16_t *gx = a.gx[0], *gy = a.gy[0];
-  int w = a.w[0], h = a.h[0], tile0 = 0;
+  int w = a.w[0], h = a.h[0], pitch = a.pitch[0], tile0 = 0;
   size_t stride = a.stride[0];
 #pragma unroll
   for (int l = 1; l < kGradMaxLevels; l++)
     if (l < a.n_levels && b >= a.tile_end[l - 1]) {
-      src = a.src[l]; gx = a.gx[l]; gy = a.gy[l]; w = a.w[l]; h = a.h[l]; stride = a.stride[l]; tile0 = a.tile_end[l - 1];
+      src = a.src[l]; gx = a.gx[l]; gy = a.gy[l]; w = a.w[l]; h = a.h[l]; pitch = a.pitch[l]; stride = a.stride[l]; tile0 = a.tile_end[l - 1];
     }
-  if (w % 4 == 0) scharr_tile_v4<1>(lds, src, gx, gy, w, h, stride, slot, b - tile0);
-  else scharr_tile_scalar(lds, src, gx, gy, w, h, stride, (size_t)slot, b - tile0);
+  if (w % 4 == 0) scharr_tile_v4<1>(lds, src, gx, gy, w, h, pitch, stride, slot, b - tile0);
+  else scharr_tile_scalar(lds, src, gx, gy, w, h, pitch, stride, (size_t)slot, b - tile0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -649,8 +729,8 @@ __device__ __forceinline__ void pixel_warp_raw(const LevelK& L, const WarpK& K, 
 #pragma unroll
   for (int c = 0; c < lanes<F>::n; c++) {
     const float uc = get(x2, c), vc = get(y2, c);
-    okm[c] = okin_mask[c] & __builtin_amdgcn_fcmpf(vc, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(vc, (float)L.h, kFcmpOLT) &
-             __builtin_amdgcn_fcmpf(uc, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(uc, (float)L.w, kFcmpOLT);
+    okm[c] = okin_mask[c] & __builtin_amdgcn_fcmpf(vc, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(vc, (float)L.ih, kFcmpOLT) &
+             __builtin_amdgcn_fcmpf(uc, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(uc, (float)L.iw, kFcmpOLT);
   }
 }
 // 1b: sanitise invalid pixels, clamp a negative reciprocal: "if (inv_z2 < 0) inv_z2 = 0" (:452-453)
@@ -670,9 +750,9 @@ __device__ __forceinline__ void pixel_gather_index(const LevelK& L, F x2, F y2, 
 #pragma unroll
   for (int c = 0; c < lanes<F>::n; c++) {
     int ix2 = round_pos(get(x2, c)), iy2 = round_pos(get(y2, c));
-    ix2 = min(ix2, L.w - 1);  // the reference reads one past the edge here (:450, :472); clamp
-    iy2 = min(iy2, L.h - 1);
-    gidx[c] = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;  // 24-bit multiply-add: one op (dims < 2^24)
+    ix2 = min(ix2, L.iw - 1);  // the reference reads one past the edge here (:450, :472); clamp
+    iy2 = min(iy2, L.ih - 1);
+    gidx[c] = __umul24((unsigned)iy2, (unsigned)L.pitch) + (unsigned)ix2;  // 24-bit multiply-add: one op (dims < 2^24)
   }
 }
 template <int AR, typename F>
@@ -1084,10 +1164,10 @@ __device__ __forceinline__ float sample_bilinear(const uint8_t* __restrict__ I2,
   int ix0, iy0;   // (the instruction saturates and maps NaN to 0; a C++ conversion of such a value would be undefined)
   asm("v_cvt_i32_f32 %0, %1" : "=v"(ix0) : "v"(x0));
   asm("v_cvt_i32_f32 %0, %1" : "=v"(iy0) : "v"(y0));
-  asm("v_med3_i32 %0, %0, 0, %1" : "+v"(ix0) : "s"(L.w - 1));
-  asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy0) : "s"(L.h - 1));
-  const int ix1 = min(ix0 + 1, L.w - 1), iy1 = min(iy0 + 1, L.h - 1);
-  const uint32_t r0 = __umul24((unsigned)iy0, (unsigned)L.w), r1 = __umul24((unsigned)iy1, (unsigned)L.w);
+  asm("v_med3_i32 %0, %0, 0, %1" : "+v"(ix0) : "s"(L.iw - 1));
+  asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy0) : "s"(L.ih - 1));
+  const int ix1 = min(ix0 + 1, L.iw - 1), iy1 = min(iy0 + 1, L.ih - 1);
+  const uint32_t r0 = __umul24((unsigned)iy0, (unsigned)L.pitch), r1 = __umul24((unsigned)iy1, (unsigned)L.pitch);
   const float a = (float)I2[r0 + (unsigned)ix0], b = (float)I2[r0 + (unsigned)ix1];
   const float c = (float)I2[r1 + (unsigned)ix0], d = (float)I2[r1 + (unsigned)ix1];
   const float top = __builtin_fmaf(ax, b - a, a);
@@ -1359,7 +1439,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 template <int VEC, bool DEPTH, bool COMPUTE_ONLY>
 __device__ __forceinline__ void load_first_group(RefGroup<VEC>& rg, const ResidualArgs& a, int ref_slot, int slice) {
   const size_t ref_off = (size_t)ref_slot * a.L.n;
-  const int n_groups = a.L.n / VEC;
+  const int n_groups = a.L.ng / VEC;
   const int g = slice * a.groups_per_block + (int)threadIdx.x;
   load_group<VEC, DEPTH, COMPUTE_ONLY>(rg, a.img + ref_off, a.gx + ref_off, a.gy + ref_off, DEPTH ? a.depth + ref_off : nullptr,
                                        (uint32_t)min(g, n_groups - 1) * VEC);
@@ -1446,7 +1526,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     __syncthreads();
   }
 
-  const int n_groups = L.n / VEC;
+  const int n_groups = L.ng / VEC;
   const int g_begin = slice * a_groups_per_block;
   const int g_end = min(g_begin + a_groups_per_block, n_groups);
   const int iters = (g_end - g_begin + kBlock - 1) / kBlock;  // block-uniform trip count
@@ -1480,9 +1560,9 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
   // of the level run on with coordinates outside the image; they are inactive and every term of theirs is discarded.
   const uint32_t idx0 = (uint32_t)g * VEC;
   const uint32_t y0 = __umulhi(idx0, L.magic);
-  float yf = (float)y0, xf0 = (float)(idx0 - y0 * (uint32_t)L.w);
+  float yf = (float)y0, xf0 = (float)(idx0 - y0 * (uint32_t)L.pitch);
   const uint32_t step_y = __umulhi((uint32_t)(kBlock * VEC), L.magic);
-  const float step_yf = (float)step_y, step_xf = (float)((uint32_t)(kBlock * VEC) - step_y * (uint32_t)L.w), wf = (float)L.w;
+  const float step_yf = (float)step_y, step_xf = (float)((uint32_t)(kBlock * VEC) - step_y * (uint32_t)L.pitch), wf = (float)L.pitch;
   // Pixels are processed in units of N adjacent ones (N = 2: the packed-f32 form, see v2f above), all VEC pixels of the
   // group in flight through four phases: warp + validity + gather index, gather, Jacobian, residual + accumulation.
   constexpr int N = (VEC % 2 == 0) ? 2 : 1;
@@ -1519,6 +1599,8 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
       for (int c = 0; c < N; c++) {
         const int j = u * N + c;
         okin[c] = active_mask;
+        // the pixel-by-pixel form walks any level: positions of the pitched row beyond the point grid (x >= gw) carry no point
+        if constexpr (VEC == 1) okin[c] &= __builtin_amdgcn_fcmpf(xf0, (float)L.gw, kFcmpOLT);
         dlow[c] = 1.0f;
         if constexpr (DEPTH && TYPED) {
           const float d = rg.dp4[j];              // the same signed 16-bit value, converted by the load
@@ -1547,8 +1629,8 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
             const float uc = get(x2[u], c), vc = get(y2[u], c);
             float lo;
             asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(uc), "v"(vc), "v"(dlow[c]));
-            okm[u * N + c] = okin[c] & __builtin_amdgcn_fcmpf(lo, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(vc, (float)L.h, kFcmpOLT) &
-                             __builtin_amdgcn_fcmpf(uc, (float)L.w, kFcmpOLT);
+            okm[u * N + c] = okin[c] & __builtin_amdgcn_fcmpf(lo, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(vc, (float)L.ih, kFcmpOLT) &
+                             __builtin_amdgcn_fcmpf(uc, (float)L.iw, kFcmpOLT);
           }
         } else {
           pixel_warp_raw<AR, F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N]);
@@ -1560,9 +1642,9 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
           put(iz[u], c, r);
           int ix2 = round_pos(get(x2[u], c)), iy2 = round_pos(get(y2[u], c));
           // x2, y2 are not sanitised here: clamp both ways, in one instruction (the compiler keeps min and max apart)
-          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(ix2) : "s"(L.w - 1));
-          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy2) : "s"(L.h - 1));
-          gidx[u * N + c] = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;
+          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(ix2) : "s"(L.iw - 1));
+          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy2) : "s"(L.ih - 1));
+          gidx[u * N + c] = __umul24((unsigned)iy2, (unsigned)L.pitch) + (unsigned)ix2;
         }
       } else {
         pixel_warp<AR, F>(L, K, xf, bc<F>(yf), z, okin, x2[u], y2[u], iz[u], &okm[u * N], &gidx[u * N]);
@@ -1771,7 +1853,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
       n_valid_wave += (uint32_t)__builtin_popcountll(okm[j]);  // scalar
       if constexpr (DUMP) {
         if (active) {
-          const size_t p = (size_t)pair * L.n + idx + j;
+          const size_t p = (size_t)pair * L.ng + idx + j;
           if (a.dumpV) a.dumpV[p] = lane_bit(okm[j]) ? 1 : 0;
           if (a.dumpR) a.dumpR[p] = (float)ri;
           if (a.dumpJ)
@@ -1869,12 +1951,12 @@ template <int AR, bool DEPTH>
 __device__ __forceinline__ bool general_pixel(const LevelK& L, const WarpK& K, int sampler,
                                               const uint8_t* I1, const uint8_t* I2, const uint16_t* DP, uint32_t idx,
                                               float& x2, float& y2, float& iz, float& rf) {
-  const uint32_t y = __umulhi(idx, L.magic), x = idx - y * L.w;
+  const uint32_t y = __umulhi(idx, L.magic), x = idx - y * (uint32_t)L.pitch;
   float z = 1.0f;
-  bool ok = true;
+  bool ok = x < (uint32_t)L.gw;   // positions of the pitched row beyond the point grid carry no point
   if constexpr (DEPTH) {
     const int d = (int)(int16_t)DP[idx];
-    ok = d > 0;
+    ok = ok && d > 0;
     z = (float)d * L.zscale;
   }
   uint32_t gidx;
@@ -1903,7 +1985,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist(const ResidualArgs a, con
   const uint8_t* I1 = a.img + ref_off;
   const uint8_t* I2 = a.img + tgt_off;
   const uint16_t* DP = DEPTH ? a.depth + ref_off : nullptr;
-  const int p_begin = blockIdx.x * a.groups_per_block, p_end = min(p_begin + a.groups_per_block, L.n);
+  const int p_begin = blockIdx.x * a.groups_per_block, p_end = min(p_begin + a.groups_per_block, L.ng);
   for (int p = p_begin + (int)threadIdx.x; p < p_end; p += kBlock) {
     float x2, y2, iz, rf;
     if (!general_pixel<AR, DEPTH>(L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf)) continue;
@@ -2068,7 +2150,7 @@ __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, con
   load_planes(g_begin + (int)threadIdx.x);
   for (int g = g_begin + (int)threadIdx.x; g < g_end; g += kBlock) {
     const uint32_t idx = (uint32_t)g * VEC;
-    const uint32_t y = __umulhi(idx, L.magic), x = idx - y * L.w;
+    const uint32_t y = __umulhi(idx, L.magic), x = idx - y * (uint32_t)L.pitch;
     uint8_t i1[VEC];
     uint16_t dp[VEC];
 #pragma unroll
@@ -2088,6 +2170,7 @@ __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, con
       for (int c = 0; c < N; c++) {
         const int j = u * N + c;
         okin_m[c] = ~0ull;
+        if constexpr (VEC == 1) okin_m[c] = __builtin_amdgcn_fcmpf((float)x, (float)L.gw, kFcmpOLT);   // beyond the point grid: no point
         dlow[c] = 1.0f;
         if constexpr (DEPTH) {
           const int d = (int)(int16_t)dp[j];
@@ -2106,7 +2189,8 @@ __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, con
           const float uc = get(x2u, c), vc = get(y2u, c);
           float lo;
           asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(uc), "v"(vc), "v"(dlow[c]));
-          okm[c] = __builtin_amdgcn_fcmpf(lo, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(vc, (float)L.h, kFcmpOLT) & __builtin_amdgcn_fcmpf(uc, (float)L.w, kFcmpOLT);
+          okm[c] = __builtin_amdgcn_fcmpf(lo, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(vc, (float)L.ih, kFcmpOLT) & __builtin_amdgcn_fcmpf(uc, (float)L.iw, kFcmpOLT);
+          if constexpr (VEC == 1) okm[c] &= okin_m[c];
         }
       } else {
         pixel_warp_raw<AR, F>(L, K, xf, bc<F>((float)y), z, okin_m, x2u, y2u, izu, okm);
@@ -2117,9 +2201,9 @@ __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, con
 #pragma unroll
         for (int c = 0; c < N; c++) {
           int ix2 = round_pos(get(x2u, c)), iy2 = round_pos(get(y2u, c));
-          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(ix2) : "s"(L.w - 1));
-          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy2) : "s"(L.h - 1));
-          gidx[u * N + c] = __umul24((unsigned)iy2, (unsigned)L.w) + (unsigned)ix2;
+          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(ix2) : "s"(L.iw - 1));
+          asm("v_med3_i32 %0, %0, 0, %1" : "+v"(iy2) : "s"(L.ih - 1));
+          gidx[u * N + c] = __umul24((unsigned)iy2, (unsigned)L.pitch) + (unsigned)ix2;
         }
       }   // (bilinear: sample_bilinear clamps its four addresses both ways; nothing to prepare)
 #pragma unroll
@@ -2187,7 +2271,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
   const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
   // bin q of this thread's replica: myh[q * kHistRep]
   unsigned int* myh = h + 255 * kHistRep + (threadIdx.x & (kHistRep - 1));
-  const int n_groups = L.n / VEC;
+  const int n_groups = L.ng / VEC;
   const int g_begin = blockIdx.x * a.groups_per_block, g_end = min(g_begin + a.groups_per_block, n_groups);
   hist_groups<AR, VEC, DEPTH, SAMPLER>(L, K, I1, I2, DP, myh, g_begin, g_end, n_groups);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the masked ds_add_u32 above are the asm's own: the compiler does not count them
@@ -2248,7 +2332,7 @@ __global__ __launch_bounds__(kBlock) void k_residual_general(const ResidualArgs 
   for (int i = 0; i < kAccFloats; i++) acc[i] = 0.0;
   double err = 0.0;
   uint32_t sum_r2 = 0, n_valid = 0;
-  const int p_begin = blockIdx.x * a.groups_per_block, p_end = min(p_begin + a.groups_per_block, L.n);
+  const int p_begin = blockIdx.x * a.groups_per_block, p_end = min(p_begin + a.groups_per_block, L.ng);
   for (int p = p_begin + (int)threadIdx.x; p < p_end; p += kBlock) {
     float x2, y2, iz, rf;
     const bool ok = general_pixel<AR, DEPTH>(L, K, ga.sampler, I1, I2, DP, (uint32_t)p, x2, y2, iz, rf);
@@ -2277,11 +2361,11 @@ __global__ __launch_bounds__(kBlock) void k_residual_general(const ResidualArgs 
       sum_r2 += (uint32_t)(q * q);
       n_valid += 1;
     }
-    if (a.dumpV) a.dumpV[(size_t)pair * L.n + p] = ok ? 1 : 0;
-    if (a.dumpR) a.dumpR[(size_t)pair * L.n + p] = ok ? rf : 0.f;
+    if (a.dumpV) a.dumpV[(size_t)pair * L.ng + p] = ok ? 1 : 0;
+    if (a.dumpR) a.dumpR[(size_t)pair * L.ng + p] = ok ? rf : 0.f;
     if (a.dumpJ)
-      for (int k = 0; k < 6; k++) a.dumpJ[((size_t)pair * L.n + p) * 6 + k] = ok ? J[k] : 0.f;
-    if (a.dumpW) a.dumpW[(size_t)pair * L.n + p] = ok ? w : 0.f;
+      for (int k = 0; k < 6; k++) a.dumpJ[((size_t)pair * L.ng + p) * 6 + k] = ok ? J[k] : 0.f;
+    if (a.dumpW) a.dumpW[(size_t)pair * L.ng + p] = ok ? w : 0.f;
   }
   block_reduce_store<double, true>(acc, sum_r2, n_valid, a.partials + ((size_t)pair * a.slices + blockIdx.x) * kRecWords, err);
 }
@@ -2653,9 +2737,9 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
   for (int li = 0; li < NLEV; li++) {
     if (li >= ca.n_levels) break;   // block-uniform
     const ResidualArgs& a = ca.lv[li];   // read in place (the kernel-argument segment); what differs travels in `ov`
-    const bool v4 = VECSEL == 4 || (VECSEL == 0 && a.L.w % 4 == 0);   // block-uniform
+    const bool v4 = VECSEL == 4 || (VECSEL == 0 && a.L.gw == a.L.pitch);   // block-uniform
     CoreOverride ov;
-    ov.groups_per_block = ((a.L.n / (v4 ? 4 : 1) + kBlock - 1) / kBlock) * kBlock;   // the whole level
+    ov.groups_per_block = ((a.L.ng / (v4 ? 4 : 1) + kBlock - 1) / kBlock) * kBlock;   // the whole level
     ov.rec = rec;
     UpdateArgs u = ca.u;
     u.slices = 1;
@@ -2724,7 +2808,7 @@ __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca)
     if (li >= ca.n_levels) break;   // block-uniform
     const ResidualArgs& a = ca.lv[li];
     const LevelK L = a.L;
-    const int n_groups = L.n / VEC;
+    const int n_groups = L.ng / VEC;
     CoreOverride ov;
     ov.groups_per_block = ((n_groups + kBlock - 1) / kBlock) * kBlock;   // the whole level
     ov.rec = rec;
@@ -2996,18 +3080,18 @@ __global__ __launch_bounds__(kBlock) void k_residual_points(const ResidualArgs a
     float y2 = o[1] * L.fy; y2 = y2 / o[2]; y2 = y2 + L.cy; y2 = y2 * wq;
     const float z2 = o[2];
     float iz = 1.0f / z2;
-    bool ok = (y2 > 0.f) && (y2 < (float)L.h) && (x2 > 0.f) && (x2 < (float)L.w) && (z2 != 0.f);
+    bool ok = (y2 > 0.f) && (y2 < (float)L.ih) && (x2 > 0.f) && (x2 < (float)L.iw) && (z2 != 0.f);
     const int ix1 = (int)P.x, iy1 = (int)P.y;
-    ok = ok && ix1 >= 0 && ix1 < L.w && iy1 >= 0 && iy1 < L.h;  // the reference would read out of bounds
+    ok = ok && ix1 >= 0 && ix1 < L.iw && iy1 >= 0 && iy1 < L.ih;  // the reference would read out of bounds
     float J[6];
     int ri = 0;
     if (ok) {
       if (iz < 0.f) iz = 0.f;
-      const uint32_t i1x = (uint32_t)(iy1 * L.w + ix1);
+      const uint32_t i1x = (uint32_t)(iy1 * L.pitch + ix1);
       int ix2 = round_pos(x2), iy2 = round_pos(y2);
-      ix2 = min(ix2, L.w - 1);
-      iy2 = min(iy2, L.h - 1);
-      ri = (int)I2[iy2 * L.w + ix2] - (int)I1[i1x];
+      ix2 = min(ix2, L.iw - 1);
+      iy2 = min(iy2, L.ih - 1);
+      ri = (int)I2[iy2 * L.pitch + ix2] - (int)I1[i1x];
       pixel_jacobian<AR, UNIT_FACTORS, false, DUMP>(L, a.zf, a.af, x2, y2, iz, (float)GX[i1x], (float)GY[i1x], J);
       accumulate(acc, J, ri);
       sum_r2 += (uint32_t)(ri * ri);
@@ -3036,22 +3120,22 @@ __device__ __forceinline__ bool general_point(const LevelK& L, const float* T, i
   y2 = o[1] * L.fy; y2 = y2 / o[2]; y2 = y2 + L.cy; y2 = y2 * wq;
   const float z2 = o[2];
   iz = 1.0f / z2;
-  bool ok = (y2 > 0.f) && (y2 < (float)L.h) && (x2 > 0.f) && (x2 < (float)L.w) && (z2 != 0.f);
+  bool ok = (y2 > 0.f) && (y2 < (float)L.ih) && (x2 > 0.f) && (x2 < (float)L.iw) && (z2 != 0.f);
   const int ix1 = (int)P.x, iy1 = (int)P.y;
-  ok = ok && ix1 >= 0 && ix1 < L.w && iy1 >= 0 && iy1 < L.h;  // the reference would read out of bounds
+  ok = ok && ix1 >= 0 && ix1 < L.iw && iy1 >= 0 && iy1 < L.ih;  // the reference would read out of bounds
   rf = 0.f;
   i1x = 0;
   if (!ok) return false;
   if (iz < 0.f) iz = 0.f;
-  i1x = (uint32_t)(iy1 * L.w + ix1);
+  i1x = (uint32_t)(iy1 * L.pitch + ix1);
   const int i1 = I1[i1x];
   if (sampler) {
     rf = sample_bilinear(I2, L, x2, y2) - (float)i1;
   } else {
     int ix2 = round_pos(x2), iy2 = round_pos(y2);
-    ix2 = min(ix2, L.w - 1);
-    iy2 = min(iy2, L.h - 1);
-    rf = (float)((int)I2[iy2 * L.w + ix2] - i1);
+    ix2 = min(ix2, L.iw - 1);
+    iy2 = min(iy2, L.ih - 1);
+    rf = (float)((int)I2[iy2 * L.pitch + ix2] - i1);
   }
   return true;
 }
@@ -3136,8 +3220,11 @@ __global__ __launch_bounds__(kBlock) void k_points_general(const ResidualArgs a,
 
 // gradient_ = addWeighted(convertScaleAbs(gx), 0.5, convertScaleAbs(gy), 0.5) (src/Tracker.cpp:1139-1142), u8,
 // plus its integer sum for cuda::meanStdDev (:1325).  (a + b)/2 with cvRound's round-half-to-even.
+// n = pitch * ih plane elements, laid out like the gradient planes; the sum runs over the image's iw columns alone (the pad
+// columns of a pitched row hold nothing of the image).
 static __global__ __launch_bounds__(kBlock) void k_grad_mag(const int16_t* __restrict__ gx, const int16_t* __restrict__ gy, int n,
-                                                     uint8_t* __restrict__ mag, unsigned long long* __restrict__ sum) {
+                                                     int pitch, int iw, uint8_t* __restrict__ mag,
+                                                     unsigned long long* __restrict__ sum) {
   unsigned int local = 0;
   for (int i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) {
     const int ax = min(abs((int)gx[i]), 255), ay = min(abs((int)gy[i]), 255);
@@ -3145,7 +3232,7 @@ static __global__ __launch_bounds__(kBlock) void k_grad_mag(const int16_t* __res
     int m = s >> 1;
     if (s & 1) m += (m & 1);
     mag[i] = (uint8_t)m;
-    local += (unsigned int)m;
+    if (i % pitch < iw) local += (unsigned int)m;
   }
   __shared__ unsigned int red[kBlock];
   red[threadIdx.x] = local;
@@ -3160,7 +3247,7 @@ static __global__ __launch_bounds__(kBlock) void k_grad_mag(const int16_t* __res
 // Tracker::ObtainCandidatePoints (src/Tracker.cpp:1314-1362) for a batch of frames, many blocks per frame, three passes:
 // gradient_ and its per-frame sum: grid (blocks, frames)
 static __global__ __launch_bounds__(kBlock) void k_grad_mag_batch(const int16_t* __restrict__ gx, const int16_t* __restrict__ gy, int n,
-                                                           int first_slot, uint8_t* __restrict__ mag,
+                                                           int pitch, int iw, int first_slot, uint8_t* __restrict__ mag,
                                                            unsigned long long* __restrict__ sums) {
   const int f = blockIdx.y;
   const size_t src = (size_t)(first_slot + f) * n, dst = (size_t)f * n;
@@ -3171,7 +3258,7 @@ static __global__ __launch_bounds__(kBlock) void k_grad_mag_batch(const int16_t*
     int m = s >> 1;
     if (s & 1) m += (m & 1);
     mag[dst + i] = (uint8_t)m;
-    local += (unsigned int)m;
+    if (i % pitch < iw) local += (unsigned int)m;
   }
   __shared__ unsigned int red[kBlock];
   red[threadIdx.x] = local;
@@ -3190,24 +3277,26 @@ static __global__ __launch_bounds__(kBlock) void k_grad_mag_batch(const int16_t*
 // reference's order, x outer, y inner (src/Tracker.cpp:1334-1335).
 template <bool WRITE>
 __global__ __launch_bounds__(kBlock) void k_candidates_batch(const uint8_t* __restrict__ mag, const uint16_t* __restrict__ depth,
-                                                             int first_slot, int w, int h, int bands,
+                                                             int first_slot, int pitch, int iw, int ih, int w, int h, int bands,
                                                              const unsigned long long* __restrict__ sums, double threshold,
                                                              int* __restrict__ counts, const int* __restrict__ offsets,
                                                              float4* __restrict__ out, int cap) {
+  // w x h: the level's point grid (w_[lvl] x h_[lvl], the loops of :1334-1335); iw x ih: its image (the mean of :1324 runs over
+  // the whole gradient_ Mat); rows of `pitch` elements
   const int f = blockIdx.z, band = blockIdx.y, x = blockIdx.x * kBlock + threadIdx.x;
   if (x >= w) return;
-  const size_t n = (size_t)w * h;
-  const double thres = (double)sums[f] / (double)n + threshold;  // cuda::meanStdDev mean + GRADIENT_THRESHOLD (:1325-1327)
+  const size_t n = (size_t)pitch * ih;
+  const double thres = (double)sums[f] / (double)((size_t)iw * ih) + threshold;  // cuda::meanStdDev mean + GRADIENT_THRESHOLD (:1325-1327)
   const uint8_t* m = mag + (size_t)f * n;
   const uint16_t* dp = depth ? depth + (size_t)(first_slot + f) * n : nullptr;
   const int rows = (h + bands - 1) / bands, y0 = band * rows, y1 = min(y0 + rows, h);
   int k = WRITE ? offsets[(size_t)f * w * bands + (size_t)x * bands + band] : 0;
   float4* o = WRITE ? out + (size_t)f * cap : nullptr;
   for (int y = y0; y < y1; y++) {
-    if (!((double)m[(size_t)y * w + x] > thres)) continue;
+    if (!((double)m[(size_t)y * pitch + x] > thres)) continue;
     float z = 1.0f;
     if (dp) {  // the reference indexes the 16-bit plane through at<uchar> (:1339, :1344): byte x of row y
-      const uint8_t b = reinterpret_cast<const uint8_t*>(dp + (size_t)y * w)[x];
+      const uint8_t b = reinterpret_cast<const uint8_t*>(dp + (size_t)y * pitch)[x];
       if (b == 0) continue;
       z = (float)b * 0.0002f;
     }
@@ -3246,7 +3335,7 @@ static __global__ __launch_bounds__(1024) void k_scan_counts(const int* __restri
 // ("patch_size_ - 1 / 2" = 5), x-major inside a patch, key points in order.  One thread per key point counts, a
 // serial prefix orders, the thread then writes its patch.
 static __global__ __launch_bounds__(256) void k_patch_points(const float2* __restrict__ kp, int n_kp, const uint16_t* __restrict__ depth0,
-                                                      int w, int h, float4* __restrict__ out, int cap, int* __restrict__ count) {
+                                                      int pitch, int w, int h, float4* __restrict__ out, int cap, int* __restrict__ count) {
   __shared__ int cnt[256];
   const int q = threadIdx.x;
   const int start_point = 5;
@@ -3255,7 +3344,7 @@ static __global__ __launch_bounds__(256) void k_patch_points(const float2* __res
   if (live) {
     x = kp[q].x; y = kp[q].y;
     if (depth0) {
-      const int d = (int)(int16_t)depth0[(size_t)(int)y * w + (int)x];  // at<short>(y, x) != 0 (:1202)
+      const int d = (int)(int16_t)depth0[(size_t)(int)y * pitch + (int)x];  // at<short>(y, x) != 0 (:1202)
       if (d == 0) live = false;
       z = (float)d * 0.0002f * 1.0f;                                      // * factor_depth * factor_lvl (:1204)
     }
@@ -3336,7 +3425,7 @@ static __global__ __launch_bounds__(256) void k_add_patch_points(const float4* _
 // ------------------------------------------------------------------------------------------------------------
 static __global__ __launch_bounds__(kBlock) void k_remap_crop(const uint8_t* __restrict__ src, int sw, int sh, size_t s_stride,
                                                        const short2* __restrict__ map1, const uint16_t* __restrict__ map2,
-                                                       int mw, int x0, int y0, uint8_t* __restrict__ dst, int cw, int ch) {
+                                                       int mw, int x0, int y0, uint8_t* __restrict__ dst, int cw, int ch, int dst_pitch) {
   const int q = blockIdx.x * kBlock + threadIdx.x;
   if (q >= cw * ch) return;
   const int oy = q / cw, ox = q - oy * cw;
@@ -3352,7 +3441,7 @@ static __global__ __launch_bounds__(kBlock) void k_remap_crop(const uint8_t* __r
   const int p10 = (xin0 && yin1) ? src[(size_t)(sy + 1) * s_stride + sx] : 0;
   const int p11 = (xin1 && yin1) ? src[(size_t)(sy + 1) * s_stride + sx + 1] : 0;
   const int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
-  dst[(size_t)oy * cw + ox] = (uint8_t)min(v, 255);
+  dst[(size_t)oy * dst_pitch + ox] = (uint8_t)min(v, 255);
 }
 
 // Visualizer::UpdateMessages pose accumulation (src/Visualizer.cpp:304-325): final_i = final_{i-1} * SE3(q_i, s·t_i).
