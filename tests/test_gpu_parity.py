@@ -454,8 +454,9 @@ def test_identical_frames_identity_and_status_codes(capi, synth):
     with pytest.raises(capi.UwtError) as e:
         ctx.estimate_pose_batch([0, 0], [1, 1])    # exceeds max_pairs
     assert e.value.status == capi.ERR_CAPACITY
+    capi.Context(capi.default_params(100, 96, *MID)).close()   # any size is a frame size (round 6: 100 / 50 / 25 / 12 / 6 wide) ...
     with pytest.raises(capi.UwtError):
-        capi.Context(capi.default_params(100, 96, *MID))  # width not divisible by 2^(levels-1)
+        capi.Context(capi.default_params(12, 96, *MID))   # ... as long as the coarsest level has a point grid: 12 >> 4 = 0
 
 
 # ------------------------------------------------------------------ full size (BASELINE configs): properties

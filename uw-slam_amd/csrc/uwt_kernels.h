@@ -716,7 +716,7 @@ __device__ __forceinline__ int keep_i(int x, unsigned long long mask) {
 // The reference's fifth condition, z2 != 0 (:451), needs no compare of its own: a zero z2 makes the reciprocal infinite,
 // refined_rcp turns that into NaN (0 * inf), x2 and y2 come out NaN and fail x2 > 0 — exactly as the IEEE quotient by
 // zero (infinite or NaN) fails one of the reference's four bounds tests before z2 != 0 is looked at.
-constexpr int kFcmpOGT = 2, kFcmpOLT = 4, kFcmpUGE = 11, kFcmpUNE = 14, kIcmpSGT = 38, kIcmpSLT = 40;
+constexpr int kFcmpOGT = 2, kFcmpOLT = 4, kFcmpUGE = 11, kFcmpUNE = 14, kIcmpULT = 36, kIcmpSGT = 38, kIcmpSLT = 40;
 __device__ __forceinline__ bool lane_bit(unsigned long long mask) { return (mask >> (threadIdx.x & 63u)) & 1ull; }
 
 // 1a: warp and validity masks; x2, y2, iz come back raw (possibly NaN / out of range where the mask is clear)
@@ -1590,6 +1590,22 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     F x2[NU], y2[NU], iz[NU];
     unsigned long long okm[VEC];  // validity as a wave mask (SGPR pair)
     uint32_t gidx[VEC];
+    // Which pixels of the group are points of the level's grid.  A level whose grid rows are whole groups of four (gw == pitch)
+    // has no other position; elsewhere — every level of a frame size that is not a multiple of 2^(levels-1) x 4, src/System.cpp:
+    // 148-191 — the last group of a row holds positions x >= gw of the pitched row, which carry no point (src/Tracker.cpp:
+    // 1267-1268 walks x < w_[lvl]).  Groups start at multiples of four, so pixel j of a group is a point iff x0 < gw - (gw & 3)
+    // ("every pixel of the group is") or j < (gw & 3) and x0 < gw ("the row's last, partial group"): two compares per group under
+    // a block-uniform branch, nothing where the level is whole.
+    unsigned long long colm[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; j++) colm[j] = active_mask;
+    if (L.gw != L.pitch) {
+      const unsigned long long m_in = active_mask & __builtin_amdgcn_fcmpf(xf0, (float)L.gw, kFcmpOLT);
+      const unsigned long long m_all = active_mask & __builtin_amdgcn_fcmpf(xf0, (float)(L.gw & ~3), kFcmpOLT);
+      const int rem = L.gw & 3;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) colm[j] = (VEC == 1 || j < rem) ? m_in : m_all;
+    }
 #pragma unroll
     for (int u = 0; u < NU; u++) {
       F z = bc<F>(1.0f), xf;
@@ -1598,9 +1614,7 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 #pragma unroll
       for (int c = 0; c < N; c++) {
         const int j = u * N + c;
-        okin[c] = active_mask;
-        // the pixel-by-pixel form walks any level: positions of the pitched row beyond the point grid (x >= gw) carry no point
-        if constexpr (VEC == 1) okin[c] &= __builtin_amdgcn_fcmpf(xf0, (float)L.gw, kFcmpOLT);
+        okin[c] = colm[j];
         dlow[c] = 1.0f;
         if constexpr (DEPTH && TYPED) {
           const float d = rg.dp4[j];              // the same signed 16-bit value, converted by the load
@@ -2161,6 +2175,16 @@ __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, con
     float x2[VEC], y2[VEC];
     unsigned long long okv[VEC];
     uint32_t gidx[VEC];
+    unsigned long long colm[VEC];   // the grid points of the group (see residual_core): all of them where the level is whole
+#pragma unroll
+    for (int j = 0; j < VEC; j++) colm[j] = ~0ull;
+    if (L.gw != L.pitch) {
+      const unsigned long long m_in = __builtin_amdgcn_uicmp(x, (uint32_t)L.gw, kIcmpULT);
+      const unsigned long long m_all = __builtin_amdgcn_uicmp(x, (uint32_t)(L.gw & ~3), kIcmpULT);
+      const int rem = L.gw & 3;
+#pragma unroll
+      for (int j = 0; j < VEC; j++) colm[j] = (VEC == 1 || j < rem) ? m_in : m_all;
+    }
 #pragma unroll
     for (int u = 0; u < VEC / N; u++) {
       F z = bc<F>(1.0f), xf, x2u, y2u, izu;
@@ -2169,8 +2193,7 @@ __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, con
 #pragma unroll
       for (int c = 0; c < N; c++) {
         const int j = u * N + c;
-        okin_m[c] = ~0ull;
-        if constexpr (VEC == 1) okin_m[c] = __builtin_amdgcn_fcmpf((float)x, (float)L.gw, kFcmpOLT);   // beyond the point grid: no point
+        okin_m[c] = colm[j];
         dlow[c] = 1.0f;
         if constexpr (DEPTH) {
           const int d = (int)(int16_t)dp[j];
@@ -2190,7 +2213,7 @@ __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, con
           float lo;
           asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(uc), "v"(vc), "v"(dlow[c]));
           okm[c] = __builtin_amdgcn_fcmpf(lo, 0.f, kFcmpOGT) & __builtin_amdgcn_fcmpf(vc, (float)L.ih, kFcmpOLT) & __builtin_amdgcn_fcmpf(uc, (float)L.iw, kFcmpOLT);
-          if constexpr (VEC == 1) okm[c] &= okin_m[c];
+          okm[c] &= okin_m[c];
         }
       } else {
         pixel_warp_raw<AR, F>(L, K, xf, bc<F>((float)y), z, okin_m, x2u, y2u, izu, okm);

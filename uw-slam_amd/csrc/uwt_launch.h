@@ -15,10 +15,9 @@ struct LaunchSel {
   bool compute_only;   // the diagnostic twin (uwt_profile_enable bit 2)
 };
 
-// pixels per vector group at a level: 4 where every position of the pitched row is a grid point (the grid's rows are whole groups
-// of four), else 1 — the pixel-by-pixel form masks the positions beyond the grid (the coarsest levels of sizes like 736 x 480 x 5:
-// 46 wide in rows of 48; every level of an odd-sized frame)
-inline int level_vec(const LevelK& L) { return L.gw == L.pitch ? 4 : 1; }
+// pixels per vector group at a level: 4 — a level's rows are pitched to whole groups of four, and the kernels mask the positions
+// of a row's last group that lie beyond the point grid (residual_core: colm)
+inline int level_vec(const LevelK&) { return 4; }
 inline bool level_plain(const ResidualArgs& a) { return a.zf == 1.0f && a.af == 1.0f && a.L.fx == a.L.fy; }
 
 // k_residual, identity weights / nearest sampler (and the per-stage dump form)
