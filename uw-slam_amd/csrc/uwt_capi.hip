@@ -23,7 +23,7 @@ struct uwt_ctx {
   uwt_params p;
   uwt_level info[UWT_MAX_LEVELS];
   LevelK lv[UWT_MAX_LEVELS];
-  int vecl[UWT_MAX_LEVELS];             // pixels per vector group at each level (level_vec: 4 where the grid's rows are whole groups of four, else 1)
+  int vecl[UWT_MAX_LEVELS];             // pixels per vector group at each level: 4 (rows are pitched to whole groups of four)
   bool whole = true;                    // the level-0 size is divisible by 2^(n_levels-1): every level's image is its grid, every cell of
                                         // the resize chain whole (the one-launch pyramid forms apply)
   int slices[UWT_MAX_LEVELS];
@@ -274,19 +274,14 @@ int launch_scharr(uwt_ctx* c, const uint8_t* src, int16_t* gx, int16_t* gy, int 
                   const int* d_slots = nullptr, int first_slot = 0, hipStream_t on = nullptr) {
   if (n_frames == 0) return UWT_OK;
   hipStream_t stream = on ? on : c->stream;
-  if (w % 4 == 0) {
-    if (h >= 8 * kGradVRows) {  // four rows per thread on the tall levels
-      const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + 4 * kGradVRows - 1) / (4 * kGradVRows));
-      hipLaunchKernelGGL(k_scharr3_v4<4>, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, pitch, fs, d_slots,
-                         first_slot);
-    } else {
-      const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + kGradVRows - 1) / kGradVRows);
-      hipLaunchKernelGGL(k_scharr3_v4<1>, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, pitch, fs, d_slots,
-                         first_slot);
-    }
+  if (h >= 8 * kGradVRows) {  // four rows per thread on the tall levels
+    const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + 4 * kGradVRows - 1) / (4 * kGradVRows));
+    hipLaunchKernelGGL(k_scharr3_v4<4>, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, pitch, fs, d_slots,
+                       first_slot);
   } else {
-    const int tiles = ((w + kGradTW - 1) / kGradTW) * ((h + kGradTH - 1) / kGradTH);
-    hipLaunchKernelGGL(k_scharr3, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, pitch, fs, d_slots, first_slot);
+    const int tiles = ((w + kGradVW - 1) / kGradVW) * ((h + kGradVRows - 1) / kGradVRows);
+    hipLaunchKernelGGL(k_scharr3_v4<1>, dim3(tiles, n_frames), dim3(kBlock), 0, stream, src, gx, gy, w, h, pitch, fs, d_slots,
+                       first_slot);
   }
   HIPCHK(c, hipGetLastError());
   return UWT_OK;
@@ -998,7 +993,7 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   c->tn = default_tuning();
   size_t max_slices = 1;
   for (int l = 0; l < p->n_levels; l++) {
-    c->vecl[l] = level_vec(c->lv[l]);   // per level: only the levels whose rows are not whole groups of four go pixel by pixel
+    c->vecl[l] = 4;
     const int n_groups = c->lv[l].ng / c->vecl[l];
     const int gpt = std::max(kGroupsPerThread, (n_groups + kMaxSlices * kBlock - 1) / (kMaxSlices * kBlock));
     c->groups_per_block[l] = kBlock * gpt;
@@ -1344,8 +1339,7 @@ static int enqueue_gradients(uwt_ctx* c, int first_slot, int n, const int* d_slo
     for (int l = 0; l < c->p.n_levels; l++) {
       a.src[l] = c->img[l]; a.gx[l] = c->gx[l]; a.gy[l] = c->gy[l];
       a.w[l] = c->lv[l].iw; a.h[l] = c->lv[l].ih; a.pitch[l] = c->lv[l].pitch; a.stride[l] = c->lv[l].n;
-      tiles += a.w[l] % 4 == 0 ? ((a.w[l] + kGradVW - 1) / kGradVW) * ((a.h[l] + kGradVRows - 1) / kGradVRows)
-                               : ((a.w[l] + kGradTW - 1) / kGradTW) * ((a.h[l] + kGradTH - 1) / kGradTH);
+      tiles += ((a.w[l] + kGradVW - 1) / kGradVW) * ((a.h[l] + kGradVRows - 1) / kGradVRows);
       a.tile_end[l] = tiles;
     }
     a.n_levels = c->p.n_levels;

@@ -345,10 +345,7 @@ __global__ __launch_bounds__(kBlock) void k_pyramid_batch(const PyramidBatchArgs
 
 // ------------------------------------------------------------------------------------------------------------
 // gradients: 3 x Scharr, reflect-101 border, exact in int (src/Tracker.cpp:1133-1134).
-// A 64x16 output tile per block; the (64+2)x(16+2) u8 source patch is staged in LDS once, every output then
-// reads its 8 neighbours from LDS.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int kGradTW = 64, kGradTH = 16;
 
 __device__ inline int reflect101(int i, int n) {
   if (n == 1) return 0;
@@ -357,49 +354,7 @@ __device__ inline int reflect101(int i, int n) {
   return i;
 }
 
-// one 64x16 output tile (`tile_id` of frame `frame`); lds: (kGradTH + 2) x (kGradTW + 4) bytes
-__device__ __forceinline__ void scharr_tile_scalar(unsigned char* __restrict__ lds, const uint8_t* __restrict__ src,
-                                                   int16_t* __restrict__ gx, int16_t* __restrict__ gy, int w, int h, int pitch,
-                                                   size_t frame_stride, size_t frame, int tile_id) {
-  uint8_t(*tile)[kGradTW + 4] = reinterpret_cast<uint8_t(*)[kGradTW + 4]>(lds);
-  const int tiles_x = (w + kGradTW - 1) / kGradTW;
-  const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
-  const int x0 = tx * kGradTW, y0 = ty * kGradTH;
-  const uint8_t* img = src + frame * frame_stride;
-  for (int i = threadIdx.x; i < (kGradTH + 2) * (kGradTW + 2); i += kBlock) {
-    const int ly = i / (kGradTW + 2), lx = i - ly * (kGradTW + 2);
-    const int sy = reflect101(min(y0 + ly - 1, h), h), sx = reflect101(min(x0 + lx - 1, w), w);
-    tile[ly][lx] = img[(size_t)sy * pitch + sx];
-  }
-  __syncthreads();
-  const int lx = threadIdx.x & (kGradTW - 1);
-#pragma unroll
-  for (int r = 0; r < kGradTH / (kBlock / kGradTW); r++) {
-    const int ly = (threadIdx.x / kGradTW) + r * (kBlock / kGradTW);
-    const int x = x0 + lx, y = y0 + ly;
-    if (x < w && y < h) {
-      const int a = tile[ly][lx], b = tile[ly][lx + 1], c = tile[ly][lx + 2];
-      const int d = tile[ly + 1][lx], f = tile[ly + 1][lx + 2];
-      const int g = tile[ly + 2][lx], hh = tile[ly + 2][lx + 1], k = tile[ly + 2][lx + 2];
-      const int sx = 3 * (3 * (c - a) + 10 * (f - d) + 3 * (k - g));
-      const int sy = 3 * (3 * (g - a) + 10 * (hh - b) + 3 * (k - c));
-      const size_t o = frame * frame_stride + (size_t)y * pitch + x;
-      gx[o] = (int16_t)sx;  // |s| <= 48*255*... = 12240 < 32767: never saturates
-      gy[o] = (int16_t)sy;
-    }
-  }
-}
-
-// (src / gx / gy point at slot 0; the frames processed are slots[0..gridDim.y) if given, else first_slot..)
-static __global__ __launch_bounds__(kBlock) void k_scharr3(const uint8_t* __restrict__ src, int16_t* __restrict__ gx,
-                                                           int16_t* __restrict__ gy, int w, int h, int pitch, size_t frame_stride,
-                                                           const int* __restrict__ slots, int first_slot) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(kGradTH + 2) * (kGradTW + 4)];
-  const size_t frame = slots ? slots[blockIdx.y] : first_slot + (int)blockIdx.y;
-  scharr_tile_scalar(lds, src, gx, gy, w, h, pitch, frame_stride, frame, (int)blockIdx.x);
-}
-
-// Vector variant for level widths that are multiples of 4: a 128 x (8·RPT) output tile per block, the source patch (tile
+// Vector variant (any width: rows are pitched to whole words): a 128 x (8·RPT) output tile per block, the source patch (tile
 // + 1-pixel ring) staged in LDS with 4-byte loads; a thread owns 4 adjacent columns and RPT consecutive rows, slides a
 // three-row window of LDS words down them and stores two 8-byte vectors per row.  HBM-bound: 1 B read + 4 B written per
 // pixel.  RPT = 4 on levels tall enough: fewer, longer blocks with 4-5 loads in flight per thread before the barrier.
@@ -422,25 +377,37 @@ __device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, 
   const unsigned char* img = src + (size_t)slot * frame_stride;
   unsigned char* gxf = reinterpret_cast<unsigned char*>(gx + (size_t)slot * frame_stride);
   unsigned char* gyf = reinterpret_cast<unsigned char*>(gy + (size_t)slot * frame_stride);
-  const int tw = min(kGradVW, w - x0);  // valid width of this tile (multiple of 4)
-  const int rows = min(TH, h - y0) + 2; // patch rows this tile needs
+  const int tw = min(kGradVW, w - x0);       // image columns of this tile
+  const int twp = min(kGradVW, pitch - x0);  // ... rounded up to whole words: the pitched row's pad columns ride along (never read back)
+  const int rows = min(TH, h - y0) + 2;      // patch rows this tile needs
   const int ly = threadIdx.x / WPR, c = threadIdx.x - ly * WPR;
+  // An image whose width is not a multiple of four ends INSIDE a word: the byte behind its last column (column w, the right
+  // neighbour of column w - 1) must read as column w - 2 (reflect-101), not as the pad byte memory holds there.  The thread that
+  // stages that word fetches the byte for each of its rows and puts it in place before the word goes to LDS.
+  const bool patch = (tw & 3) != 0 && c == (tw >> 2);
+  const int patch_shift = 8 * (tw & 3);
   // reflect-101 of a row index in [-1, h]: |y|, then folded at the bottom edge
   auto reflect_row = [&](int y) { const int ay = y < 0 ? -y : y; return max(min(ay, 2 * h - 2 - ay), 0); };   // (h = 1: row 0)
   // a thread stages its own column of words: rows ly, ly + 8, ...  All of its loads are issued before the first is waited
   // for: rows / columns past the tile's patch read a clamped (valid) address and are not written to LDS.
   constexpr int kStage = (TH + 2 + kGradVRows - 1) / kGradVRows;
-  const uint32_t colb = (uint32_t)(x0 + min(4 * c, tw - 4));
-  uint32_t staged[kStage];
+  const uint32_t colb = (uint32_t)(x0 + min(4 * c, twp - 4));
+  uint32_t staged[kStage], mirrored[kStage];
 #pragma unroll
   for (int i = 0; i < kStage; i++) {
     const int r = min(ly + kGradVRows * i, rows - 1);
-    staged[i] = *reinterpret_cast<const uint32_t*>(img + (__umul24((unsigned)reflect_row(y0 + r - 1), (unsigned)pitch) + colb));
+    const uint32_t row = __umul24((unsigned)reflect_row(y0 + r - 1), (unsigned)pitch);
+    staged[i] = *reinterpret_cast<const uint32_t*>(img + (row + colb));
+    mirrored[i] = patch ? img[row + (uint32_t)max(w - 2, 0)] : 0u;
+  }
+  if (patch) {
+#pragma unroll
+    for (int i = 0; i < kStage; i++) staged[i] = (staged[i] & ~(0xffu << patch_shift)) | (mirrored[i] << patch_shift);
   }
   // the two halo bytes of a patch row (threads 0 .. 2·rows-1 keep theirs), requested behind the words
   const int hr = min((int)threadIdx.x >> 1, rows - 1), side = threadIdx.x & 1;
   const uint32_t halo = img[__umul24((unsigned)reflect_row(y0 + hr - 1), (unsigned)pitch) + (unsigned)reflect101(side ? x0 + tw : x0 - 1, w)];
-  if (4 * c < tw) {   // (rows past the patch hold a clamped row's words: never read)
+  if (4 * c < twp) {   // (rows past the patch hold a clamped row's words: never read)
 #pragma unroll
     for (int i = 0; i < kStage; i++) {
       const int r = ly + kGradVRows * i;
@@ -448,11 +415,12 @@ __device__ __forceinline__ void scharr_tile_v4(unsigned char* __restrict__ lds, 
     }
   }
   if ((int)threadIdx.x < 2 * rows) {
-    if (side) tile[hr][1 + tw / 4] = halo; else tile[hr][0] = halo << 24;
+    if (!side) tile[hr][0] = halo << 24;
+    else if ((tw & 3) == 0) tile[hr][1 + tw / 4] = halo;   // (a tile that ends inside a word: the staging thread patched the byte)
   }
   __syncthreads();
   const int x = x0 + 4 * c, yb = y0 + ly * RPT;
-  if (4 * c >= tw || yb >= h) return;
+  if (4 * c >= twp || yb >= h) return;
   // Separable form over packed 16-bit pairs (round 3; the scalar form spent ~30 integer instructions per pixel and was bound
   // by them, not by its 5 bytes per pixel).  Per source row and pixel j: the horizontal difference d = p[j+2] - p[j] and the
   // horizontal smoothing s = 3 p[j] + 10 p[j+1] + 3 p[j+2]; then gx = 3 (3 d_top + 10 d_mid + 3 d_bot) = 9 (d_top + d_bot) +
@@ -521,7 +489,7 @@ __global__ __launch_bounds__(kBlock) void k_scharr3_v4(const uint8_t* __restrict
 }
 
 // The gradients of every level of a frame (or a few) in one launch: block -> (level, tile) through the levels' tile
-// counts; the 128x8 vector tile where the level's width is a multiple of 4, the scalar 64x16 tile elsewhere.
+// counts, the 128x8 vector tile.
 constexpr int kGradMaxLevels = 8;
 struct GradLevelsArgs {
   const uint8_t* src[kGradMaxLevels];
@@ -536,8 +504,8 @@ struct GradLevelsArgs {
 };
 
 static __global__ __launch_bounds__(kBlock) void k_scharr3_levels(const GradLevelsArgs a) {
-  constexpr int kV4Bytes = scharr_v4_lds_rows(1) * (kGradVW / 4 + 2) * 4, kScBytes = (kGradTH + 2) * (kGradTW + 4);
-  __shared__ __attribute__((aligned(16))) unsigned char lds[kV4Bytes > kScBytes ? kV4Bytes : kScBytes];
+  constexpr int kV4Bytes = scharr_v4_lds_rows(1) * (kGradVW / 4 + 2) * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[kV4Bytes];
   const int slot = a.slots ? a.slots[blockIdx.y] : a.first_slot + (int)blockIdx.y;
   const int b = (int)blockIdx.x;
   // the level's parameters by selects over the (by-value) table: an indexed read would go through scratch memory
@@ -550,8 +518,7 @@ static __global__ __launch_bounds__(kBlock) void k_scharr3_levels(const GradLeve
     if (l < a.n_levels && b >= a.tile_end[l - 1]) {
       src = a.src[l]; gx = a.gx[l]; gy = a.gy[l]; w = a.w[l]; h = a.h[l]; pitch = a.pitch[l]; stride = a.stride[l]; tile0 = a.tile_end[l - 1];
     }
-  if (w % 4 == 0) scharr_tile_v4<1>(lds, src, gx, gy, w, h, pitch, stride, slot, b - tile0);
-  else scharr_tile_scalar(lds, src, gx, gy, w, h, pitch, stride, (size_t)slot, b - tile0);
+  scharr_tile_v4<1>(lds, src, gx, gy, w, h, pitch, stride, slot, b - tile0);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1430,7 +1397,7 @@ __device__ __forceinline__ void wait_planes_typed(RefGroup<4>& r) {
 // by register arithmetic — results are meaningless, its duration is the kernel's own instruction-issue floor.
 // residual_core evaluates one slice of one pair at `pose`; `lds` (optional) is the caller's buffer for the block reduction.
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, int EXT_LDS = 0, int STREAM = 0>   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's; STREAM: load_group
+          bool COMPUTE_ONLY = false, int EXT_LDS = 0, int STREAM = 0, bool RAGGED = false>   // EXT_LDS: 0 = own LDS, else rows per reduction pass in the caller's; STREAM: load_group; RAGGED: the level's grid rows are not whole groups of four (colm)
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first = nullptr, int ref_slot = -1,
                                               int tgt_slot = -1, const CoreOverride* ov = nullptr);
@@ -1446,7 +1413,7 @@ __device__ __forceinline__ void load_first_group(RefGroup<VEC>& rg, const Residu
 }
 
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, int STREAM = 0>
+          bool COMPUTE_ONLY = false, int STREAM = 0, bool RAGGED = false>
 __device__ __forceinline__ bool residual_block(const ResidualArgs& a, const int pair, const int slice) {   // false: the pair is not iterating
   Pose pose;
   if constexpr (COMPUTE_ONLY) {
@@ -1458,12 +1425,12 @@ __device__ __forceinline__ bool residual_block(const ResidualArgs& a, const int 
   } else {
     pose = a.pose;
   }
-  residual_core<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, 0, STREAM>(a, pair, slice, pose, nullptr);
+  residual_core<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, 0, STREAM, RAGGED>(a, pair, slice, pose, nullptr);
   return true;
 }
 
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE, int SAMPLER, int WEIGHTS, bool COMPUTE_ONLY,
-          int EXT_LDS, int STREAM>
+          int EXT_LDS, int STREAM, bool RAGGED>
 __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int pair, const int slice, const Pose& pose,
                                               unsigned char* lds, const RefGroup<VEC>* first, int ref_slot, int tgt_slot,
                                               const CoreOverride* ov) {
@@ -1591,15 +1558,15 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
     unsigned long long okm[VEC];  // validity as a wave mask (SGPR pair)
     uint32_t gidx[VEC];
     // Which pixels of the group are points of the level's grid.  A level whose grid rows are whole groups of four (gw == pitch)
-    // has no other position; elsewhere — every level of a frame size that is not a multiple of 2^(levels-1) x 4, src/System.cpp:
-    // 148-191 — the last group of a row holds positions x >= gw of the pitched row, which carry no point (src/Tracker.cpp:
-    // 1267-1268 walks x < w_[lvl]).  Groups start at multiples of four, so pixel j of a group is a point iff x0 < gw - (gw & 3)
-    // ("every pixel of the group is") or j < (gw & 3) and x0 < gw ("the row's last, partial group"): two compares per group under
-    // a block-uniform branch, nothing where the level is whole.
+    // has no other position.  RAGGED — every level of a frame size that is not a multiple of 2^(levels-1) x 4: the ROI crops of
+    // src/System.cpp:148-191 — : the last group of a row holds positions x >= gw of the pitched row, which carry no point
+    // (src/Tracker.cpp:1267-1268 walks x < w_[lvl]).  Groups start at multiples of four, so pixel j of a group is a point iff
+    // x0 < gw - (gw & 3) ("every pixel of the group is") or j < (gw & 3) and x0 < gw ("the row's last, partial group"): two compares
+    // per group; the whole-level instantiations carry nothing of it.
     unsigned long long colm[VEC];
 #pragma unroll
     for (int j = 0; j < VEC; j++) colm[j] = active_mask;
-    if (L.gw != L.pitch) {
+    if constexpr (RAGGED) {
       const unsigned long long m_in = active_mask & __builtin_amdgcn_fcmpf(xf0, (float)L.gw, kFcmpOLT);
       const unsigned long long m_all = active_mask & __builtin_amdgcn_fcmpf(xf0, (float)(L.gw & ~3), kFcmpOLT);
       const int rem = L.gw & 3;
@@ -1925,10 +1892,10 @@ __device__ __forceinline__ void residual_core(const ResidualArgs& a, const int p
 __device__ __forceinline__ void tail_update_wave(const ResidualArgs& a, int pair);   // (behind update_solve_wave)
 
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          bool COMPUTE_ONLY = false, int STREAM = 0>
+          bool COMPUTE_ONLY = false, int STREAM = 0, bool RAGGED = false>
 __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
   const int pair = (int)blockIdx.y + a.pair_base;
-  const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, STREAM>(a, pair, (int)blockIdx.x);
+  const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, COMPUTE_ONLY, STREAM, RAGGED>(a, pair, (int)blockIdx.x);
   if constexpr (!COMPUTE_ONLY && !DUMP) {
     if (a.tail.on && live && threadIdx.x < 64) tail_update_wave(a, pair);   // wave 0 wrote the block's record
   }
@@ -1937,10 +1904,10 @@ __global__ __launch_bounds__(kBlock) void k_residual(const ResidualArgs a) {
 // The same kernel held to four waves per SIMD (128 registers), for the one instantiation whose allocation lands just above
 // (bilinear sampler + Huber: 129 — the 129th register holds scalar registers the compiler parks across the loop).
 template <int AR, int VEC, bool DEPTH, bool UNIT_FACTORS, bool DUMP, typename AccT, bool SQUARE = false, int SAMPLER = 0, int WEIGHTS = 0,
-          int STREAM = 0>
+          int STREAM = 0, bool RAGGED = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_residual_w4(const ResidualArgs a) {
   const int pair = (int)blockIdx.y + a.pair_base;
-  const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, false, STREAM>(a, pair, (int)blockIdx.x);
+  const bool live = residual_block<AR, VEC, DEPTH, UNIT_FACTORS, DUMP, AccT, SQUARE, SAMPLER, WEIGHTS, false, STREAM, RAGGED>(a, pair, (int)blockIdx.x);
   if constexpr (!DUMP) {
     if (a.tail.on && live && threadIdx.x < 64) tail_update_wave(a, pair);
   }
@@ -2144,7 +2111,7 @@ constexpr int kHistTicketWord = kHistBins - 1;
 // The scale pass over groups [g_begin, g_end) of one pair's level at `pose`: every valid pixel's rounded residual counted in the
 // caller's LDS histogram (myh: bin 0 of this thread's replica).  Shared by k_resid_hist_v (one slice per block) and
 // k_coarse_weighted (a whole level per block).  The masked ds_add_u32 are the asm's own: the caller waits (lgkmcnt(0)).
-template <int AR, int VEC, bool DEPTH, int SAMPLER>
+template <int AR, int VEC, bool DEPTH, int SAMPLER, bool RAGGED = false>
 __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, const uint8_t* __restrict__ I1, const uint8_t* __restrict__ I2,
                                             const uint16_t* __restrict__ DP, unsigned int* myh, const int g_begin, const int g_end,
                                             const int n_groups) {
@@ -2178,7 +2145,7 @@ __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, con
     unsigned long long colm[VEC];   // the grid points of the group (see residual_core): all of them where the level is whole
 #pragma unroll
     for (int j = 0; j < VEC; j++) colm[j] = ~0ull;
-    if (L.gw != L.pitch) {
+    if constexpr (RAGGED) {
       const unsigned long long m_in = __builtin_amdgcn_uicmp(x, (uint32_t)L.gw, kIcmpULT);
       const unsigned long long m_all = __builtin_amdgcn_uicmp(x, (uint32_t)(L.gw & ~3), kIcmpULT);
       const int rem = L.gw & 3;
@@ -2275,7 +2242,7 @@ __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, con
   }
 }
 
-template <int AR, int VEC, bool DEPTH, int SAMPLER>
+template <int AR, int VEC, bool DEPTH, int SAMPLER, bool RAGGED = false>
 __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, unsigned int* __restrict__ hist, PairScale* __restrict__ scale_out,
                                                          int weights) {
   const int pair = blockIdx.y + a.pair_base;
@@ -2296,7 +2263,7 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
   unsigned int* myh = h + 255 * kHistRep + (threadIdx.x & (kHistRep - 1));
   const int n_groups = L.ng / VEC;
   const int g_begin = blockIdx.x * a.groups_per_block, g_end = min(g_begin + a.groups_per_block, n_groups);
-  hist_groups<AR, VEC, DEPTH, SAMPLER>(L, K, I1, I2, DP, myh, g_begin, g_end, n_groups);
+  hist_groups<AR, VEC, DEPTH, SAMPLER, RAGGED>(L, K, I1, I2, DP, myh, g_begin, g_end, n_groups);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the masked ds_add_u32 above are the asm's own: the compiler does not count them
   __syncthreads();
   unsigned int* gh = hist + (size_t)pair * kHistBins;
@@ -2663,7 +2630,7 @@ constexpr int iterate_lds_bytes(int pass) { return kUpdateLdsBytes > reduce_lds_
 // z / angle factors —, i.e. residual_core<UNIT_FACTORS, SQUARE>; false = the general form (fx != fy and / or other factors:
 // every product written out, the factors multiplied in), which computes the same bits where both apply (x * 1.0f == x).
 // f64 sums only (a context with accumulate_f64 = 0 stays on the per-evaluation launches).
-template <int AR, int VEC, bool DEPTH, bool PLAIN, bool COMPUTE_ONLY = false, int PASS = kIteratePass>
+template <int AR, int VEC, bool DEPTH, bool PLAIN, bool COMPUTE_ONLY = false, int PASS = kIteratePass, bool RAGGED = false>
 __global__ __launch_bounds__(kBlock) void k_iterate(const ResidualArgs a, const IterArgs ia) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[iterate_lds_bytes(PASS)];   // the update's staging, then the reduction's image
   const int pair = (int)blockIdx.y + a.pair_base, slice = (int)blockIdx.x;
@@ -2683,7 +2650,7 @@ __global__ __launch_bounds__(kBlock) void k_iterate(const ResidualArgs a, const 
   }
   if (st.level_done || st.status) return;
   __syncthreads();   // the staging bytes become the reduction's
-  residual_core<AR, VEC, DEPTH, PLAIN, false, double, PLAIN, 0, 0, COMPUTE_ONLY, PASS>(a, pair, slice, st.pose, lds, &first, ref_slot, tgt_slot);
+  residual_core<AR, VEC, DEPTH, PLAIN, false, double, PLAIN, 0, 0, COMPUTE_ONLY, PASS, 0, RAGGED>(a, pair, slice, st.pose, lds, &first, ref_slot, tgt_slot);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -2715,8 +2682,9 @@ struct CoarseArgs {
 // NLEV: levels the launch can run (the loop over them is unrolled).  The batch form (one block per pair of a whole batch, one
 // level per launch, PASS 14) stays at ~210 registers, two waves per SIMD: forced to 128 it spills and loses (measured), so it
 // pays only on the smallest levels, where the per-evaluation launches run furthest below the level-0 rate.
-// VECSEL: pixels per vector group of the levels the launch runs: 4 (every level's rows are whole groups of four), 1 (none's are:
-// a lone level like 46 x 30 or 47 x 30), 0 (decided per level at run time: a chain like 46 -> 92 wide)
+// VECSEL: the grid rows of the levels the launch runs: 4 (every level's are whole groups of four), 1 (none's are: a lone level
+// like 46 x 30 or 47 x 30, every level of an odd-sized frame: the RAGGED instantiation of residual_core), 0 (decided per level at
+// run time: a chain like 46 -> 92 wide)
 template <int AR, bool DEPTH, bool PLAIN, int PASS, int NLEV, int VECSEL>
 __device__ __forceinline__ void coarse_body(const CoarseArgs& ca);
 
@@ -2762,7 +2730,7 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
     const ResidualArgs& a = ca.lv[li];   // read in place (the kernel-argument segment); what differs travels in `ov`
     const bool v4 = VECSEL == 4 || (VECSEL == 0 && a.L.gw == a.L.pitch);   // block-uniform
     CoreOverride ov;
-    ov.groups_per_block = ((a.L.ng / (v4 ? 4 : 1) + kBlock - 1) / kBlock) * kBlock;   // the whole level
+    ov.groups_per_block = ((a.L.ng / 4 + kBlock - 1) / kBlock) * kBlock;   // the whole level
     ov.rec = rec;
     UpdateArgs u = ca.u;
     u.slices = 1;
@@ -2774,10 +2742,10 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
         if constexpr (VECSEL == 4) {
           residual_core<AR, 4, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
         } else if constexpr (VECSEL == 1) {
-          residual_core<AR, 1, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
+          residual_core<AR, 4, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS, 0, true>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
         } else {
           if (v4) residual_core<AR, 4, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
-          else residual_core<AR, 1, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
+          else residual_core<AR, 4, DEPTH, PLAIN, false, double, PLAIN, 0, 0, false, PASS, 0, true>(a, pair, 0, st.pose, lds, nullptr, ref_slot, tgt_slot, &ov);
         }
         __syncthreads();   // the record and the state are in LDS; the reduction's image is free
         u.k = k;
@@ -2803,8 +2771,9 @@ __device__ __forceinline__ void coarse_body(const CoarseArgs& ca) {
 // launch, the weighted launch and the update (three dependent launches of a few blocks each, ~20 us for a lone pair) by ~8 us
 // of one resident block.  Same device functions as the launches it replaces: same bits.
 // ------------------------------------------------------------------------------------------------------------
-template <int AR, bool DEPTH, int WEIGHTS, bool PLAIN, int NLEV = kCoarseMaxLevels, int VEC = 4>
+template <int AR, bool DEPTH, int WEIGHTS, bool PLAIN, int NLEV = kCoarseMaxLevels, bool RAGGED = false>
 __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca) {
+  constexpr int VEC = 4;
   __shared__ unsigned int h[kHistBins * kHistRep];                                  // the residual histogram, kHistRep replicas per bin
   __shared__ unsigned int h_scratch[kHistBins];                                     // wave_scale's working copy
   __shared__ __attribute__((aligned(16))) unsigned char ulds[kUpdateLdsBytes];      // update_compute's staging
@@ -2850,7 +2819,7 @@ __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca)
         {
           WarpK K;
           warp_setup<AR>(st.pose, K);
-          hist_groups<AR, VEC, DEPTH, 0>(L, K, a.img + ref_off, a.img + tgt_off, DEPTH ? a.depth + ref_off : nullptr,
+          hist_groups<AR, VEC, DEPTH, 0, RAGGED>(L, K, a.img + ref_off, a.img + tgt_off, DEPTH ? a.depth + ref_off : nullptr,
                                        h + 255 * kHistRep + (threadIdx.x & (kHistRep - 1)), 0, n_groups, n_groups);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // hist_groups' masked ds_add_u32 are its asm's own
@@ -2873,7 +2842,7 @@ __global__ __launch_bounds__(kBlock) void k_coarse_weighted(const CoarseArgs ca)
         }
         __syncthreads();
         // the weighted sums (src/Tracker.cpp:554-561) through the weight table; the record lands in LDS
-        residual_core<AR, VEC, DEPTH, PLAIN, false, double, PLAIN, 0, WEIGHTS>(a, pair, 0, st.pose, nullptr, nullptr, ref_slot, tgt_slot, &ov);
+        residual_core<AR, VEC, DEPTH, PLAIN, false, double, PLAIN, 0, WEIGHTS, false, 0, 0, RAGGED>(a, pair, 0, st.pose, nullptr, nullptr, ref_slot, tgt_slot, &ov);
         __syncthreads();
         u.k = k;
         st = update_compute(u, rec, &cur, ulds, false);   // ends with a barrier: every thread has the new state

@@ -15,9 +15,10 @@ struct LaunchSel {
   bool compute_only;   // the diagnostic twin (uwt_profile_enable bit 2)
 };
 
-// pixels per vector group at a level: 4 — a level's rows are pitched to whole groups of four, and the kernels mask the positions
-// of a row's last group that lie beyond the point grid (residual_core: colm)
-inline int level_vec(const LevelK&) { return 4; }
+// A level's rows are pitched to whole groups of four pixels and walked in such groups.  level_ragged: the grid's rows are not
+// whole groups (46 wide in rows of 48; every level of an odd-sized frame): the RAGGED instantiations mask the positions of a
+// row's last group that lie beyond the point grid (residual_core: colm).
+inline bool level_ragged(const LevelK& L) { return L.gw != L.pitch; }
 inline bool level_plain(const ResidualArgs& a) { return a.zf == 1.0f && a.af == 1.0f && a.L.fx == a.L.fy; }
 
 // k_residual, identity weights / nearest sampler (and the per-stage dump form)

@@ -11,8 +11,9 @@ void launch_iterate_t(hipStream_t s, const ResidualArgs& a, const IterArgs& ia, 
   const dim3 grid(a.slices, n_pairs), blk(kBlock);
   const bool plain = level_plain(a);
   const bool wide = n_pairs > 3;   // four blocks per CU (two-pass reduction) instead of blocks alone on their CUs
-  if (level_vec(a.L) != 4) {       // a level whose rows are not whole groups of four: one pixel per step, the general form
-    hipLaunchKernelGGL((k_iterate<AR, 1, DEPTH, false, false, 14>), grid, blk, 0, s, a, ia);
+  if (level_ragged(a.L)) {   // grid rows that are not whole groups of four: the masking instantiations (square pixels with unit factors or the general form)
+    if (plain) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, true, false, 14, true>), grid, blk, 0, s, a, ia);
+    else hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, false, false, 14, true>), grid, blk, 0, s, a, ia);
     return;
   }
   if (plain && compute_only) hipLaunchKernelGGL((k_iterate<AR, 4, DEPTH, true, true>), grid, blk, 0, s, a, ia);
@@ -25,16 +26,16 @@ void launch_iterate_t(hipStream_t s, const ResidualArgs& a, const IterArgs& ia, 
 template <int AR, bool DEPTH>
 void launch_coarse_level_t(hipStream_t s, const CoarseArgs& ca, int cnt, int weights) {
   const dim3 grid(cnt), blk(kBlock);
-  const bool v4 = level_vec(ca.lv[0].L) == 4;
-  const bool plain = v4 && level_plain(ca.lv[0]);   // (a level that goes pixel by pixel takes the general form: one instantiation)
+  const bool v4 = !level_ragged(ca.lv[0].L);
+  const bool plain = v4 && level_plain(ca.lv[0]);   // (a level with ragged grid rows takes the general form: one instantiation)
   if (weights == kWeightsTukeyRef) {
     if (plain) hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsTukeyRef, true, 1>), grid, blk, 0, s, ca);
     else if (v4) hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsTukeyRef, false, 1>), grid, blk, 0, s, ca);
-    else hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsTukeyRef, false, 1, 1>), grid, blk, 0, s, ca);
+    else hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsTukeyRef, false, 1, true>), grid, blk, 0, s, ca);
   } else if (weights == kWeightsHuber) {
     if (plain) hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsHuber, true, 1>), grid, blk, 0, s, ca);
     else if (v4) hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsHuber, false, 1>), grid, blk, 0, s, ca);
-    else hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsHuber, false, 1, 1>), grid, blk, 0, s, ca);
+    else hipLaunchKernelGGL((k_coarse_weighted<AR, DEPTH, kWeightsHuber, false, 1, true>), grid, blk, 0, s, ca);
   } else {
     if (plain) hipLaunchKernelGGL((k_coarse_w4<AR, DEPTH, true>), grid, blk, 0, s, ca);
     else if (v4) hipLaunchKernelGGL((k_coarse_w4<AR, DEPTH, false>), grid, blk, 0, s, ca);
@@ -50,12 +51,12 @@ void launch_iterate(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, 
     else launch_iterate_t<AR, false>(s, a, ia, n_pairs, sel.compute_only));
 }
 
-// up to kCoarseMaxLevels coarsest levels of a few pairs, to their end, in one launch; when one of them goes pixel by pixel
-// (rows that are not whole groups of four) the launch takes the general form with the group width decided per level
+// up to kCoarseMaxLevels coarsest levels of a few pairs, to their end, in one launch; when one of them has ragged grid rows
+// (not whole groups of four) the launch takes the general form with the masking decided per level
 void launch_coarse_chain(hipStream_t s, const LaunchSel& sel, const CoarseArgs& ca, int n_pairs) {
   const dim3 grid(n_pairs), blk(kBlock);
   bool all4 = true;
-  for (int i = 0; i < ca.n_levels; i++) all4 = all4 && level_vec(ca.lv[i].L) == 4;
+  for (int i = 0; i < ca.n_levels; i++) all4 = all4 && !level_ragged(ca.lv[i].L);
   const bool plain = all4 && level_plain(ca.lv[0]);
   UWT_WITH_AR(sel.arith,
     if (sel.depth) {

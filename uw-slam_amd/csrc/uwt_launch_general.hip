@@ -7,11 +7,12 @@ namespace {
 
 // One residual evaluation on the general path for pairs [pair_base, +n): the dense kernel specialised for the sampler / weights.
 // Same slicing as the fast path.
-template <int AR, int VEC, bool DEPTH, bool UNIT>
+template <int AR, bool RAGGED, bool DEPTH, bool UNIT>
 void launch_general_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sampler, int weights) {
   const dim3 grid(a.slices, n_pairs), blk(kBlock);
   const int key = sampler * 3 + weights;
-  if constexpr (VEC == 4 && UNIT) {
+  constexpr int VEC = 4;
+  if constexpr (!RAGGED && UNIT) {
     if (a.L.fx == a.L.fy) {   // SQUARE: the Jacobian's coinciding products once (pixel_jacobian), as on the identity path
       if (a.stream_planes) {   // the streamed twins (load_group)
         switch (key) {
@@ -37,19 +38,19 @@ void launch_general_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sam
       return;
     }
   }
-  switch (key) {
-    case 1: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 0, 1>), grid, blk, 0, s, a); break;
-    case 2: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 0, 2>), grid, blk, 0, s, a); break;
-    case 3: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 1, 0>), grid, blk, 0, s, a); break;
-    default: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 1, 2>), grid, blk, 0, s, a); break;
+  switch (key) {   // the general Jacobian form; RAGGED: with the positions beyond the grid masked
+    case 1: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 0, 1, false, 0, RAGGED>), grid, blk, 0, s, a); break;
+    case 2: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 0, 2, false, 0, RAGGED>), grid, blk, 0, s, a); break;
+    case 3: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 1, 0, false, 0, RAGGED>), grid, blk, 0, s, a); break;
+    default: hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, false, double, false, 1, 2, false, 0, RAGGED>), grid, blk, 0, s, a); break;
   }
 }
 
-template <int AR, int VEC, bool DEPTH>
+template <int AR, bool RAGGED, bool DEPTH>
 void launch_hist_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sampler, int weights, unsigned int* hist, PairScale* scale) {
   const dim3 grid(a.slices, n_pairs), blk(kBlock);
-  if (sampler) hipLaunchKernelGGL((k_resid_hist_v<AR, VEC, DEPTH, 1>), grid, blk, 0, s, a, hist, scale, weights);
-  else hipLaunchKernelGGL((k_resid_hist_v<AR, VEC, DEPTH, 0>), grid, blk, 0, s, a, hist, scale, weights);
+  if (sampler) hipLaunchKernelGGL((k_resid_hist_v<AR, 4, DEPTH, 1, RAGGED>), grid, blk, 0, s, a, hist, scale, weights);
+  else hipLaunchKernelGGL((k_resid_hist_v<AR, 4, DEPTH, 0, RAGGED>), grid, blk, 0, s, a, hist, scale, weights);
 }
 
 }  // namespace
@@ -60,28 +61,28 @@ void launch_hist_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sample
 void launch_general(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, int n_pairs, int sampler, int weights,
                     unsigned int* hist, PairScale* scale) {
   const bool unit = (a.zf == 1.0f && a.af == 1.0f);
-  const int vec = level_vec(a.L);
+  const bool ragged = level_ragged(a.L);
   if (weights) {
     UWT_WITH_AR(sel.arith,
-      if (vec == 4) {
-        if (sel.depth) launch_hist_t<AR, 4, true>(s, a, n_pairs, sampler, weights, hist, scale);
-        else launch_hist_t<AR, 4, false>(s, a, n_pairs, sampler, weights, hist, scale);
+      if (!ragged) {
+        if (sel.depth) launch_hist_t<AR, false, true>(s, a, n_pairs, sampler, weights, hist, scale);
+        else launch_hist_t<AR, false, false>(s, a, n_pairs, sampler, weights, hist, scale);
       } else {
-        if (sel.depth) launch_hist_t<AR, 1, true>(s, a, n_pairs, sampler, weights, hist, scale);
-        else launch_hist_t<AR, 1, false>(s, a, n_pairs, sampler, weights, hist, scale);
+        if (sel.depth) launch_hist_t<AR, true, true>(s, a, n_pairs, sampler, weights, hist, scale);
+        else launch_hist_t<AR, true, false>(s, a, n_pairs, sampler, weights, hist, scale);
       });
   }
-  const int key = (vec == 4 ? 4 : 0) | (sel.depth ? 2 : 0) | (unit ? 1 : 0);
+  const int key = (ragged ? 0 : 4) | (sel.depth ? 2 : 0) | (unit ? 1 : 0);
   UWT_WITH_AR(sel.arith,
     switch (key) {
-      case 0: launch_general_t<AR, 1, false, false>(s, a, n_pairs, sampler, weights); break;
-      case 1: launch_general_t<AR, 1, false, true>(s, a, n_pairs, sampler, weights); break;
-      case 2: launch_general_t<AR, 1, true, false>(s, a, n_pairs, sampler, weights); break;
-      case 3: launch_general_t<AR, 1, true, true>(s, a, n_pairs, sampler, weights); break;
-      case 4: launch_general_t<AR, 4, false, false>(s, a, n_pairs, sampler, weights); break;
-      case 5: launch_general_t<AR, 4, false, true>(s, a, n_pairs, sampler, weights); break;
-      case 6: launch_general_t<AR, 4, true, false>(s, a, n_pairs, sampler, weights); break;
-      default: launch_general_t<AR, 4, true, true>(s, a, n_pairs, sampler, weights); break;
+      case 0: launch_general_t<AR, true, false, false>(s, a, n_pairs, sampler, weights); break;
+      case 1: launch_general_t<AR, true, false, true>(s, a, n_pairs, sampler, weights); break;
+      case 2: launch_general_t<AR, true, true, false>(s, a, n_pairs, sampler, weights); break;
+      case 3: launch_general_t<AR, true, true, true>(s, a, n_pairs, sampler, weights); break;
+      case 4: launch_general_t<AR, false, false, false>(s, a, n_pairs, sampler, weights); break;
+      case 5: launch_general_t<AR, false, false, true>(s, a, n_pairs, sampler, weights); break;
+      case 6: launch_general_t<AR, false, true, false>(s, a, n_pairs, sampler, weights); break;
+      default: launch_general_t<AR, false, true, true>(s, a, n_pairs, sampler, weights); break;
     });
 }
 

@@ -5,10 +5,31 @@
 namespace uwt {
 namespace {
 
-template <int AR, int VEC, bool DEPTH, bool UNIT, bool DUMP>
-void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64, bool compute_only) {
+// RAGGED: the level's grid rows are not whole groups of four (level_ragged): the instantiations that mask the positions beyond the
+// grid.  They exist for the shapes odd-sized frames run in production — f64 sums with typed plane loads, square pixels or not —
+// and as one plain form for everything else (f32 sums, the per-stage dumps, non-unit factors, typed loads switched off).
+template <int AR, bool DEPTH, bool UNIT, bool DUMP>
+void launch_residual_ragged_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64) {
   const dim3 grid(a.slices, n_pairs), blk(kBlock);
-  if constexpr (VEC == 4 && UNIT && !DUMP) {
+  if constexpr (UNIT && !DUMP) {
+    if (acc64 && a.typed_loads) {
+      const bool sq = a.L.fx == a.L.fy;
+      if (sq && a.stream_planes) hipLaunchKernelGGL((k_residual<AR, 4, DEPTH, UNIT, DUMP, double, true, 0, 0, false, kLoadsTyped | kLoadsStream, true>), grid, blk, 0, s, a);
+      else if (sq) hipLaunchKernelGGL((k_residual<AR, 4, DEPTH, UNIT, DUMP, double, true, 0, 0, false, kLoadsTyped, true>), grid, blk, 0, s, a);
+      else if (a.stream_planes) hipLaunchKernelGGL((k_residual<AR, 4, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsTyped | kLoadsStream, true>), grid, blk, 0, s, a);
+      else hipLaunchKernelGGL((k_residual<AR, 4, DEPTH, UNIT, DUMP, double, false, 0, 0, false, kLoadsTyped, true>), grid, blk, 0, s, a);
+      return;
+    }
+  }
+  if (acc64) hipLaunchKernelGGL((k_residual<AR, 4, DEPTH, UNIT, DUMP, double, false, 0, 0, false, 0, true>), grid, blk, 0, s, a);
+  else hipLaunchKernelGGL((k_residual<AR, 4, DEPTH, UNIT, DUMP, float, false, 0, 0, false, 0, true>), grid, blk, 0, s, a);
+}
+
+template <int AR, bool DEPTH, bool UNIT, bool DUMP>
+void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool acc64, bool compute_only) {
+  constexpr int VEC = 4;
+  const dim3 grid(a.slices, n_pairs), blk(kBlock);
+  if constexpr (UNIT && !DUMP) {
     if (acc64 && a.L.fx == a.L.fy) {   // the production instantiation, its diagnostic twin and its streamed twin (load_group)
       if (compute_only) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, true>), grid, blk, 0, s, a);
       else if (a.typed_loads && a.stream_planes) hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, double, true, 0, 0, false, kLoadsTyped | kLoadsStream>), grid, blk, 0, s, a);
@@ -18,7 +39,7 @@ void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool a
       return;
     }
   }
-  if constexpr (VEC == 4 && !DUMP) {
+  if constexpr (!DUMP) {
     // the general Jacobian form (fx != fy — the reference's own EUROC calibration: 458.654 / 457.296 — and / or non-unit
     // factors): its streamed twin too
     if constexpr (UNIT) {   // fx != fy with unit factors (EUROC): typed plane loads here too
@@ -37,14 +58,24 @@ void launch_residual_t(hipStream_t s, const ResidualArgs& a, int n_pairs, bool a
   else hipLaunchKernelGGL((k_residual<AR, VEC, DEPTH, UNIT, DUMP, float>), grid, blk, 0, s, a);
 }
 
-template <int AR, int VEC, bool DEPTH>
+template <int AR, bool DEPTH>
 void launch_residual_vd(hipStream_t s, const ResidualArgs& a, int n_pairs, bool unit, bool dump, bool acc64, bool co) {
+  if (level_ragged(a.L)) {   // (no compute-only twin of the ragged forms: the diagnostic measures the whole-level production kernel)
+    if (unit) {
+      if (dump) launch_residual_ragged_t<AR, DEPTH, true, true>(s, a, n_pairs, acc64);
+      else launch_residual_ragged_t<AR, DEPTH, true, false>(s, a, n_pairs, acc64);
+    } else {
+      if (dump) launch_residual_ragged_t<AR, DEPTH, false, true>(s, a, n_pairs, acc64);
+      else launch_residual_ragged_t<AR, DEPTH, false, false>(s, a, n_pairs, acc64);
+    }
+    return;
+  }
   if (unit) {
-    if (dump) launch_residual_t<AR, VEC, DEPTH, true, true>(s, a, n_pairs, acc64, false);
-    else launch_residual_t<AR, VEC, DEPTH, true, false>(s, a, n_pairs, acc64, co);
+    if (dump) launch_residual_t<AR, DEPTH, true, true>(s, a, n_pairs, acc64, false);
+    else launch_residual_t<AR, DEPTH, true, false>(s, a, n_pairs, acc64, co);
   } else {
-    if (dump) launch_residual_t<AR, VEC, DEPTH, false, true>(s, a, n_pairs, acc64, false);
-    else launch_residual_t<AR, VEC, DEPTH, false, false>(s, a, n_pairs, acc64, co);
+    if (dump) launch_residual_t<AR, DEPTH, false, true>(s, a, n_pairs, acc64, false);
+    else launch_residual_t<AR, DEPTH, false, false>(s, a, n_pairs, acc64, co);
   }
 }
 
@@ -53,15 +84,9 @@ void launch_residual_vd(hipStream_t s, const ResidualArgs& a, int n_pairs, bool 
 void launch_residual(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, int n_pairs, bool dump) {
   const bool unit = (a.zf == 1.0f && a.af == 1.0f);
   const bool co = sel.compute_only && !dump;
-  const int vec = level_vec(a.L);
   UWT_WITH_AR(sel.arith,
-    if (vec == 4) {
-      if (sel.depth) launch_residual_vd<AR, 4, true>(s, a, n_pairs, unit, dump, sel.acc64, co);
-      else launch_residual_vd<AR, 4, false>(s, a, n_pairs, unit, dump, sel.acc64, co);
-    } else {
-      if (sel.depth) launch_residual_vd<AR, 1, true>(s, a, n_pairs, unit, dump, sel.acc64, co);
-      else launch_residual_vd<AR, 1, false>(s, a, n_pairs, unit, dump, sel.acc64, co);
-    });
+    if (sel.depth) launch_residual_vd<AR, true>(s, a, n_pairs, unit, dump, sel.acc64, co);
+    else launch_residual_vd<AR, false>(s, a, n_pairs, unit, dump, sel.acc64, co));
 }
 
 void launch_points(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const PointsArgs& pa) {
