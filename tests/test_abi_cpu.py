@@ -112,17 +112,54 @@ def test_product_never_touches_the_oracle():
 def test_hand_written_loads_of_the_typed_kernels_are_released_before_use():
     """The typed instantiations of k_residual (uwt_kernels.h: load_group_typed) issue every vector-memory operation of their loop
     from asm statements, which the compiler's s_waitcnt bookkeeping does not see: between such a load and the written-out wait
-    that releases it, no instruction of the SHIPPED assembly may touch the load's destination registers.  Compiles the
-    dispatcher unit to assembly (the library's own `make asm` recipe) and scans every typed instantiation
-    (tools/check_asm_loads.py)."""
+    that releases it, no instruction may touch the load's destination registers, on any path (branch targets and loop back-edges
+    followed), and no such load may reach s_endpgm unwaited.  Checked on the code objects INSIDE THE SHIPPED libuwt_hip.so
+    (llvm-objdump --offloading + -d; hipcc's register allocation differs from build to build, so a fresh compile proves nothing
+    about the binary that ships) and, for the tool's other input format, on a fresh listing of the dispatcher unit."""
     import subprocess
+    tool = os.path.join(ROOT, "tools", "check_asm_loads.py")
+    lib = os.path.join(ROOT, "uw-slam_amd", "libuwt_hip.so")
+    out = subprocess.run([sys.executable, tool, "--shipped", lib, "--all-typed"], capture_output=True, text=True)
+    assert out.returncode == 0 and " 0 violations" in out.stdout, out.stdout[-3000:] + out.stderr[-1000:]
+    m = re.search(r"(\d+) vector loads checked in (\d+) kernels", out.stdout)
+    # production + EUROC (fx != fy) forms x depth x streamed x whole / ragged rows, both arithmetic sets; two register sets of
+    # (1 + 2 or 3) plane loads + 4 gathers per kernel and the first group's request
+    assert int(m.group(2)) >= 32 and int(m.group(1)) >= 16 * int(m.group(2)), out.stdout
     csrc = os.path.join(ROOT, "uw-slam_amd", "csrc")
     r = subprocess.run(["make", "-C", csrc, "asm", "UNIT=uwt_launch_residual"], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
-    asm = os.path.join(csrc, "uwt_launch_residual.gfx950.s")
-    names = sorted(set(re.findall(r"^(_ZN3uwt10k_residualI\w+?ELi[23]EEEvNS_12ResidualArgsE):", open(asm).read(), re.M)))
-    assert len(names) >= 8, names            # production + EUROC forms x depth x streamed, both arithmetic sets
-    for n in names:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_asm_loads.py"), asm, n], capture_output=True, text=True)
-        assert out.returncode == 0 and " 0 violations" in out.stdout, (n, out.stdout[-1500:])
-        assert int(out.stdout.split()[0]) >= 16, out.stdout          # the loop's loads were found (two register sets)
+    out = subprocess.run([sys.executable, tool, os.path.join(csrc, "uwt_launch_residual.gfx950.s"), "--all-typed"], capture_output=True, text=True)
+    assert out.returncode == 0 and " 0 violations" in out.stdout, out.stdout[-3000:]
+
+
+def test_the_load_checker_catches_what_it_is_for(tmp_path):
+    """tools/check_asm_loads.py on hand-made listings: a use before the wait, a younger store whose data register is the load's
+    destination, a load that reaches s_endpgm unwaited, a use that is only reachable through the loop's back-edge — and the
+    packed-f32 broadcast that names a register pair but reads its low half only."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "check_asm_loads.py")
+
+    def run(body):
+        f = tmp_path / "k.s"
+        f.write_text("_ZN3uwt6k_testEv:\n" + "".join("\t%s\n" % l if not l.endswith(":") else l + "\n" for l in body) + "\ts_endpgm\n")
+        out = subprocess.run([sys.executable, tool, str(f), "k_test"], capture_output=True, text=True)
+        return out.returncode, out.stdout
+
+    ok = ["tbuffer_load_format_xyzw v[4:7], v1, s[8:11], 0 offen", "v_add_f32 v2, v3, v3", "s_waitcnt vmcnt(0)", "v_add_f32 v2, v4, v4"]
+    assert run(ok)[0] == 0
+    assert run(["tbuffer_load_format_xyzw v[4:7], v1, s[8:11], 0 offen", "v_add_f32 v2, v5, v3", "s_waitcnt vmcnt(0)"])[0] == 1
+    assert run(["tbuffer_load_format_xyzw v[4:7], v1, s[8:11], 0 offen", "global_store_dword v1, v6, s[2:3]", "s_waitcnt vmcnt(0)"])[0] == 1
+    rc, txt = run(["tbuffer_load_format_xyzw v[4:7], v1, s[8:11], 0 offen", "v_add_f32 v2, v3, v3"])
+    assert rc == 1 and "s_endpgm" in txt
+    loop = [".LBB0_1:", "v_add_f32 v2, v4, v4", "s_waitcnt vmcnt(0)", "tbuffer_load_format_xyzw v[4:7], v1, s[8:11], 0 offen",
+            "s_cbranch_scc1 .LBB0_1", "s_waitcnt vmcnt(0)"]
+    assert run(loop)[0] == 1                                   # the use at the loop's head comes before the head's wait
+    assert run([".LBB0_1:", "s_waitcnt vmcnt(0)", "v_add_f32 v2, v4, v4", "tbuffer_load_format_xyzw v[4:7], v1, s[8:11], 0 offen",
+                "s_cbranch_scc1 .LBB0_1", "s_waitcnt vmcnt(0)"])[0] == 0
+    # a wait that leaves N younger operations outstanding releases the load only once N younger ones were issued
+    assert run(["global_load_ubyte v9, v1, s[2:3]", "tbuffer_load_format_xyzw v[4:7], v1, s[8:11], 0 offen", "s_waitcnt vmcnt(1)", "v_add_u32 v2, v9, v9",
+                "s_waitcnt vmcnt(0)"])[0] == 0
+    assert run(["global_load_ubyte v9, v1, s[2:3]", "s_waitcnt vmcnt(1)", "v_add_u32 v2, v9, v9", "s_waitcnt vmcnt(0)"])[0] == 1
+    bcast = ["global_load_ubyte v45, v1, s[2:3]", "v_pk_add_f32 v[92:93], v[44:45], s[58:59] op_sel_hi:[0,1]", "s_waitcnt vmcnt(0)"]
+    assert run(bcast)[0] == 0                                  # both lanes read v44
+    assert run([bcast[0], "v_pk_add_f32 v[92:93], v[44:45], s[58:59]", bcast[2]])[0] == 1
