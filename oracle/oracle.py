@@ -11,11 +11,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libuwt_oracle.so")
+# UWT_ORACLE_SAN=1: the AddressSanitizer + UBSan build of the same sources (oracle/Makefile SAN=1; the sanitizer runtimes must be
+# preloaded into the interpreter: tools/sanitize_cpu.sh).  Test infrastructure may read the environment; the product never does.
+_SAN = os.environ.get("UWT_ORACLE_SAN", "") == "1"
+_LIB_PATH = os.path.join(_HERE, "libuwt_oracle_san.so" if _SAN else "libuwt_oracle.so")
 
 MAX_LEVELS = 8
 ARITH_OPENCV, ARITH_LEGACY = 0, 1   # uwo_params.arith (oracle/uwt_oracle.h: G1..G4 / S1, S3, S4)
 ARITH_NAMES = {ARITH_OPENCV: "opencv", ARITH_LEGACY: "legacy"}
+TRIG_ROUNDED, TRIG_LIBM = 0, 1     # uwo_params.trig (S5): (float)sin((double)x) / this host's sinf, cosf
 
 
 class Params(C.Structure):
@@ -28,6 +32,7 @@ class Params(C.Structure):
         ("depth_scale", C.c_float), ("initial_error", C.c_float),
         ("early_exit", C.c_int32), ("has_depth", C.c_int32), ("handoff_scale_t", C.c_int32),
         ("weights", C.c_int32), ("sampler", C.c_int32), ("arith", C.c_int32), ("gemm_fold", C.c_int32),
+        ("trig", C.c_int32),
     ]
 
 
@@ -55,7 +60,9 @@ def build(force=False):
     if (not force and os.path.exists(_LIB_PATH)
             and os.path.getmtime(_LIB_PATH) >= max(os.path.getmtime(src), os.path.getmtime(hdr))):
         return _LIB_PATH
-    subprocess.check_call(["make", "-C", _HERE, "-B", "libuwt_oracle.so"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ)
+    env.pop("LD_PRELOAD", None)   # (a preloaded sanitizer runtime is for the interpreter, not for make / gcc)
+    subprocess.check_call(["make", "-C", _HERE, "-B", os.path.basename(_LIB_PATH)] + (["SAN=1"] if _SAN else []), stdout=subprocess.DEVNULL, env=env)
     return _LIB_PATH
 
 
@@ -290,6 +297,11 @@ def set_gemm_fold(fold):
     source's "s0 += s1 + s2 + s3": s0 + ((s1 + s2) + s3)) or 1 (((s0 + s1) + s2) + s3, diagnosis only: the HIP kernels
     implement fold 0).  Returns the previous one."""
     return lib().uwo_set_gemm_fold(int(fold))
+
+
+def set_trig(trig):
+    """Sine / cosine of se3_exp for the calling thread (TRIG_ROUNDED / TRIG_LIBM); returns the previous one."""
+    return lib().uwo_set_trig(int(trig))
 
 
 def solve6(A, b):

@@ -219,8 +219,27 @@ void uwo_dense_points_ex(const uint16_t* depth, int stride, int w, int h, int lv
 /* SE(3) (Sophus SE3f / SO3f, Eigen quaternion kernels; S5, S6)                                */
 /* ------------------------------------------------------------------------------------------ */
 
-static inline float sin32(float x) { return (float)sin((double)x); }
-static inline float cos32(float x) { return (float)cos((double)x); }
+/* The arithmetic set, the gemm fold and the sine / cosine travel WITH THE CALL (uwo_ar): uwo_estimate_pose* take them from
+ * uwo_params and hand them down, so that a thread pool may run alignments of different sets side by side.  The per-stage entry
+ * points that have no parameter block (uwo_warp, uwo_residual_jacobian*, uwo_error, uwo_normal_equations, uwo_solve_delta,
+ * uwo_se3_exp) read the CALLING THREAD's defaults, which uwo_set_arith / uwo_set_gemm_fold / uwo_set_trig change for that thread
+ * alone (thread-local: nothing process-wide is left). */
+typedef struct uwo_ar { int arith, fold, trig; } uwo_ar;
+static _Thread_local uwo_ar t_ar = {UWO_ARITH_OPENCV, 0, UWO_TRIG_ROUNDED};
+
+/* S5.  Sophus calls std::sin / std::cos on float (so3.hpp:538-558, se3.hpp:738-740): libm's sinf / cosf, whose last bit is the
+ * libm build's (glibc 2.35's sinf is one ulp off the correctly rounded value at 0.063 % of the floats of [0, 0.5], its cosf at
+ * 0.0015 %: tools/trig/trig_sweep.c, exhaustive; the reference's Ubuntu 16.04 glibc 2.23 has a different sinf again).
+ * UWO_TRIG_ROUNDED (default, and what the HIP library computes): (float)sin((double)x), the correctly rounded value in all but
+ * double-rounding corner cases — a function of x alone, the same on every host.  UWO_TRIG_LIBM: THIS host's sinf / cosf, for
+ * measuring how much of a pose rides on that bit (tests/test_oracle.py). */
+static inline float sin32(uwo_ar ar, float x) { return ar.trig == UWO_TRIG_LIBM ? sinf(x) : (float)sin((double)x); }
+static inline float cos32(uwo_ar ar, float x) { return ar.trig == UWO_TRIG_LIBM ? cosf(x) : (float)cos((double)x); }
+int uwo_set_trig(int trig) {
+  int prev = t_ar.trig;
+  t_ar.trig = trig == UWO_TRIG_LIBM ? UWO_TRIG_LIBM : UWO_TRIG_ROUNDED;
+  return prev;
+}
 
 void uwo_se3_identity(float pose[7]) {
   /* Tracker.cpp:385: SE3(SO3::exp(0), 0) — Taylor branch of expAndTheta gives (0,0,0,1). */
@@ -267,7 +286,7 @@ static void quat_rotate(const float q[4], const float v[3], float o[3]) {
 }
 
 /* SO3::expAndTheta, so3.hpp:534-566.  epsilon<float> = 1e-5 (common.hpp:154-158). */
-static void so3_exp_theta(const float om[3], float q[4], float* theta_out) {
+static void so3_exp_theta(uwo_ar ar, const float om[3], float q[4], float* theta_out) {
   float theta_sq = om[0] * om[0] + om[1] * om[1] + om[2] * om[2];
   float theta = sqrtf(theta_sq);
   float half_theta = 0.5f * theta;
@@ -277,20 +296,20 @@ static void so3_exp_theta(const float om[3], float q[4], float* theta_out) {
     imag = 0.5f - (float)(1.0 / 48.0) * theta_sq + (float)(1.0 / 3840.0) * theta_po4;
     real = 1.0f - (float)(1.0 / 8.0) * theta_sq + (float)(1.0 / 384.0) * theta_po4;
   } else {
-    float s = sin32(half_theta);
+    float s = sin32(ar, half_theta);
     imag = s / theta;
-    real = cos32(half_theta);
+    real = cos32(ar, half_theta);
   }
   q[0] = imag * om[0]; q[1] = imag * om[1]; q[2] = imag * om[2]; q[3] = real;
   *theta_out = theta;
 }
 
 /* SE3::exp, se3.hpp:723-744.  xi = [upsilon(3), omega(3)]. */
-void uwo_se3_exp(const float xi[6], float pose[7]) {
+static void se3_exp_ar(uwo_ar ar, const float xi[6], float pose[7]) {
   const float* up = xi;
   const float* om = xi + 3;
   float q[4], theta;
-  so3_exp_theta(om, q, &theta);
+  so3_exp_theta(ar, om, q, &theta);
   float Om[9] = {0.0f, -om[2], om[1], om[2], 0.0f, -om[0], -om[1], om[0], 0.0f}; /* so3.hpp:618-627 */
   float Om2[9];
   for (int i = 0; i < 3; i++)
@@ -301,8 +320,8 @@ void uwo_se3_exp(const float xi[6], float pose[7]) {
     quat_to_R(q, V); /* se3.hpp:734 "V = so3.matrix()" */
   } else {
     float theta_sq = theta * theta;
-    float c1 = (1.0f - cos32(theta)) / theta_sq;
-    float c2 = (theta - sin32(theta)) / (theta_sq * theta);
+    float c1 = (1.0f - cos32(ar, theta)) / theta_sq;
+    float c2 = (theta - sin32(ar, theta)) / (theta_sq * theta);
     for (int i = 0; i < 9; i++) {
       float id = (i == 0 || i == 4 || i == 8) ? 1.0f : 0.0f;
       V[i] = (id + c1 * Om[i]) + c2 * Om2[i];
@@ -311,6 +330,7 @@ void uwo_se3_exp(const float xi[6], float pose[7]) {
   pose[0] = q[0]; pose[1] = q[1]; pose[2] = q[2]; pose[3] = q[3];
   for (int i = 0; i < 3; i++) pose[4 + i] = (V[3 * i] * up[0] + V[3 * i + 1] * up[1]) + V[3 * i + 2] * up[2];
 }
+void uwo_se3_exp(const float xi[6], float pose[7]) { se3_exp_ar(t_ar, xi, pose); }
 
 /* SE3::operator*= (se3.hpp:317-321) + SO3::operator*= with first-order renormalisation (so3.hpp:338-354). */
 void uwo_se3_mul(const float a[7], const float b[7], float out[7]) {
@@ -353,12 +373,6 @@ int uwo_se3_handoff(float pose[7], int scale_t) {
 /* warp + per-point terms                                                                       */
 /* ------------------------------------------------------------------------------------------ */
 
-/* The arithmetic set and the gemm fold travel WITH THE CALL (uwo_ar): uwo_estimate_pose* take them from uwo_params and hand them
- * down, so that a thread pool may run alignments of different sets side by side.  The per-stage entry points that have no
- * parameter block (uwo_warp, uwo_residual_jacobian*, uwo_error, uwo_normal_equations, uwo_solve_delta) read the CALLING THREAD's
- * defaults, which uwo_set_arith / uwo_set_gemm_fold change for that thread alone (thread-local: nothing process-wide is left). */
-typedef struct uwo_ar { int arith, fold; } uwo_ar;
-static _Thread_local uwo_ar t_ar = {UWO_ARITH_OPENCV, 0};
 int uwo_set_arith(int arith) {
   int prev = t_ar.arith;
   t_ar.arith = arith == UWO_ARITH_LEGACY ? UWO_ARITH_LEGACY : UWO_ARITH_OPENCV;
@@ -614,7 +628,7 @@ static float signed_hist_median(const int* q, int n, int lo, int hi) { /* first 
 
 void uwo_huber_weights(const float* r, int n, float* w) {
   const float k = 1.345f;
-  int* q = (int*)malloc(sizeof(int) * (size_t)(n > 0 ? n : 1));
+  int* q = (int*)calloc((size_t)(n > 0 ? n : 1), sizeof(int));
   for (int i = 0; i < n; i++) q[i] = (int)lrintf(r[i]);
   float med = signed_hist_median(q, n, -255, 255);
   for (int i = 0; i < n; i++) q[i] = abs(q[i] - (int)med);
@@ -840,7 +854,8 @@ int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const u
                              const float* const* tables, const int32_t* n_points,
                              float pose_out[7], uwo_trace* trace, int32_t* n_trace) {
   /* the call's arithmetic: the set from the parameters; the gemm fold from the parameters, or the calling thread's default */
-  const uwo_ar ar = {p->arith == UWO_ARITH_LEGACY ? UWO_ARITH_LEGACY : UWO_ARITH_OPENCV, (p->gemm_fold || t_ar.fold) ? 1 : 0};
+  const uwo_ar ar = {p->arith == UWO_ARITH_LEGACY ? UWO_ARITH_LEGACY : UWO_ARITH_OPENCV, (p->gemm_fold || t_ar.fold) ? 1 : 0,
+                     (p->trig == UWO_TRIG_LIBM || t_ar.trig == UWO_TRIG_LIBM) ? UWO_TRIG_LIBM : UWO_TRIG_ROUNDED};
   if (p->first_level >= p->n_levels || p->last_level < 0 || p->last_level > p->first_level) return UWO_ERR_INVALID_ARG;
   int cap = (trace && n_trace) ? *n_trace : 0;
   int nt = 0;
@@ -904,7 +919,7 @@ int uwo_estimate_pose_points(const uwo_params* p, const uwo_frame* prev, const u
       normal_equations_ar(ar, J, r, W, nv, p->gain, A, b); /* :554-561 */
       solve_delta_ar(ar, A, b, delta);                 /* :564 */
       float dT[7], np[7];
-      uwo_se3_exp(delta, dT);                          /* :574 */
+      se3_exp_ar(ar, delta, dT);                       /* :574 */
       uwo_se3_mul(pose, dT, np);
       memcpy(pose, np, sizeof(pose));
       if (tr) {

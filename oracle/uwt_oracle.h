@@ -49,7 +49,10 @@
  * Common to both sets:
  *  S2  N-long reductions accumulate exact f32 products in double and round to f32 once; Σr² is an exact integer
  *      (residuals are integer differences of u8).
- *  S5  sinf/cosf := (float)sin/cos((double)x); sqrtf, 1/x, a/b correctly rounded.
+ *  S5  sinf/cosf := (float)sin/cos((double)x) — the correctly rounded value, a function of x alone; the reference calls libm's
+ *      sinf / cosf, whose last bit is the libm build's (glibc 2.35: 1 ulp off at 0.063 % / 0.0015 % of the floats of [0, 0.5],
+ *      tools/trig/trig_sweep.c); uwo_params::trig = UWO_TRIG_LIBM evaluates this host's instead (diagnosis).  sqrtf, 1/x, a/b
+ *      correctly rounded (sqrtf == (float)sqrt((double)x) on every float: the same sweep).
  *  S6  Sophus / Eigen quaternion formulas: generic (non-SIMD) left-to-right f32, no FMA.
  *  S7  nearest-neighbour index round(x2) may equal the dimension (reference reads out of
  *      bounds, Tracker.cpp:450,472); the oracle clamps the index to dim-1.
@@ -78,6 +81,7 @@ enum {
 enum { UWO_WEIGHTS_IDENTITY = 0, UWO_WEIGHTS_TUKEY_REFERENCE = 1, UWO_WEIGHTS_HUBER = 2 };
 enum { UWO_SAMPLER_NEAREST = 0, UWO_SAMPLER_BILINEAR = 1 };
 enum { UWO_ARITH_OPENCV = 0, UWO_ARITH_LEGACY = 1 };
+enum { UWO_TRIG_ROUNDED = 0, UWO_TRIG_LIBM = 1 };   /* S5: (float)sin((double)x) (default) / this host's sinf, cosf */
 
 typedef struct uwo_params {
   int32_t width, height;     /* level-0 size */
@@ -99,6 +103,7 @@ typedef struct uwo_params {
   int32_t sampler;           /* UWO_SAMPLER_* (bilinear is a north-star extension, not in the reference) */
   int32_t arith;             /* UWO_ARITH_OPENCV (0, default: G1..G4 above) or UWO_ARITH_LEGACY (1: S1, S3, S4) */
   int32_t gemm_fold;         /* 0 (default): GEMMSingleMul's partial sums folded s0 + ((s1 + s2) + s3); 1: ((s0 + s1) + s2) + s3 */
+  int32_t trig;              /* UWO_TRIG_ROUNDED (0, default) or UWO_TRIG_LIBM (1: the host libm's sinf / cosf; diagnosis, S5) */
 } uwo_params;
 
 typedef struct uwo_level {
@@ -160,6 +165,8 @@ int uwo_set_arith(int arith);
 /* fold of GEMMSingleMul's four partial sums for the calling thread: 0 (default) s0 + ((s1 + s2) + s3), 1 ((s0 + s1) + s2) + s3;
  * returns the previous.  uwo_estimate_pose* use fold 1 when uwo_params::gemm_fold or the calling thread's default says so. */
 int uwo_set_gemm_fold(int fold);
+/* sine / cosine of the SE(3) exponential for the calling thread: UWO_TRIG_ROUNDED (default) or UWO_TRIG_LIBM; returns the previous */
+int uwo_set_trig(int trig);
 
 /* per-point loop of Tracker::EstimatePose, Tracker.cpp:432-490.
  * J (n x 6) and r (n) receive the valid rows compacted; idx (n, optional) their point index. */

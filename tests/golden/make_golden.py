@@ -8,7 +8,7 @@ scipy.ndimage correlate) live in tests/test_oracle.py.
 Every arithmetic-dependent vector exists twice: under its plain key for the default set (OpenCV's generic paths,
 O.ARITH_OPENCV) and under "legacy_<key>" for the legacy set (tests/conftest.py::GoldenView picks by the active set).
 
-Run from the repo root:  python tests/golden/make_golden.py
+Run from the repo root:  python tests/golden/make_golden.py [output directory, default: tests/golden]
 """
 import importlib
 import os
@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 from oracle import oracle as O  # noqa: E402
 
 synth = importlib.import_module("uw-slam_amd.synth")
-OUT = os.path.dirname(os.path.abspath(__file__))
+OUT = sys.argv[1] if len(sys.argv) > 1 else os.path.dirname(os.path.abspath(__file__))   # (another directory: tools/sanitize_cpu.sh)
 
 
 def pack_trace(tr):

@@ -544,3 +544,38 @@ def test_two_threads_with_different_arithmetic_sets(O, synth):
         t_.join()
     for a in (0, 1):
         assert len(out[a]) == 12 and all(np.array_equal(p, alone[a]) for p in out[a])
+
+
+@pytest.mark.one_arith
+def test_sine_of_the_exponential_rounded_or_libm(O, synth):
+    """S5: Sophus calls libm's sinf / cosf (so3.hpp:538-558), whose last bit is the libm build's; the oracle and the HIP library
+    compute the correctly rounded (float)sin((double)x).  uwo_params::trig = TRIG_LIBM evaluates this host's sinf / cosf instead:
+    at x = 0x1.d12ed2p-12 — the smallest float where glibc 2.35's sinf is not the rounded value (tools/trig/trig_sweep.c,
+    exhaustive over [0, 0.5]) — the exponential's quaternion moves by one ulp, by no more anywhere, and whole alignments,
+    whose Gauss-Newton rotation steps stay below 1e-2 rad (842 such floats of 4e7 there), keep their poses."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    libm.sinf.restype = ctypes.c_float
+    libm.sinf.argtypes = [ctypes.c_float]
+    x = float.fromhex("0x1.d12ed2p-12")
+    xi = np.array([0.1, 0.2, 0.3, 2 * x, 0, 0], np.float32)
+    a = O.se3_exp(xi)
+    prev = O.set_trig(O.TRIG_LIBM)
+    try:
+        b = O.se3_exp(xi)
+    finally:
+        O.set_trig(prev)
+    rounded = np.float32(np.sin(np.float64(np.float32(x))))
+    host = np.float32(libm.sinf(x))
+    assert a[0] == np.float32(rounded / np.float32(2 * x)) * np.float32(2 * x)          # imag * omega_x, imag = sin(theta / 2) / theta
+    if host != rounded:                                                                  # (a libm whose sinf is correctly rounded here: nothing to see)
+        assert abs(int(a[:1].view(np.uint32)[0]) - int(b[:1].view(np.uint32)[0])) == 1 and np.array_equal(a[1:], b[1:])
+    else:
+        assert np.array_equal(a, b)
+    w, h, f = 160, 96, 131.25
+    for s in range(6):
+        ref, tgt, _, _, _ = synth.render_pair(w, h, f, f, 79.5, 47.5, seed=9000 + s)
+        for over in (dict(n_levels=4, first_level=3, last_level=0, max_iters=10, early_exit=0), {}):
+            p0 = O.align_pair(O.default_params(w, h, f, f, 79.5, 47.5, trig=O.TRIG_ROUNDED, **over), ref, tgt)[1]
+            p1 = O.align_pair(O.default_params(w, h, f, f, 79.5, 47.5, trig=O.TRIG_LIBM, **over), ref, tgt)[1]
+            assert np.abs(p0.astype(np.float64) - p1.astype(np.float64)).max() <= 1e-6

@@ -36,10 +36,10 @@ inline void blur_axis(std::vector<float>& img, int w, int h, bool horizontal, co
       float s = 0.f;
       for (int i = -r; i <= r; i++) {
         int xx = horizontal ? x + i : x, yy = horizontal ? y : y + i;
-        if (xx < 0) xx = -xx - 1;
-        if (xx >= w) xx = 2 * w - 1 - xx;
-        if (yy < 0) yy = -yy - 1;
-        if (yy >= h) yy = 2 * h - 1 - yy;
+        // symmetric reflection, folded until inside: one fold is all a side of 12 pixels or more needs (the kernel reaches 12), a
+        // smaller image is folded again (found by tools/sanitize_cpu.sh: a 9 x 7 frame read outside its rows)
+        while (xx < 0 || xx >= w) xx = xx < 0 ? -xx - 1 : 2 * w - 1 - xx;
+        while (yy < 0 || yy >= h) yy = yy < 0 ? -yy - 1 : 2 * h - 1 - yy;
         s += k[i + r] * img[(size_t)yy * w + xx];
       }
       out[(size_t)y * w + x] = s;
