@@ -95,7 +95,11 @@ def parse_args(argv=None):
                     help="the reference's EstimatePose constants: 5 levels, iterate 4..1, <= 50 iterations, early exit "
                          "(src/Tracker.cpp:364-372); not the headline workload")
     ap.add_argument("--tuning", default="", help="launch-shape switches for A/B runs: comma-separated uwt_tuning fields, e.g. "
-                    "residual_plane=0,split=1 (never changes results; include/uwt.h)")
+                    "typed_loads=0,split=1 (never changes results; include/uwt.h)")
+    ap.add_argument("--dump-poses", default="", help="rank 0 writes the last step's poses of the whole job, global pair order, [total, 7] float32 (.npy)")
+    ap.add_argument("--n1-value", type=float, default=0.0,
+                    help="alignments/s of the same workload on ONE GPU (a line of this program at --gpus 1): a multi-GPU line then "
+                         "carries efficiency_vs_n1 = value / (n_gpus x this) beside per_rank_ms")
     ap.add_argument("--cpu-pairs", type=int, default=96,
                     help="alignments timed on the CPU oracle, 1 thread (rank 0, N=1 only; 0 = skip); ~10 s at 640x480")
     ap.add_argument("--no-profile", action="store_true",
@@ -219,7 +223,11 @@ def other_arith_figure(capi, params, pair_block, Pa, steps, warmup, dev):
             "ms_per_step": round(1e3 * dt / steps, 4), "pairs": Pa, "steps": steps}
 
 
-def main(args):
+def main(args, standin=None):
+    """One rank of the job.  `standin` (tests only: tests/test_bench_ranks_cpu.py) replaces the HIP library's binding by an object
+    with the same Context surface that fills the pose buffers from the uploaded frames on the CPU: the rank body — sharding,
+    uploads in blocks, the step loop through GatherPipeline, the barrier, the MAX-reduce of the step time, the JSON line — then
+    runs over gloo on a machine without a GPU.  Never set by this program itself: without it the HIP library is required."""
     # A stalled run ends with every thread's Python traceback instead of sitting there until the caller's clock runs out.
     faulthandler.dump_traceback_later(int(os.environ.get("UWT_BENCH_WATCHDOG_S", "1500")), exit=True)
 
@@ -231,27 +239,35 @@ def main(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE %d" % (args.gpus, world))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    if torch.cuda.device_count() <= local_rank:
-        raise SystemExit("bench.py: rank %d needs device %d, %d visible" % (rank, local_rank, torch.cuda.device_count()))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if standin is None:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+        if torch.cuda.device_count() <= local_rank:
+            raise SystemExit("bench.py: rank %d needs device %d, %d visible" % (rank, local_rank, torch.cuda.device_count()))
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+    else:
+        dev = torch.device("cpu")
     use_dist = world > 1 or "RANK" in os.environ          # under a launcher the RCCL path runs even with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if standin is None:
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
-    capi = importlib.import_module("uw-slam_amd.capi")
+    capi = standin if standin is not None else importlib.import_module("uw-slam_amd.capi")
     synth = importlib.import_module("uw-slam_amd.synth")
     distm = importlib.import_module("uw-slam_amd.dist")
 
     w, h = args.width, args.height
     strong = args.total_pairs > 0
     total = args.total_pairs if strong else args.pairs * world
+    if total < world:   # (decided from the arguments alone: every rank leaves here, none is left waiting in a collective)
+        raise SystemExit("bench.py: %d pairs over %d GPUs: a rank would own no pair" % (total, world))
     my_pairs = distm.shard_round_robin(total, world, rank)     # global pair ids owned by this rank: i mod N == rank
     P = len(my_pairs)
     if P < 1:
@@ -277,7 +293,12 @@ def main(args):
     # form of a batch overlaps launches of half the size, whose durations a trace cannot tell apart from waiting
     tuning = dict(split=1) if _under_profiler() else {}
     for kv in filter(None, args.tuning.split(",")):
-        k, v = kv.split("=")
+        if "=" not in kv:
+            raise SystemExit("bench.py: --tuning takes field=value items separated by commas; got %r" % kv)
+        k, v = kv.split("=", 1)
+        if k.strip() not in [f[0] for f in capi.Tuning._fields_ if f[0] != "reserved"]:
+            raise SystemExit("bench.py: --tuning: no uwt_tuning field %r (include/uwt.h: %s)"
+                             % (k.strip(), ", ".join(f[0] for f in capi.Tuning._fields_ if f[0] != "reserved")))
         tuning[k.strip()] = int(v)
     ctx = capi.Context(params, tuning=tuning or None)
 
@@ -338,10 +359,12 @@ def main(args):
 
     def fence():
         ctx.sync()
-        torch.cuda.synchronize()
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
-            torch.cuda.synchronize()
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
 
     t_w = time.perf_counter()
     for _ in range(args.warmup):
@@ -353,7 +376,13 @@ def main(args):
         step()
     fence()
     dt = time.perf_counter() - t0
+    per_rank_ms = [1e3 * dt / args.steps]
     if use_dist:
+        # every rank's own time for the K steps (barrier to barrier), then the job's: the slowest rank's
+        mine_t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        all_t = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(all_t, mine_t)
+        per_rank_ms = [round(1e3 * float(v) / args.steps, 4) for v in all_t.cpu().tolist()]
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -447,6 +476,8 @@ def main(args):
         },
     }
     if rank == 0:
+        if args.dump_poses:
+            np.save(args.dump_poses, all_poses)
         if use_dist:
             # every rank's block must have arrived in global pair order: rank 0's own pairs sit at i = rank + k * world,
             # and pairs that repeat a distinct input (same seed modulo the tiling) must carry identical poses
@@ -455,6 +486,12 @@ def main(args):
             assert np.isfinite(all_poses).all() and (np.abs(np.linalg.norm(all_poses[:, :4], axis=1) - 1.0) < 1e-3).all()
             out["config"]["gather"] = {"collective_ran": bool(pipe.collective), "world": world,
                                        "rank0_block_bitwise_equal_to_its_own_poses": True}
+            # what the driver's command measures: `--gpus N` with the default --pairs keeps 1024 pairs PER RANK (weak scaling:
+            # 8 ranks = BASELINE config 4's 8192 pairs); --total-pairs T fixes the job instead (strong)
+            out["per_rank_ms"] = per_rank_ms
+            if args.n1_value > 0:
+                out["efficiency_vs_n1"] = round(value / (world * args.n1_value), 4)
+                out["n1_value"] = args.n1_value
         # SURVEY §8(d) secondary figure: the same step with the batch's frames crossing PCIe first (never `value`)
         out["h2d_inclusive"] = {"value": round(P / (upload_s + dt / args.steps), 2), "unit": "alignments/s per GPU",
                                 "upload_ms": round(upload_s * 1e3, 2), "upload_GBs": round(upload_bytes / upload_s / 1e9, 2),

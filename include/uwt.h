@@ -158,8 +158,10 @@ int uwt_create(const uwt_params* p, uwt_ctx** out);
 int uwt_update_params(uwt_ctx* ctx, const uwt_params* p);
 /* the context's current parameters */
 int uwt_get_params(const uwt_ctx* ctx, uwt_params* out);
-/* the context's launch-shape switches (uwt_tuning); uwt_set_tuning waits for the context's work in flight, validates and
- * clamps, and applies to every later call */
+/* the context's launch-shape switches (uwt_tuning); uwt_set_tuning waits for the context's work in flight and applies to every
+ * later call.  A value outside its range (split 1..4, split_min >= 1, split_min_px >= 1, stream_bytes >= 0, tail_update 0..2,
+ * target_blocks 0..2^20, coarse_batch_px 0..2^24, first_poll 1..2^20, chained -1..1) returns UWT_ERR_INVALID_ARG and changes
+ * nothing; the on / off switches take any non-zero value as 1. */
 int uwt_get_tuning(const uwt_ctx* ctx, uwt_tuning* out);
 int uwt_set_tuning(uwt_ctx* ctx, const uwt_tuning* t);
 /* Tracker::~Tracker (src/Tracker.cpp:280-293) */

@@ -82,6 +82,7 @@ def _pipeline_worker(rank, world, port, n_pairs, steps, q):
             buf.copy_(torch.arange(7, dtype=torch.float32)[None, :] + 10.0 * torch.from_numpy(mine).to(torch.float32)[:, None] + 1000.0 * k)
         glob = pipe.step(align)
         assert pipe.wait() is glob                                   # (CPU: nothing to wait for; the handle is the same buffer)
+        pipe.release()                                               # (CPU: nothing to order either)
         seen.append(glob.clone().numpy())
         assert np.array_equal(pipe.last_local().numpy()[:, 0], 10.0 * mine + 1000.0 * k)
     assert len(bufs) == min(2, steps)                                # the two pose buffers take turns

@@ -432,6 +432,47 @@ print("ok")
 
 
 @pytest.mark.gpu
+def test_gather_pipeline_consumer_on_its_own_stream_wait_and_release():
+    """GatherPipeline.wait() / release() (uw-slam_amd/dist.py): a consumer that reads a step's gathered poses on a stream of its own
+    — held up there by a long-running kernel — while two more steps are enqueued.  The step that reuses the gatherer's buffer (the
+    next but one) must not overwrite it before the consumer's queued read has run: wait() orders the consumer behind the exchange,
+    release() orders the buffer's next writer behind the consumer."""
+    code = r'''
+import os, importlib, torch, torch.distributed as dist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", RANK="0", WORLD_SIZE="1")
+dev = torch.device("cuda", 0); torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=dev)
+d = importlib.import_module("uw-slam_amd.dist")
+n = 64
+work = torch.cuda.Stream()                      # stands for the context's stream
+pipe = d.GatherPipeline(n, n, dev, work.cuda_stream)
+consumer = torch.cuda.Stream()
+def align_of(k):
+    def align(buf):
+        with torch.cuda.stream(work):
+            buf.copy_(torch.full((n, 7), float(k), device=dev))
+    return align
+for trial in range(5):
+    base = 10 * trial
+    g = pipe.step(align_of(base))
+    pipe.wait(consumer)
+    with torch.cuda.stream(consumer):
+        torch.cuda._sleep(400_000_000)          # ~0.2 s: the read below is still queued when the next two steps are enqueued
+        seen = g.clone()
+    pipe.release(consumer)
+    pipe.step(align_of(base + 1))
+    pipe.step(align_of(base + 2))               # reuses the gatherer buffer `g` lives in
+    torch.cuda.synchronize()
+    assert bool((seen == float(base)).all()), (trial, seen[0])
+    assert bool((pipe.gathered == float(base + 2)).all())
+dist.destroy_process_group()
+print("ok")
+'''
+    r = _run([sys.executable, "-c", code])
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stderr.decode()[-2000:]
+
+
+@pytest.mark.gpu
 def test_update_launch_form_matches_the_tail_update():
     """Where a batch runs as two parts on two streams the Gauss-Newton update runs in the tail of the evaluation's own launch
     (tail_update_wave: the pair's last block folds the records and solves); elsewhere a k_gn_update launch follows every

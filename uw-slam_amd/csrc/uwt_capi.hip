@@ -427,8 +427,8 @@ int launch_iterate(uwt_ctx* c, const ResidualArgs& a, const IterArgs& ia, int n_
   return UWT_OK;
 }
 
-// The chained form of Tracker::EstimatePose for a batch (dense points, nearest-neighbour sampler, identity weights, level
-// widths divisible by 4): one k_iterate launch per iteration — each block first applies the update of the previous
+// The chained form of Tracker::EstimatePose for a batch (dense points, nearest-neighbour sampler, identity weights, any level
+// size): one k_iterate launch per iteration — each block first applies the update of the previous
 // evaluation (and the level hand-off when a level begins), then evaluates — and one k_finish at the end; levels x
 // iterations + 1 launches instead of 2 x levels x iterations + levels + 2.
 int enqueue_estimate_chained(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats, const hipEvent_t* level_ready) {
@@ -1138,9 +1138,9 @@ int uwt_get_tuning(const uwt_ctx* c, uwt_tuning* out) {
 int uwt_set_tuning(uwt_ctx* c, const uwt_tuning* t) {
   if (!c || !t) return UWT_ERR_INVALID_ARG;
   if (t->split < 1 || t->split > uwt_ctx::kMaxParts || t->split_min < 1 || t->split_min_px < 1 || t->stream_bytes < 0 ||
-      t->tail_update < 0 || t->tail_update > 2 || t->target_blocks < 0 || t->coarse_batch_px < 0 || t->first_poll < 1 ||
-      t->chained < -1 || t->chained > 1)
-    return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_tuning: value out of range");
+      t->tail_update < 0 || t->tail_update > 2 || t->target_blocks < 0 || t->target_blocks > (1 << 20) || t->coarse_batch_px < 0 ||
+      t->coarse_batch_px > (1 << 24) || t->first_poll < 1 || t->first_poll > (1 << 20) || t->chained < -1 || t->chained > 1)
+    return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_tuning: value out of range");   // (first_poll is doubled and incremented by the schedulers: bounded well inside int)
   (void)hipSetDevice(c->p.device);
   HIPCHK(c, hipStreamSynchronize(c->stream));
   c->tn = *t;

@@ -95,6 +95,7 @@ class GatherPipeline:
             self.gather_stream = torch.cuda.Stream(device=device)
             self.align_done = [torch.cuda.Event() for _ in range(self.N_BUF)]
             self.gather_done = [torch.cuda.Event() for _ in range(self.N_BUF)]
+            self.consumed = [None] * self.N_BUF    # release(): a consumer's reads of gatherers[b]'s output have been enqueued up to here
 
     @property
     def collective(self):
@@ -111,6 +112,9 @@ class GatherPipeline:
             self.align_done[b].record(self.ctx_stream)
             with self.torch.cuda.stream(self.gather_stream):
                 self.gather_stream.wait_event(self.align_done[b])
+                if self.consumed[b] is not None:   # a consumer on another stream may still be reading this gatherer's output
+                    self.gather_stream.wait_event(self.consumed[b])
+                    self.consumed[b] = None
                 self.gathered = self.gatherers[b].gather(self.poses[b])   # RCCL all_gather over xGMI + permutation to global order
                 self.gather_done[b].record(self.gather_stream)
         else:
@@ -125,9 +129,21 @@ class GatherPipeline:
     def wait(self, stream=None):
         """Orders `stream` (default: torch's current stream) behind the exchange of the last step(): the tensor step() returned
         — a buffer of the gatherer, overwritten by the next step but one — may be read on that stream after this call, and only
-        until the next-but-one step().  step() itself returns with the all_gather and the un-shuffle still in flight on the
+        until the next-but-one step() (a consumer whose reads may still be queued by then says so with release()).  step() itself returns with the all_gather and the un-shuffle still in flight on the
         pipeline's private stream; without this (or a device synchronisation, as bench.py's fence) a consumer races them.
         No-op on a CPU device (the gloo form runs synchronously)."""
         if self.cuda and self.pending[self.last]:
             (stream or self.torch.cuda.current_stream()).wait_event(self.gather_done[self.last])
         return self.gathered
+
+    def release(self, stream=None):
+        """The other half of wait(): call it once the kernels that read the tensor wait() returned have been ENQUEUED on `stream`
+        (default: torch's current stream).  It records how far that stream has come; the step that next writes the same gatherer
+        buffer (the next but one) makes the pipeline's private stream wait for that point before its all_gather and un-shuffle
+        overwrite the buffer.  Without it the "valid until the next-but-one step()" rule of wait() is host order only: a consumer
+        kernel still queued on its stream when that step is enqueued could be overtaken.  bench.py needs neither (it fences the
+        device before it reads); a consumer that pipelines steps against its own stream needs both.  No-op on a CPU device."""
+        if self.cuda and self.pending[self.last]:
+            ev = self.torch.cuda.Event()
+            ev.record(stream or self.torch.cuda.current_stream())
+            self.consumed[self.last] = ev
