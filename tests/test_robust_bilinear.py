@@ -196,3 +196,50 @@ def test_tracker_mirror_weight_helpers(O):
     assert np.array_equal(gx, ox) and np.array_equal(gy, oy)
 
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(160, 96), (320, 240), (166, 98)], ids=lambda s: "%dx%d" % s)
+@pytest.mark.parametrize("mode", ["tukey", "huber", "bilinear_huber"])
+@pytest.mark.parametrize("sched", ["fixed", "reference"])
+def test_chained_robust_flow_is_the_launch_per_stage_flow(capi, O, synth, size, mode, sched):
+    """A few pairs under robust weights (round 6): the update of an evaluation runs at the head of the next evaluation's scale pass
+    (k_hist_iterate) instead of in a launch of its own, the last one in k_finish — two launches per evaluation instead of three.
+    uwt_tuning::chained = 0 keeps the three-launch form.  Both give the oracle's poses and iteration counts, one to four pairs,
+    fixed and early-exit schedules, with the coarse levels in one block (Tukey / Huber over the nearest sampler) or not (bilinear)."""
+    w, h = size
+    f = 525.0 * w / 640.0
+    intr = (f, f * 0.996, w / 2 - 0.5, h / 2 - 0.5)
+    over = dict(has_depth=1, weights={"tukey": 1, "huber": 2, "bilinear_huber": 2}[mode], sampler=int(mode == "bilinear_huber"))
+    over.update(dict(n_levels=4, first_level=3, last_level=0, max_iters=5, early_exit=0) if sched == "fixed" else {})
+    n = 4
+    pairs = [synth.render_pair(w, h, *intr, seed=7700 + s, with_depth=True, max_t=0.012, max_deg=0.6) for s in range(n)]
+    po = O.default_params(w, h, *intr, **over)
+    want = [O.align_pair(po, p[0], p[1], p[2], want_trace=True) for p in pairs]
+    frames = np.stack([f_ for p in pairs for f_ in p[:2]])
+    depth = np.stack([p[2] for p in pairs for _ in (0, 1)])
+    got = {}
+    for chained in (-1, 0):
+        ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over), tuning=dict(chained=chained))
+        ctx.upload_frames(0, frames, depth)
+        ctx.build_pyramids(0, 2 * n)
+        ctx.apply_gradient(0, 2 * n)
+        for count in (1, 2, 4):
+            for rep in range(2):       # twice: the histograms and tickets are left clean for the next call
+                ref = np.arange(count) * 2
+                poses, stats = ctx.estimate_pose_batch(ref, ref + 1)
+                got[(chained, count, rep)] = (poses.copy(), [s["iterations"] for s in stats], [s["status"] for s in stats])
+        ctx.close()
+    for count in (1, 2, 4):
+        for rep in range(2):
+            a, b = got[(-1, count, rep)], got[(0, count, rep)]
+            assert np.array_equal(a[0].view(np.uint32), b[0].view(np.uint32)) and a[1] == b[1] and a[2] == b[2], (count, rep)
+            for i in range(count):
+                st, pose_cpu, tr = want[i]
+                assert a[2][i] == st
+                if st == 0:
+                    assert a[1][i] == len(tr), (count, i, a[1][i], len(tr))
+                    if mode == "bilinear_huber":
+                        assert np.abs(a[0][i] - pose_cpu).max() <= 1e-4
+                    else:
+                        assert np.array_equal(a[0][i].view(np.uint32), pose_cpu.view(np.uint32)), (count, i)

@@ -571,9 +571,116 @@ static bool takes_chained_flow(const uwt_ctx* c, int n_pairs) {
   return c->p.accumulate_f64 != 0 && c->p.sampler == 0 && c->p.weights == 0 && (c->tn.chained > 0 || (c->tn.chained < 0 && n_pairs <= few));
 }
 
+// The chained flow under robust weights (round 6): a few pairs per call — the drop-in use with the Tukey / Huber weighting on.  An
+// evaluation is two launches instead of three (scale pass, weighted sums, update): the update of evaluation k — and the level
+// hand-off where a level ends — runs at the head of evaluation k + 1's scale pass (k_hist_iterate), the last one in k_finish.
+// 640 x 480, one pair, 4 x 10: 91 launches -> 61.  Same device functions as the launches it replaces: the same poses bit for bit.
+static bool takes_chained_general(const uwt_ctx* c, int n_pairs) {
+  return c->p.accumulate_f64 != 0 && c->p.weights != 0 && !c->profiling && !c->compute_only &&
+         (c->tn.chained > 0 || (c->tn.chained < 0 && n_pairs <= 4));
+}
+
+int enqueue_estimate_chained_general(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats, const hipEvent_t* level_ready) {
+  const uwt_params& p = c->p;
+  uint32_t* recs[2] = {c->partials, c->partials2};
+  PairState* states[2] = {c->state, c->state2};
+  int rp = 0, sp = 0;            // parity of the records / states the NEXT evaluation writes
+  IterArgs ia;
+  std::memset(&ia, 0, sizeof(ia));
+  ia.u.max_iters = p.max_iters;
+  ia.u.early_exit = p.early_exit;
+  ia.u.epsilon = p.epsilon;
+  ia.u.gain = p.gain;
+  ia.u.general = 1;
+  ia.u.legacy_solve = p.arith == UWT_ARITH_LEGACY ? 1 : 0;
+  ia.scale_t = p.handoff_scale_t;
+  ia.initial_error = p.initial_error;
+  // the per-pair residual histograms (and the ticket word of each) start an alignment all-zero; every scale pass leaves them so
+  HIPCHK(c, hipMemsetAsync(c->hist, 0, sizeof(unsigned int) * kHistBins * n_pairs, c->stream));
+  bool first = true, after_coarse = false;
+  int prev_slices = 0, prev_k = 0, prev_lvl = p.first_level;
+  int start_lvl = p.first_level;
+  // the coarsest levels a single block evaluates, each to its end in one launch (k_coarse_weighted), one finer level at least
+  // left for the chained launches
+  while (c->tn.coarse_weighted && p.sampler == 0 && start_lvl > p.last_level && c->lv[start_lvl].ng <= kCoarseMaxPixels) {
+    if (level_ready && start_lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(c->stream, level_ready[start_lvl], 0));  // its gradients
+    CoarseArgs ca;
+    std::memset(&ca, 0, sizeof(ca));
+    ca.lv[0] = residual_args(c, start_lvl);
+    ca.lv[0].state = nullptr;
+    ca.level_id[0] = start_lvl;
+    ca.n_levels = 1;
+    ca.u = ia.u;
+    ca.state_out = states[sp ^ 1];     // where the first k_hist_iterate launch looks for its state
+    ca.scale_t = ia.scale_t;
+    ca.initial_error = ia.initial_error;
+    ca.resume = after_coarse ? 1 : 0;
+    uwt::launch_coarse_level(c->stream, launch_sel(c), ca, n_pairs, p.weights);
+    HIPCHK(c, hipGetLastError());
+    start_lvl--;
+    after_coarse = true;
+  }
+  for (int lvl = start_lvl; lvl >= p.last_level; lvl--) {
+    if (level_ready && lvl != p.first_level) HIPCHK(c, hipStreamWaitEvent(c->stream, level_ready[lvl], 0));  // its gradients
+    ResidualArgs ra = residual_args(c, lvl);
+    {  // slicing follows the batch, as in enqueue_estimate
+      const int n_groups = c->lv[lvl].ng / c->vecl[lvl];
+      int want = ((c->tn.target_blocks ? c->tn.target_blocks : 4096) + n_pairs - 1) / n_pairs;
+      want = std::max(1, std::min(want, c->slices[lvl]));
+      const int gpt = (n_groups + want * kBlock - 1) / (want * kBlock);
+      ra.groups_per_block = gpt * kBlock;
+      ra.slices = (n_groups + ra.groups_per_block - 1) / ra.groups_per_block;
+    }
+    int next_poll = c->tn.first_poll;
+    for (int k = 0; k < p.max_iters; k++) {
+      ia.mode = first ? (after_coarse ? 3 : 0) : (k == 0 ? 2 : 1);
+      ia.u.partials = recs[rp ^ 1];
+      ia.u.slices = prev_slices;
+      ia.u.k = prev_k;
+      ia.prev_lvl = prev_lvl;
+      ia.state_in = states[sp ^ 1];
+      ia.state_out = states[sp];
+      ra.partials = recs[rp];
+      ra.state = states[sp];           // the weighted launch reads the state the scale pass has just published
+      // the update inside launch k belongs to evaluation k - 1 (see enqueue_estimate_chained)
+      const bool poll = p.early_exit && k == next_poll && k < p.max_iters;
+      ia.u.active = poll ? c->d_active : nullptr;
+      if (poll) HIPCHK(c, hipMemsetAsync(c->d_active, 0, sizeof(int), c->stream));
+      uwt::launch_hist_iterate(c->stream, launch_sel(c), ra, ia, n_pairs, p.sampler, p.weights, c->hist, c->scale);
+      uwt::launch_weighted(c->stream, launch_sel(c), ra, n_pairs, p.sampler, p.weights);
+      HIPCHK(c, hipGetLastError());
+      first = false;
+      prev_slices = ra.slices;
+      prev_k = k;
+      prev_lvl = lvl;
+      rp ^= 1;
+      sp ^= 1;
+      if (poll) {  // reference-mode early exit: stop launching once every pair has left this level
+        HIPCHK(c, hipMemcpyAsync(c->h_active, c->d_active, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (*c->h_active == 0) break;
+        next_poll *= 2;
+      }
+    }
+  }
+  // the last evaluation's update, the last level's hand-off, results
+  ia.mode = 2;
+  ia.u.partials = recs[rp ^ 1];
+  ia.u.slices = prev_slices;
+  ia.u.k = prev_k;
+  ia.u.active = nullptr;
+  ia.prev_lvl = prev_lvl;
+  ia.state_in = states[sp ^ 1];
+  ia.state_out = ia.state_in == c->state ? c->state2 : c->state;
+  uwt::launch_finish(c->stream, ia, n_pairs, d_poses, d_stats);
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
 int enqueue_estimate(uwt_ctx* c, int n_pairs, float* d_poses, StatsOut* d_stats, const hipEvent_t* level_ready = nullptr) {
   const uwt_params& p = c->p;
   if (takes_chained_flow(c, n_pairs)) return enqueue_estimate_chained(c, n_pairs, d_poses, d_stats, level_ready);
+  if (takes_chained_general(c, n_pairs)) return enqueue_estimate_chained_general(c, n_pairs, d_poses, d_stats, level_ready);
   const int tb = 128;
   const bool general = p.sampler != 0 || p.weights != 0;
   // Slicing follows the batch: the create-time slicing (kGroupsPerThread) gives a single pair enough blocks to spread

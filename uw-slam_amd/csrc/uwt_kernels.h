@@ -2242,20 +2242,18 @@ __device__ __forceinline__ void hist_groups(const LevelK& L, const WarpK& K, con
   }
 }
 
-template <int AR, int VEC, bool DEPTH, int SAMPLER, bool RAGGED = false>
-__global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, unsigned int* __restrict__ hist, PairScale* __restrict__ scale_out,
-                                                         int weights) {
-  const int pair = blockIdx.y + a.pair_base;
-  const PairState st = a.state[pair];
-  if (st.level_done || st.status) return;
+// the scale pass of one block: slice blockIdx.x of `pair` at `pose` (the body of k_resid_hist_v and of k_hist_iterate)
+template <int AR, int VEC, bool DEPTH, int SAMPLER, bool RAGGED>
+__device__ __forceinline__ void hist_block(const ResidualArgs& a, const int pair, const Pose& pose, const int ref_slot, const int tgt_slot,
+                                           unsigned int* __restrict__ hist, PairScale* __restrict__ scale_out, int weights) {
   __shared__ unsigned int h[kHistBins * kHistRep];
   __shared__ int s_last;
   for (int i = threadIdx.x; i < kHistRep * kHistBins; i += kBlock) h[i] = 0;
   __syncthreads();
   WarpK K;
-  warp_setup<AR>(st.pose, K);
+  warp_setup<AR>(pose, K);
   const LevelK L = a.L;
-  const size_t ref_off = (size_t)a.ref_slots[pair] * L.n, tgt_off = (size_t)a.tgt_slots[pair] * L.n;
+  const size_t ref_off = (size_t)ref_slot * L.n, tgt_off = (size_t)tgt_slot * L.n;
   const uint8_t* __restrict__ I1 = a.img + ref_off;
   const uint8_t* __restrict__ I2 = a.img + tgt_off;
   const uint16_t* __restrict__ DP = DEPTH ? a.depth + ref_off : nullptr;
@@ -2292,6 +2290,15 @@ __global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, u
   if (lane == 0) atomicExch(&gh[kHistTicketWord], 0u);
   const PairScale sc = wave_scale(mine, h, weights == kWeightsTukeyRef, lane);   // (h: every wave of the block is past its flush)
   if (lane == 0) scale_out[pair] = sc;
+}
+
+template <int AR, int VEC, bool DEPTH, int SAMPLER, bool RAGGED = false>
+__global__ __launch_bounds__(kBlock) void k_resid_hist_v(const ResidualArgs a, unsigned int* __restrict__ hist, PairScale* __restrict__ scale_out,
+                                                         int weights) {
+  const int pair = blockIdx.y + a.pair_base;
+  const PairState st = a.state[pair];
+  if (st.level_done || st.status) return;
+  hist_block<AR, VEC, DEPTH, SAMPLER, RAGGED>(a, pair, st.pose, a.ref_slots[pair], a.tgt_slots[pair], hist, scale_out, weights);
 }
 
 // weighted / bilinear accumulation: J <- w·J, r <- gain·r, A = Σ(wJ)(wJ)ᵀ, jtr = Σ(wJ)·((gain r)·w) (src/Tracker.cpp:554-561),
@@ -2383,7 +2390,8 @@ struct UpdateArgs {
 };
 
 constexpr int kUpdateBlock = 256;   // threads of an updating block: all fold the records, wave 0 solves
-constexpr int kFoldBatch = 16;      // record loads a thread keeps in flight (8 x 16 = 128 records per round trip)
+constexpr int kFoldBatch = 16;      // record loads a thread keeps in flight (8 x 16 = 128 records per round trip; 20 — every fold of up to kMaxSlices records one
+                                    // round trip — was measured in round 6: no gain at 150 records, the reference schedule 4 % slower: profiles/r06/EXPERIMENTS.md)
 constexpr int kUpdateLdsBytes = 2 * 8 * 32 * 8 + 512;   // part sums (two readings) + sums, integer sums, the state to broadcast
 
 // One wave, uniform values: from the evaluation's folded sums (sums[0..26]: JtJ upper triangle and Jtr, sums[27]: the
@@ -2651,6 +2659,26 @@ __global__ __launch_bounds__(kBlock) void k_iterate(const ResidualArgs a, const 
   if (st.level_done || st.status) return;
   __syncthreads();   // the staging bytes become the reduction's
   residual_core<AR, VEC, DEPTH, PLAIN, false, double, PLAIN, 0, 0, COMPUTE_ONLY, PASS, 0, RAGGED>(a, pair, slice, st.pose, lds, &first, ref_slot, tgt_slot);
+}
+
+// k_hist_iterate (round 6): what k_iterate is to the identity path, for robust weights — a few pairs per call.  An evaluation under
+// robust weights is two launches (the scale needs every residual before any weight exists): the scale pass (k_resid_hist_v) and
+// the weighted sums (k_residual<.., WEIGHTS>).  The update that used to follow as a third launch (k_gn_update, and k_level_end where a
+// level ends) is folded into the head of the NEXT evaluation's scale pass: every block first brings its pair's state up to date from
+// the previous evaluation's records (iterate_state: the same fold, solve and hand-off, bit for bit), slice 0 publishes it for the
+// weighted launch behind, then the block bins its slice at the new pose.  States and records are double-buffered as in k_iterate.
+template <int AR, bool DEPTH, int SAMPLER, bool RAGGED = false>
+__global__ __launch_bounds__(kBlock) void k_hist_iterate(const ResidualArgs a, const IterArgs ia, unsigned int* __restrict__ hist,
+                                                         PairScale* __restrict__ scale_out, int weights) {
+  __shared__ __attribute__((aligned(16))) unsigned char ulds[kUpdateLdsBytes];
+  const int pair = (int)blockIdx.y + a.pair_base, slice = (int)blockIdx.x;
+  const int lp = (int)blockIdx.y;
+  const int ref_slot = ia.inline_pairs ? (lp == 0 ? ia.pair_slots[0] : ia.pair_slots[2]) : a.ref_slots[pair];
+  const int tgt_slot = ia.inline_pairs ? (lp == 0 ? ia.pair_slots[1] : ia.pair_slots[3]) : a.tgt_slots[pair];
+  const PairState st = iterate_state(ia, pair, ulds, slice == 0);
+  if (slice == 0 && threadIdx.x == 0) ia.state_out[pair] = st;
+  if (st.level_done || st.status) return;   // (every block of the pair alike: nobody draws a ticket)
+  hist_block<AR, 4, DEPTH, SAMPLER, RAGGED>(a, pair, st.pose, ref_slot, tgt_slot, hist, scale_out, weights);
 }
 
 // ------------------------------------------------------------------------------------------------------------

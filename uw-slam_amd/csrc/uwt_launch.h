@@ -37,6 +37,11 @@ void launch_points_general(hipStream_t s, const LaunchSel& sel, const ResidualAr
 void launch_iterate(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const IterArgs& ia, int n_pairs);
 void launch_coarse_chain(hipStream_t s, const LaunchSel& sel, const CoarseArgs& ca, int n_pairs);
 void launch_finish(hipStream_t s, const IterArgs& ia, int n_pairs, float* d_poses, StatsOut* d_stats);
+// the chained flow under robust weights: the pending update + the scale pass in one launch (k_hist_iterate); the weighted pass
+// behind it is launch_general's second half (launch_weighted)
+void launch_hist_iterate(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const IterArgs& ia, int n_pairs, int sampler,
+                         int weights, unsigned int* hist, PairScale* scale);
+void launch_weighted(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, int n_pairs, int sampler, int weights);
 // one coarse level of a batch, one block per pair: k_coarse_w4 (identity weights) / k_coarse_weighted
 void launch_coarse_level(hipStream_t s, const LaunchSel& sel, const CoarseArgs& ca, int cnt, int weights);
 

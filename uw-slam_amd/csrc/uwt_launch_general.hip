@@ -60,7 +60,6 @@ void launch_hist_t(hipStream_t s, const ResidualArgs& a, int n_pairs, int sample
 // the dense kernel specialised for the sampler / weights.
 void launch_general(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, int n_pairs, int sampler, int weights,
                     unsigned int* hist, PairScale* scale) {
-  const bool unit = (a.zf == 1.0f && a.af == 1.0f);
   const bool ragged = level_ragged(a.L);
   if (weights) {
     UWT_WITH_AR(sel.arith,
@@ -72,6 +71,13 @@ void launch_general(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, 
         else launch_hist_t<AR, true, false>(s, a, n_pairs, sampler, weights, hist, scale);
       });
   }
+  launch_weighted(s, sel, a, n_pairs, sampler, weights);
+}
+
+// the weighted / bilinear sums of one evaluation (the scale, where weights are on, is in place)
+void launch_weighted(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, int n_pairs, int sampler, int weights) {
+  const bool unit = (a.zf == 1.0f && a.af == 1.0f);
+  const bool ragged = level_ragged(a.L);
   const int key = (ragged ? 0 : 4) | (sel.depth ? 2 : 0) | (unit ? 1 : 0);
   UWT_WITH_AR(sel.arith,
     switch (key) {
@@ -83,6 +89,25 @@ void launch_general(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, 
       case 5: launch_general_t<AR, false, false, true>(s, a, n_pairs, sampler, weights); break;
       case 6: launch_general_t<AR, false, true, false>(s, a, n_pairs, sampler, weights); break;
       default: launch_general_t<AR, false, true, true>(s, a, n_pairs, sampler, weights); break;
+    });
+}
+
+// the chained flow's first launch of an evaluation under robust weights: pending update + scale pass (k_hist_iterate)
+void launch_hist_iterate(hipStream_t s, const LaunchSel& sel, const ResidualArgs& a, const IterArgs& ia, int n_pairs, int sampler,
+                         int weights, unsigned int* hist, PairScale* scale) {
+  const dim3 grid(a.slices, n_pairs), blk(kBlock);
+  const bool ragged = level_ragged(a.L);
+  const int key = (sampler ? 4 : 0) | (sel.depth ? 2 : 0) | (ragged ? 1 : 0);
+  UWT_WITH_AR(sel.arith,
+    switch (key) {
+      case 0: hipLaunchKernelGGL((k_hist_iterate<AR, false, 0, false>), grid, blk, 0, s, a, ia, hist, scale, weights); break;
+      case 1: hipLaunchKernelGGL((k_hist_iterate<AR, false, 0, true>), grid, blk, 0, s, a, ia, hist, scale, weights); break;
+      case 2: hipLaunchKernelGGL((k_hist_iterate<AR, true, 0, false>), grid, blk, 0, s, a, ia, hist, scale, weights); break;
+      case 3: hipLaunchKernelGGL((k_hist_iterate<AR, true, 0, true>), grid, blk, 0, s, a, ia, hist, scale, weights); break;
+      case 4: hipLaunchKernelGGL((k_hist_iterate<AR, false, 1, false>), grid, blk, 0, s, a, ia, hist, scale, weights); break;
+      case 5: hipLaunchKernelGGL((k_hist_iterate<AR, false, 1, true>), grid, blk, 0, s, a, ia, hist, scale, weights); break;
+      case 6: hipLaunchKernelGGL((k_hist_iterate<AR, true, 1, false>), grid, blk, 0, s, a, ia, hist, scale, weights); break;
+      default: hipLaunchKernelGGL((k_hist_iterate<AR, true, 1, true>), grid, blk, 0, s, a, ia, hist, scale, weights); break;
     });
 }
 
