@@ -46,7 +46,7 @@ HBM_COPY_GBS = 6290.0                  # MI355X_MICROARCH.md §Chip-level parame
 # per arithmetic set, each naming its source file, stamped with the source id (uwt_source_id(): sha256 of sources + flags) of the
 # libuwt_hip.so they were collected on (tools/make_profile_facts.py).  They are quoted only while the library this process
 # loaded reports that id — hipcc's output is not byte-reproducible, so the binary's own hash would not survive a rebuild.
-PROFILE_FACTS = os.path.join(ROOT, "profiles", "r05", "k_residual_facts.json")
+PROFILE_FACTS = os.path.join(ROOT, "profiles", "r06", "k_residual_facts.json")
 
 
 def _quoted_facts(capi, arith):

@@ -66,9 +66,9 @@ def test_gpu_ingest_matches_oracle(O, synth):
     big = np.zeros((480, 800), np.uint8)
     big[:, :752] = raw
     assert np.array_equal(ing.undistort(big[:, :752]), und)
-    # fused remap + crop into a tracker slot: largest window inside the ROI with sizes divisible by 16
+    # fused remap + crop into a tracker slot: the ROI itself (any size is a frame size since round 6)
     x0, y0 = int(roi[0]), int(roi[1])
-    cw, ch = (int(roi[2]) // 16) * 16, (int(roi[3]) // 16) * 16
+    cw, ch = int(roi[2]), int(roi[3])
     f = float(ing.newK[0])
     ctx = capi.Context(capi.default_params(cw, ch, f, float(ing.newK[1]), float(ing.newK[2]) - x0, float(ing.newK[3]) - y0,
                                            max_frames=2, max_pairs=1))
@@ -76,4 +76,49 @@ def test_gpu_ingest_matches_oracle(O, synth):
     assert np.array_equal(ctx.get_plane(1, 0, capi.PLANE_IMAGE), und[y0:y0 + ch, x0:x0 + cw])
     with pytest.raises(capi.UwtError):
         ing.frame(ctx, 1, raw, 736 - cw + 1, 0)              # window leaves the undistorted frame
+    ing.close()
+
+
+@pytest.mark.gpu
+def test_euroc_pipeline_end_to_end_at_the_roi_size(O, synth):
+    """The reference's own EUROC path (configs 1-2) from raw frame to pose, without the survey's "centre-crop to 640 x 480"
+    deviation: remap with the rectification maps (src/System.cpp:233), System::CalculateROI on the first frame (:148-191) — a
+    data-dependent, odd-sized window —, every frame cropped to it (:234), w_ / h_ = the ROI size (:186-190), the tracker initialised
+    with that size and the UNSHIFTED new camera matrix (:105-123: the crop does not move cx, cy — reference quirk C-10), pyramids
+    by cv::resize, EstimatePose.  GPU: uwt_ingest_frame straight into the tracker's slots at the ROI size; oracle: its restatement
+    of each stage.  Poses bit for bit."""
+    capi = importlib.import_module("uw-slam_amd.capi")
+    ing = capi.Ingest(EUROC_K, EUROC_D, 752, 480, 736, 480)
+    nk = O.optimal_new_camera_matrix(EUROC_K, EUROC_D, 752, 480, 736, 480)
+    o1, o2 = O.init_undistort_maps(EUROC_K, EUROC_D, nk, 736, 480)
+    f, cx, cy = 458.654, 367.215, 248.375
+    frames = []
+    for s in range(3):   # a raw (distorted-camera) frame and two moved views of it
+        ref, tgt, _, _, _ = synth.render_pair(752, 480, f, f, cx, cy, seed=8100, max_t=0.004 * (s + 1), max_deg=0.2 * (s + 1))
+        fr = ref if s == 0 else tgt
+        fr = fr.copy()
+        fr[fr == 0] = 1                                      # 0 is the "outside" marker CalculateROI looks for
+        frames.append(fr)
+    roi = ing.calculate_roi(frames[0])
+    x0, y0, rw, rh = [int(v) for v in roi]
+    assert (rw % 16, rh % 16) != (0, 0) and rw >= 600 and rh >= 300, roi      # a size no earlier round could track
+    K = [float(np.float32(v)) for v in nk]                   # K_ = camera_model_->GetK(): the new camera matrix, not shifted by the crop
+    over = dict(has_depth=0)                                 # EUROC is monocular; the reference schedule (levels 4 -> 1, early exit)
+    ctx = capi.Context(capi.default_params(rw, rh, *K, max_frames=3, max_pairs=2, **over))
+    und = []
+    for i, fr in enumerate(frames):
+        ing.frame(ctx, i, fr, x0, y0)
+        und.append(O.remap_linear(fr, o1, o2)[y0:y0 + rh, x0:x0 + rw])
+        assert np.array_equal(ctx.get_plane(i, 0, capi.PLANE_IMAGE), und[i]), i
+    ctx.build_pyramids(0, 3)
+    ctx.apply_gradient(0, 3)
+    po = O.default_params(rw, rh, *K, **over)
+    poses, stats = ctx.estimate_pose_batch([0, 1], [1, 2], raise_on_pair_failure=True)
+    for i in range(2):
+        st, pose_cpu, tr = O.align_pair(po, und[i], und[i + 1], None, want_trace=True)
+        assert st == 0 and stats[i]["iterations"] == len(tr)
+        assert np.array_equal(poses[i].view(np.uint32), pose_cpu.view(np.uint32)), (i, poses[i], pose_cpu)
+    one, st1 = ctx.estimate_pose_batch([0], [1], raise_on_pair_failure=True)      # the drop-in call: one pair
+    assert np.array_equal(one[0].view(np.uint32), poses[0].view(np.uint32))
+    ctx.close()
     ing.close()

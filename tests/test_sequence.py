@@ -91,3 +91,44 @@ def test_streaming_many_chunks_every_pair_against_the_oracle(synth, O):
         if st == 0:
             assert np.array_equal(poses[i].view(np.uint32), pose_cpu.view(np.uint32)), i
     trk.close()
+
+
+@pytest.mark.gpu
+def test_track_sequence_tool_in_the_reference_roi_mode(tmp_path, synth, O):
+    """tools/track_sequence.py --distortion: a EUROC-layout directory of raw 752 x 480 frames through the reference's own path —
+    rectified, cropped to the ROI System::CalculateROI finds on the first frame (an odd size), tracked at that size with the new
+    camera matrix unshifted — against the oracle's restatement of every stage, pair by pair."""
+    import json
+    import subprocess
+    import sys
+    from PIL import Image
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    K = [458.654, 457.296, 367.215, 248.375]
+    D = [-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05]
+    img_dir = tmp_path / "data"
+    img_dir.mkdir()
+    base = synth.texture(752 + 32, 480 + 16, seed=11)
+    base[base == 0] = 1
+    raws = []
+    for i in range(4):
+        f = np.ascontiguousarray(base[4 + i: 4 + i + 480, 3 * i: 3 * i + 752])
+        Image.fromarray(f).save(img_dir / ("%019d.png" % (1403636579763555584 + 50000000 * i)))
+        raws.append(f)
+    out = tmp_path / "traj"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "track_sequence.py"), "--images", str(img_dir), "--fx", str(K[0]), "--fy", str(K[1]),
+                        "--cx", str(K[2]), "--cy", str(K[3]), "--distortion=" + ",".join(repr(v) for v in D), "--rectified-size", "736,480",
+                        "--out", str(out)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    nk = O.optimal_new_camera_matrix(K, D, 752, 480, 736, 480)
+    m1, m2 = O.init_undistort_maps(K, D, nk, 736, 480)
+    und = [O.remap_linear(f, m1, m2) for f in raws]
+    x0, y0, rw, rh = [int(v) for v in O.calculate_roi(und[0])]
+    crops = [np.ascontiguousarray(u[y0:y0 + rh, x0:x0 + rw]) for u in und]
+    po = O.default_params(rw, rh, *[float(np.float32(v)) for v in nk])
+    meta = json.load(open(str(out) + "_metrics.json")) if os.path.exists(str(out) + "_metrics.json") else None
+    poses = np.load(str(out) + "_poses.npy") if os.path.exists(str(out) + "_poses.npy") else None
+    assert poses is not None, (r.stdout[-2000:], os.listdir(tmp_path))
+    for i in range(3):
+        st, pose_cpu, _ = O.align_pair(po, crops[i], crops[i + 1])
+        assert st == 0 and np.array_equal(poses[i].view(np.uint32), pose_cpu.view(np.uint32)), i
+    assert meta is None or meta["crop_offset"] == [x0, y0]

@@ -27,6 +27,8 @@ def differs(what, **kw):
 for case in range(cases):
     w = int(rng.choice([32, 48, 80, 96, 112, 160, 208, 320]))
     h = int(rng.choice([16, 32, 48, 64, 96, 240]))
+    if rng.random() < 0.5:   # any size is a frame size (round 6): odd, ROI-like, grids smaller than their images
+        w, h = int(rng.integers(17, 330)), int(rng.integers(17, 250))
     n_levels = int(rng.integers(1, 4))
     fx = float(np.float32(rng.uniform(0.5, 1.5) * w))
     fy = fx if rng.random() < 0.5 else float(np.float32(fx * rng.uniform(0.9, 1.1)))
@@ -55,8 +57,8 @@ for case in range(cases):
     a_img, b_img, dp = ref, tgt, dep
     for lvl in range(n_levels):
         if lvl:
-            a_img, b_img = O.halve_u8(a_img), O.halve_u8(b_img)
-            dp = O.halve_u16(dp) if depth else None
+            a_img, b_img = O.resize_half_u8(a_img), O.resize_half_u8(b_img)
+            dp = O.resize_half_u16(dp) if depth else None
         L = O.level_intrinsics(p, lvl)
         gx, gy = O.scharr3(a_img)
         pts = O.dense_points(dp, L.w, L.h, lvl)

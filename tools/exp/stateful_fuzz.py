@@ -15,7 +15,8 @@ from concurrent.futures import ThreadPoolExecutor
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-GEOM = [(160, 96, 4), (208, 112, 5), (112, 80, 5), (320, 240, 4), (384, 256, 8), (256, 192, 7)] if os.environ.get('FUZZ_DEEP') else [(160, 96, 4), (208, 112, 5), (112, 80, 5), (320, 240, 4)]
+GEOM = [(160, 96, 4), (208, 112, 5), (112, 80, 5), (320, 240, 4), (384, 256, 8), (256, 192, 7), (163, 99, 4), (245, 157, 5), (333, 251, 5)] if os.environ.get('FUZZ_DEEP') \
+    else [(160, 96, 4), (208, 112, 5), (112, 80, 5), (320, 240, 4), (163, 99, 4), (245, 157, 5)]   # (the last ones: odd sizes, round 6)
 U, NP = 12, 64          # distinct pairs, resident pairs
 total = bad = 0
 t0 = time.time()

@@ -23,6 +23,6 @@ for a in opencv legacy; do
 done
 cp $src/sq_counters_*.csv $dst/
 [ -s $src/per_level_launch_table_trace.md ] && cp $src/per_level_launch_table_trace.md $dst/
-for f in bench_total8192_g1.json latency_single_pair.txt stage_timing.txt; do [ -s $src/$f ] && cp $src/$f $dst/; done
+for f in bench_total8192_g1.json latency_single_pair.txt latency_identity_by_level.txt call_overhead.txt stage_timing.txt; do [ -s $src/$f ] && cp $src/$f $dst/; done
 python3 tools/kernel_resources.py -o $dst/kernel_resources.md > /dev/null
 python3 tools/make_profile_facts.py $dst

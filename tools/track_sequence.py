@@ -4,6 +4,11 @@ GPU path and write the trajectory in the reference visualiser's CSV format and i
 
   python tools/track_sequence.py --images <dir> [--depth <dir>] --fx .. --fy .. --cx .. --cy .. \
          [--width 640 --height 480] [--groundtruth <file> --tum|--euroc] [--weights huber] [--bilinear] --out traj
+  python tools/track_sequence.py --images <EUROC cam0/data> --fx 458.654 --fy 457.296 --cx 367.215 --cy 248.375 \
+         --distortion=-0.28340811,0.07395907,0.00019359,1.76187114e-05 --rectified-size 736,480 --out traj
+      the reference's own EUROC path (calibration/calibrationEUROC.xml): every frame rectified with the maps of CameraModel
+      (src/CameraModel.cpp:84-90), cropped to the window System::CalculateROI finds on the first one (src/System.cpp:148-191: a
+      data-dependent, odd size) and tracked AT THAT SIZE with the unshifted new camera matrix, as the reference does
 
 No dataset ships with this repository (none is available offline); the synthetic test in tests/test_sequence.py
 exercises the same code path.
@@ -27,6 +32,9 @@ def main():
     ap.add_argument("--fx", type=float, required=True); ap.add_argument("--fy", type=float, required=True)
     ap.add_argument("--cx", type=float, required=True); ap.add_argument("--cy", type=float, required=True)
     ap.add_argument("--width", type=int, default=640); ap.add_argument("--height", type=int, default=480)
+    ap.add_argument("--distortion", default="", help="k1,k2,p1,p2: rectify + ROI-crop like the reference (System.cpp:148-191, 231-236); "
+                    "--width / --height are then ignored: the frame size is the ROI's")
+    ap.add_argument("--rectified-size", default="", help="W,H of the rectified frame (out_width / out_height of the calibration file); default: the input size")
     ap.add_argument("--start", type=int, default=0); ap.add_argument("--count", type=int, default=0)
     ap.add_argument("--weights", choices=["identity", "tukey", "huber"], default="identity")
     ap.add_argument("--bilinear", action="store_true")
@@ -43,13 +51,27 @@ def main():
         names = names[:a.count]
         dnames = dnames[:a.count] if dnames else None
     first = S.load_gray(names[0])
-    _, x0, y0 = S.centre_crop(first, a.width, a.height)
-    frames = [S.centre_crop(S.load_gray(n), a.width, a.height)[0] for n in names]
-    depths = [S.centre_crop(S.load_depth(n), a.width, a.height)[0] for n in dnames] if dnames else None
+    fx, fy, cx, cy = a.fx, a.fy, a.cx, a.cy
+    if a.distortion:
+        capi = importlib.import_module("uw-slam_amd.capi")
+        dist = [float(v) for v in a.distortion.split(",")]
+        ih, iw = first.shape
+        ow, oh = [int(v) for v in a.rectified_size.split(",")] if a.rectified_size else (iw, ih)
+        ing = capi.Ingest([a.fx, a.fy, a.cx, a.cy], dist, iw, ih, ow, oh)
+        x0, y0, a.width, a.height = [int(v) for v in ing.calculate_roi(first)]          # w_, h_ = the ROI's (src/System.cpp:186-190)
+        fx, fy, cx, cy = [float(v) for v in ing.newK]                                    # K_ = GetK(): not shifted by the crop (:105-112)
+        frames = [np.ascontiguousarray(ing.undistort(S.load_gray(n))[y0:y0 + a.height, x0:x0 + a.width]) for n in names]
+        depths = None
+        ing.close()
+        cx, cy = cx + x0, cy + y0                                                        # (undone below: the reference keeps cx, cy)
+    else:
+        _, x0, y0 = S.centre_crop(first, a.width, a.height)
+        frames = [S.centre_crop(S.load_gray(n), a.width, a.height)[0] for n in names]
+        depths = [S.centre_crop(S.load_depth(n), a.width, a.height)[0] for n in dnames] if dnames else None
     over = dict(weights={"identity": 0, "tukey": 1, "huber": 2}[a.weights], sampler=int(a.bilinear), arith={"opencv": 0, "legacy": 1}[a.arith])
     if a.fixed_iters:
         over.update(n_levels=4, first_level=3, last_level=0, max_iters=a.fixed_iters, early_exit=0)
-    trk = S.SequenceTracker(a.width, a.height, a.fx, a.fy, a.cx - x0, a.cy - y0, depth=bool(depths), **over)
+    trk = S.SequenceTracker(a.width, a.height, fx, fy, cx - x0, cy - y0, depth=bool(depths), **over)
     t0 = time.perf_counter()
     poses, stats = trk.track(frames, depths)
     dt = time.perf_counter() - t0
