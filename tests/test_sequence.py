@@ -94,7 +94,7 @@ def test_streaming_many_chunks_every_pair_against_the_oracle(synth, O):
 
 
 @pytest.mark.gpu
-def test_track_sequence_tool_in_the_reference_roi_mode(tmp_path, synth, O):
+def test_track_sequence_tool_in_the_reference_roi_mode(tmp_path, synth, O, arith):
     """tools/track_sequence.py --distortion: a EUROC-layout directory of raw 752 x 480 frames through the reference's own path —
     rectified, cropped to the ROI System::CalculateROI finds on the first frame (an odd size), tracked at that size with the new
     camera matrix unshifted — against the oracle's restatement of every stage, pair by pair."""
@@ -117,7 +117,7 @@ def test_track_sequence_tool_in_the_reference_roi_mode(tmp_path, synth, O):
     out = tmp_path / "traj"
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "track_sequence.py"), "--images", str(img_dir), "--fx", str(K[0]), "--fy", str(K[1]),
                         "--cx", str(K[2]), "--cy", str(K[3]), "--distortion=" + ",".join(repr(v) for v in D), "--rectified-size", "736,480",
-                        "--out", str(out)], capture_output=True, text=True, timeout=600)
+                        "--arith", arith, "--out", str(out)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     nk = O.optimal_new_camera_matrix(K, D, 752, 480, 736, 480)
     m1, m2 = O.init_undistort_maps(K, D, nk, 736, 480)
