@@ -294,7 +294,9 @@ int uwt_residual_jacobian_weighted(uwt_ctx* ctx, int32_t ref_slot, int32_t tgt_s
                                    uwt_accum* acc_out, double* err_num_out, float* inv_mad_out, float* J_out_or_null,
                                    float* r_out_or_null, uint8_t* valid_out_or_null, float* w_out_or_null);
 /* LS::initialize + n x LS::update(J, r, w) + LS::finishNoDivide / finish  (src/LeastSquares.cpp:30-37, 204-209,
- * 39-146) on the GPU reduction.  A: 36 row-major, b: 6 (stored sign: b = -Σ w r J), error, count. */
+ * 39-146).  Every accumulator is the f32 chain the reference's loop forms, in call order (one GPU thread per chain: the 28 chains
+ * are independent) — the reference's floats bit for bit, not a re-associated sum.  A: 36 row-major, b: 6 (stored sign:
+ * b = -Σ w r J), error, count. */
 int uwt_ls_accumulate(uwt_ctx* ctx, const float* J, const float* r, const float* w_or_null, int32_t n, int32_t divide,
                       float A[36], float b[6], float* error, int32_t* num_constraints);
 /* LS::initialize + (n/4) x LS::updateSSE + LS::finishNoDivide / finish (src/LeastSquares.cpp:148-202): the 4-wide form's

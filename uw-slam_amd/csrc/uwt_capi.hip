@@ -1903,8 +1903,7 @@ static int ls_accumulate_impl(uwt_ctx* c, const float* J, const float* r, const 
                               int32_t count, float A[36], float b[6], float* error, int32_t* num_constraints) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !J || !r || !A || !b || !error || !num_constraints || n < 0) return fail(c, UWT_ERR_INVALID_ARG, "uwt_ls_accumulate");
-  const int blocks = n == 0 ? 1 : std::min(1024, (n + kBlock - 1) / kBlock);
-  const size_t fl = (size_t)n * 8 + (size_t)blocks * 28 + 64;
+  const size_t fl = (size_t)n * 8 + 128 + 64;
   int st = ensure_scratch(c, fl * 4);
   if (st) return st;
   float* dJ = (float*)c->scratch;
@@ -1916,20 +1915,21 @@ static int ls_accumulate_impl(uwt_ctx* c, const float* J, const float* r, const 
     HIPCHK(c, hipMemcpyAsync(dr, r, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
     if (w) HIPCHK(c, hipMemcpyAsync(dw, w, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
   }
-  if (sse) hipLaunchKernelGGL(k_ls_accumulate<true>, dim3(blocks), dim3(kBlock), 0, c->stream, dJ, dr, w ? dw : nullptr, n, dp);
-  else hipLaunchKernelGGL(k_ls_accumulate<false>, dim3(blocks), dim3(kBlock), 0, c->stream, dJ, dr, w ? dw : nullptr, n, dp);
+  // one thread per accumulator chain (per lane chain in the SSE form), each in the reference's order: k_ls_sequential
+  if (sse) hipLaunchKernelGGL(k_ls_sequential<true>, dim3(1), dim3(128), 0, c->stream, dJ, dr, w ? dw : nullptr, n, dp);
+  else hipLaunchKernelGGL(k_ls_sequential<false>, dim3(1), dim3(128), 0, c->stream, dJ, dr, w ? dw : nullptr, n, dp);
   HIPCHK(c, hipGetLastError());
-  std::vector<float> parts((size_t)blocks * 28);
-  HIPCHK(c, hipMemcpyAsync(parts.data(), dp, parts.size() * 4, hipMemcpyDeviceToHost, c->stream));
+  float parts[112];
+  HIPCHK(c, hipMemcpyAsync(parts, dp, sizeof(float) * (sse ? 112 : 28), hipMemcpyDeviceToHost, c->stream));
   HIPCHK(c, hipStreamSynchronize(c->stream));
-  double s[28] = {0};
-  for (int bl = 0; bl < blocks; bl++)
-    for (int k = 0; k < 28; k++) s[k] += (double)parts[(size_t)bl * 28 + k];
+  float s[28];
+  for (int k = 0; k < 28; k++)   // LS::finishNoDivide (:39-139): the four lanes folded left to right
+    s[k] = sse ? ((parts[4 * k] + parts[4 * k + 1]) + parts[4 * k + 2]) + parts[4 * k + 3] : parts[k];
   int q = 0;
   for (int i = 0; i < 6; i++)
-    for (int j = i; j < 6; j++, q++) { A[6 * i + j] = (float)s[q]; A[6 * j + i] = (float)s[q]; }
-  for (int i = 0; i < 6; i++) b[i] = (float)(-s[21 + i]);  // LS stores b = -Σ w r J (src/LeastSquares.cpp:206)
-  *error = (float)s[27];
+    for (int j = i; j < 6; j++, q++) { A[6 * i + j] = s[q]; A[6 * j + i] = s[q]; }
+  for (int i = 0; i < 6; i++) b[i] = -s[21 + i];  // LS stores b = -Σ w r J (src/LeastSquares.cpp:206; 0 - x - y = -(x + y) in IEEE)
+  *error = s[27];
   *num_constraints = count;
   if (divide) {          // LS::finish (:141-146)
     const float nf = (float)count;

@@ -15,6 +15,7 @@
 //   k_resid_hist_v (scale pass with the scale stage in its tail) + k_residual<.., WEIGHTS>   robust weights in the alignment loop;
 //                  k_residual<.., SAMPLER = 1>: bilinear sampler
 //   k_residual_points, k_points_hist, k_points_general                   explicit point tables (identity / general path)
+//   k_ls_sequential   the LS mirror (src/LeastSquares.cpp): every accumulator's f32 chain in the reference's order
 //   k_residual_general, k_resid_hist, k_scale_stage                      per-stage (dump) forms of the general path
 //   k_grad_mag*, k_candidates_batch, k_scan_counts, k_patch_points, k_add_patch_points, k_remap_crop, k_trajectory*   the rows
 //                  next to the path
@@ -3018,41 +3019,44 @@ __global__ void k_warp_table(const float4* __restrict__ pts, float4* __restrict_
   out[i] = make_float4(u, v, o[2], wq);
 }
 
-// LS::update over n rows (src/LeastSquares.cpp:204-209) as a grid reduction: thread-sequential over a strided
-// subset, then the same deterministic block fold; weights enter as (J_i·J_j)·w, (r·w)·J_i, (r·r)·w.
+// LS::update / LS::updateSSE over n rows (src/LeastSquares.cpp:204-209, 148-202) IN THE REFERENCE'S ORDER.  Each of LS's accumulators
+// is a chain of f32 additions over the points in call order — a parallel sum cannot reproduce its roundings.  But the 28 chains (21
+// upper-triangle entries of A, 6 of b, the error) are independent of one another, and updateSSE's are 28 x 4 lane chains over every
+// fourth point: one thread per chain walks the points sequentially, the chains run side by side.  Bit for bit what the reference's
+// loop computes (rounds 1-5 folded per-thread partial sums in f64: closer to the exact sum, not the reference's floats); LS is a
+// mirror of code the reference never calls, a few hundred microseconds per 10^4 points are of no concern.
+//   SSE_ORDER = false: thread s < 28 -> out[s]; products (J_i J_j) w, J_i (r w), (r r) w.
+//   SSE_ORDER = true:  thread 4 s + l -> out[4 s + l], points l, l + 4, ...; products (J_i w) J_j, (r w) J_i, (r w) r (:151-199).
 template <bool SSE_ORDER>
-__global__ __launch_bounds__(kBlock) void k_ls_accumulate(const float* __restrict__ J, const float* __restrict__ r,
-                                                          const float* __restrict__ w, int n, float* partials) {
-  float acc[28];
-#pragma unroll
-  for (int i = 0; i < 28; i++) acc[i] = 0.f;
-  for (int p = blockIdx.x * kBlock + threadIdx.x; p < n; p += gridDim.x * kBlock) {
-    float Jr[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) Jr[k] = J[(size_t)p * 6 + k];
+__global__ __launch_bounds__(128) void k_ls_sequential(const float* __restrict__ J, const float* __restrict__ r,
+                                                       const float* __restrict__ w, int n, float* __restrict__ out) {
+  const int t = (int)threadIdx.x;
+  const int s = SSE_ORDER ? t >> 2 : t, lane = SSE_ORDER ? t & 3 : 0, step = SSE_ORDER ? 4 : 1;
+  if (s >= 28) return;
+  int i = 0, j = 0;   // accumulator s: the upper triangle row-major (i <= j), then b_0..b_5 (i = s - 21), then the error
+  if (s < 21) {
+    int q = s;
+    while (q >= 6 - i) { q -= 6 - i; i++; }
+    j = i + q;
+  } else {
+    i = s - 21;
+  }
+  float acc = 0.f;
+  for (int p = lane; p < n; p += step) {
     const float wi = w ? w[p] : 1.0f, ri = r[p];
-    int s = 0;
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int j = i; j < 6; j++, s++)
-        acc[s] += SSE_ORDER ? (Jr[i] * wi) * Jr[j]    // LS::updateSSE: J1w = J1*weight; J1w*J2 (src/LeastSquares.cpp:151-153)
-                            : (Jr[i] * Jr[j]) * wi;   // LS::update: J * J^T * weight (:205)
-    const float rw = ri * wi;
-#pragma unroll
-    for (int i = 0; i < 6; i++) acc[21 + i] += SSE_ORDER ? rw * Jr[i] : Jr[i] * rw;
-    acc[27] += SSE_ORDER ? rw * ri : ri * ri * wi;   // (res*weight)*res (:198) vs res*res*weight (:207)
+    float term;
+    if (s < 21) {
+      const float Ji = J[(size_t)p * 6 + i], Jj = J[(size_t)p * 6 + j];
+      term = SSE_ORDER ? (Ji * wi) * Jj : (Ji * Jj) * wi;
+    } else if (s < 27) {
+      const float Ji = J[(size_t)p * 6 + i], rw = ri * wi;
+      term = SSE_ORDER ? rw * Ji : Ji * rw;
+    } else {
+      term = SSE_ORDER ? (ri * wi) * ri : (ri * ri) * wi;
+    }
+    acc = acc + term;
   }
-  __shared__ float red[28][kBlock];
-  const int tid = threadIdx.x;
-#pragma unroll
-  for (int v = 0; v < 28; v++) red[v][tid] = acc[v];
-  __syncthreads();
-  if (tid < 28) {
-    double s = 0.0;
-    for (int j = 0; j < kBlock; j++) s += (double)red[tid][j];
-    partials[blockIdx.x * 28 + tid] = (float)s;
-  }
+  out[t] = acc;
 }
 
 // ------------------------------------------------------------------------------------------------------------
