@@ -554,7 +554,9 @@ __device__ __forceinline__ void warp_setup(const Pose& pose, WarpK& K) {
 // cycles for TWO pixels with or without a scalar operand, so the per-pixel float sequence is written over pairs of
 // adjacent pixels: the block-uniform operands stay in SGPRs (no VGPR cost, 4 waves/SIMD kept) and cost nothing extra.
 // Each component sees exactly the scalar IEEE operation (same rounding, no contraction), so results are bit-identical
-// to the one-pixel form, which the VEC = 1 fallback and the per-stage kernels still use (F = float).
+// to the one-pixel form (F = float), which the per-stage kernels (general_pixel, the point tables, k_warp_table) use.  (The
+// templates below still take VEC = 1 — one pixel per step — but since round 6 nothing instantiates it: every level is walked in
+// groups of four, RAGGED where its grid rows are not whole groups.)
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef unsigned int u2v __attribute__((ext_vector_type(2)));   // (the type __builtin_nontemporal_load takes for an 8-byte load)
 
