@@ -120,11 +120,14 @@ struct uwt_ctx {
 
 namespace {
 
-// x VEC pixels per thread at the finest slicing, the one a single pair runs with: short blocks, as many as the fold of
-// k_gn_update stages in LDS (kMaxSlices).  One pair at 640x480: 150 level-0 blocks of 8 pixels per thread — 0.60 ms per
-// 4 x 10 alignment against 0.75 ms with 8 groups per thread; batches coarsen the slicing in enqueue_estimate.  The f64
-// partial sums group differently with the slicing — 1e-16 relative, far below the f32 rounding of A and b.
-constexpr int kGroupsPerThread = 2;
+// x VEC pixels per thread at the finest slicing, the one a single pair runs with: short blocks, at most kMaxSlices of them per
+// level (the records the next launch's fold pulls in).  A lone pair's evaluation is a chain of latencies, and every further group a
+// thread walks adds a dependent gather round trip to it: ONE group per thread (round 6; 2 until then) wherever that stays under
+// kMaxSlices — 640 x 480: level 1 in 75 blocks, level 2 in 19; level 0 would need 300 and keeps two groups (150 blocks: 300 records
+// to fold cost more than the second round trip, measured) — takes the 4 x 10 alignment of one pair from 0.411 to 0.392 ms and the
+// reference schedule from 0.126 to 0.120 ms (profiles/r06/EXPERIMENTS.md 10).  Batches coarsen the slicing in enqueue_estimate.
+// The f64 partial sums group differently with the slicing — 1e-16 relative, far below the f32 rounding of A and b.
+constexpr int kGroupsPerThread = 1;
 
 int fail(uwt_ctx* c, int code, const std::string& msg) {
   if (c) c->last_error = msg;
