@@ -286,3 +286,50 @@ def test_sizes_with_an_empty_grid_are_refused(capi):
     with pytest.raises(capi.UwtError):
         capi.Context(capi.default_params(7, 40, 10.0, 10.0, 3.0, 20.0, n_levels=4, first_level=3, last_level=0))   # 7 >> 3 = 0
     capi.Context(capi.default_params(9, 40, 10.0, 10.0, 4.0, 20.0, n_levels=4, first_level=3, last_level=0)).close()
+
+
+@pytest.mark.parametrize("depth", [False, True], ids=["nodepth", "depth"])
+def test_point_tables_and_patches_at_an_odd_size(capi, O, synth, depth):
+    """The reference's LIVE flow (src/System.cpp:193-223: key points -> ObtainPatchesPoints -> EstimatePoseFeatures) and explicit
+    per-level tables (candidates on every level -> EstimatePose) on a 163 x 99 frame: patch points read depth through pitched rows,
+    table rows index the level's IMAGE (a candidate of the grid's last column sits one short of the image's last), the candidates
+    walk the grid."""
+    w, h, nl = 163, 99, 4
+    intr = _intr(w, h)
+    ref, tgt, dep, _, _ = synth.render_pair(w, h, *intr, seed=6900, with_depth=True, max_t=0.01, max_deg=0.5)
+    feat = dict(n_levels=nl, first_level=0, last_level=0, max_iters=10, early_exit=1, gain=1.0, z_factor=0.002, handoff_scale_t=1, has_depth=int(depth))
+    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, **feat))
+    ctx.upload_frames(0, np.stack([ref, tgt]), np.stack([dep, dep]) if depth else None)
+    ctx.build_pyramids(0, 2)
+    ctx.apply_gradient(0, 2)
+    rng = np.random.default_rng(19)
+    kp = rng.uniform([6, 6], [w - 7, h - 7], (120, 2)).astype(np.float32)
+    kp[0] = (w - 1.5, h - 1.5)                                   # a patch that leaves the frame on two sides
+    pts, n = ctx.obtain_patch_points(0, kp)
+    pts_cpu, n_cpu = O.patch_points(kp, dep if depth else None, w, h)
+    assert n == n_cpu and np.array_equal(pts, pts_cpu)
+    pose, st = ctx.estimate_pose_points(0, 1, {0: pts})
+    so, pose_cpu, tr = O.align_pair_points(O.default_params(w, h, *intr, **feat), ref, tgt, {0: pts_cpu}, ref_depth=dep if depth else None, want_trace=True)
+    assert so == st["status"] == 0 and st["iterations"] == len(tr) and np.array_equal(pose.view(np.uint32), pose_cpu.view(np.uint32))
+    ctx.close()
+    # candidates of every level as tables for EstimatePose (levels 3 -> 1)
+    over = dict(n_levels=nl, first_level=nl - 1, last_level=1, max_iters=5, early_exit=0, has_depth=int(depth))
+    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2, max_pairs=1, **over))
+    ctx.upload_frames(0, np.stack([ref, tgt]), np.stack([dep, dep]) if depth else None)
+    ctx.build_pyramids(0, 2)
+    ctx.apply_gradient(0, 2)
+    p = O.default_params(w, h, *intr, **over)
+    imgs = O.pyramid(ref, nl)
+    tables, tables_cpu = {}, {}
+    for l in range(1, nl):
+        L = O.level_intrinsics(p, l)
+        mag = O.gradient_mag(*O.scharr3(imgs[l]))
+        want, nw = O.candidate_points(mag, None, 5.0, grid=(L.w, L.h))     # z = 1 tables (the depth-less producer): x, y, 1, 1
+        got, m = ctx.obtain_candidate_points(0, l, 5.0) if not depth else (want, nw)
+        assert m == nw and np.array_equal(got, want), l
+        tables[l], tables_cpu[l] = got, want
+        assert nw > 20
+    pose, st = ctx.estimate_pose_points(0, 1, tables)
+    so, pose_cpu, tr = O.align_pair_points(p, ref, tgt, tables_cpu, ref_depth=dep if depth else None, want_trace=True)
+    assert so == st["status"] == 0 and st["iterations"] == len(tr) and np.array_equal(pose.view(np.uint32), pose_cpu.view(np.uint32))
+    ctx.close()
