@@ -104,6 +104,18 @@ def test_level_geometry_pyramids_and_gradients(capi, O, size, form):
     wd[:, :w] = depth[1]
     ctx.set_frame(0, wide[:, :w], wd[:, :w])
     assert np.array_equal(ctx.get_plane(0, 0, capi.PLANE_IMAGE), frames[1]) and np.array_equal(ctx.get_plane(0, 0, capi.PLANE_DEPTH), depth[1])
+    # ... and so does a tightly packed one (one linear copy and a kernel that spreads the rows, like the batch uploads)
+    ctx.set_frame(1, frames[2], depth[2])
+    assert np.array_equal(ctx.get_plane(1, 0, capi.PLANE_IMAGE), frames[2]) and np.array_equal(ctx.get_plane(1, 0, capi.PLANE_DEPTH), depth[2])
+    # the asynchronous upload from page-locked memory: a first call (the staging area is created), a larger one (it grows)
+    pg, pd = capi.pinned_empty((n, h, w), np.uint8), capi.pinned_empty((n, h, w), np.uint16)
+    pg[:], pd[:] = frames[::-1], depth[::-1]
+    ctx.upload_frames_async(0, pg[:1], pd[:1])
+    ctx.upload_frames_async(1, pg[1:], pd[1:])
+    ctx.sync()
+    for slot in (0, 1, n - 1):
+        assert np.array_equal(ctx.get_plane(slot, 0, capi.PLANE_IMAGE), frames[n - 1 - slot]), slot
+        assert np.array_equal(ctx.get_plane(slot, 0, capi.PLANE_DEPTH), depth[n - 1 - slot]), slot
     ctx.close()
 
 
