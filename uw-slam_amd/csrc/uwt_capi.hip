@@ -2395,7 +2395,10 @@ void init_undistort_maps(const double K[4], const double k[4], const double newK
 
 int ingest_remap(uwt_ingest* g, const uint8_t* raw, size_t stride, int x0, int y0, int cw, int ch, uint8_t* d_dst, int dst_pitch) {
   ING_CHK(hipSetDevice(g->device));
-  ING_CHK(hipMemcpy2DAsync(g->d_raw, g->in_w, raw, stride, g->in_w, g->in_h, hipMemcpyHostToDevice, g->stream));
+  if (stride == (size_t)g->in_w)   // tight rows: one linear copy (a 2-D copy is issued row by row)
+    ING_CHK(hipMemcpyAsync(g->d_raw, raw, (size_t)g->in_w * g->in_h, hipMemcpyHostToDevice, g->stream));
+  else
+    ING_CHK(hipMemcpy2DAsync(g->d_raw, g->in_w, raw, stride, g->in_w, g->in_h, hipMemcpyHostToDevice, g->stream));
   hipLaunchKernelGGL(k_remap_crop, dim3((cw * ch + kBlock - 1) / kBlock), dim3(kBlock), 0, g->stream, g->d_raw, g->in_w,
                      g->in_h, (size_t)g->in_w, g->d_map1, g->d_map2, g->out_w, x0, y0, d_dst, cw, ch, dst_pitch);
   ING_CHK(hipGetLastError());
