@@ -177,7 +177,7 @@ def latency_figure(capi, params, frames, depth, resident_pose, reps=200):
                                             "accumulate_f64", "device", "arith")}
     for name in ("bench_schedule", "reference_schedule"):
         over = dict(keep) if name == "bench_schedule" else dict(has_depth=keep["has_depth"], accumulate_f64=keep["accumulate_f64"], device=keep["device"], arith=keep["arith"])
-        if name == "reference_schedule" and (w % 16 or h % 16):
+        if name == "reference_schedule" and min(w, h) < 16:    # five levels: the coarsest grid is size >> 4
             continue
         ctx = capi.Context(capi.default_params(w, h, params.fx, params.fy, params.cx, params.cy, max_frames=2, max_pairs=1, **over))
         ctx.upload_frames(0, frames[0:2], depth[0:2] if depth is not None else None)

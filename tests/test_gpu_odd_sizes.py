@@ -192,6 +192,30 @@ def test_roi_sized_alignments_every_launch_form(capi, O, synth, size, sched):
     ctx.close()
 
 
+@pytest.mark.one_arith
+@pytest.mark.parametrize("size", [(1279, 959, 5), (1281, 963, 6)], ids=lambda s: "%dx%dx%d" % s)
+def test_large_odd_sizes_alignments(capi, O, synth, size):
+    """Config 3's scale (1280 x 960) one pixel to either side: level 0 of 1.2 M pixels in the sliced launches, rows of 1279 / 1281
+    bytes (pitch 1280 / 1284), with depth; one pair and a batch of five."""
+    w, h, nl = size
+    intr = _intr(w, h)
+    over = dict(n_levels=nl, first_level=nl - 1, last_level=0, max_iters=2, early_exit=0, has_depth=1)
+    pairs = _pairs(synth, w, h, intr, 2, 6900 + w, True)
+    po = O.default_params(w, h, *intr, **over)
+    want = [O.align_pair(po, *pr, want_trace=True) for pr in pairs]
+    n = 5
+    ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=2 * n, max_pairs=n, **over))
+    _load(ctx, pairs, n)
+    for count in (1, n):
+        ref = np.arange(count) * 2
+        poses, stats = ctx.estimate_pose_batch(ref, ref + 1)
+        for i in range(count):
+            st, pose_cpu, tr = want[i % 2]
+            assert stats[i]["status"] == st and stats[i]["iterations"] == len(tr) and stats[i]["n_valid"] == tr[-1]["n_valid"]
+            assert np.array_equal(poses[i].view(np.uint32), pose_cpu.view(np.uint32)), (count, i, poses[i], pose_cpu)
+    ctx.close()
+
+
 @pytest.mark.parametrize("size", SMALL_SIZES, ids=lambda s: "%dx%dx%d" % s)
 @pytest.mark.parametrize("depth", [False, True], ids=["nodepth", "depth"])
 def test_small_odd_sizes_alignments(capi, O, synth, size, depth):

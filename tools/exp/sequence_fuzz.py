@@ -22,7 +22,9 @@ t0 = time.time()
 pool = ThreadPoolExecutor(min(32, os.cpu_count() or 4))
 CASES = [(160, 96, dict(n_levels=4, first_level=3, last_level=0, max_iters=6, early_exit=0)), (320, 240, dict()),
          (208, 112, dict(n_levels=5, first_level=4, last_level=1, max_iters=5, early_exit=1, weights=2)),
-         (640, 480, dict(n_levels=4, first_level=3, last_level=0, max_iters=4, early_exit=0, weights=1)), (736, 480, dict())]
+         (640, 480, dict(n_levels=4, first_level=3, last_level=0, max_iters=4, early_exit=0, weights=1)), (736, 480, dict()),
+         # sizes no power of two divides (round 6): the uploads go through the staging area and the row-spreading kernel
+         (365, 233, dict()), (183, 119, dict(n_levels=4, first_level=3, last_level=0, max_iters=5, early_exit=0, weights=2))]
 for ci, (w, h, over) in enumerate(CASES):
     f = float(np.float32(0.8 * w))
     intr = (f, f if ci % 2 == 0 else float(np.float32(f * 0.997)), float(np.float32(w / 2 - 0.5)), float(np.float32(h / 2 - 0.5)))

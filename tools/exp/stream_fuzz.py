@@ -17,7 +17,8 @@ seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
 total = bad = 0
 t0 = time.time()
-for (w, h, nl, early, B) in [(160, 96, 4, 0, 48), (320, 240, 4, 1, 24), (208, 112, 5, 0, 32), (640, 480, 4, 0, 12)]:
+for (w, h, nl, early, B) in [(160, 96, 4, 0, 48), (320, 240, 4, 1, 24), (208, 112, 5, 0, 32), (640, 480, 4, 0, 12),
+                          (183, 119, 4, 0, 32), (365, 233, 5, 1, 16)]:   # pitched rows: uploads through the staging area (round 6)
     f = float(np.float32(0.8 * w))
     intr = (f, f, float(np.float32(w / 2 - 0.5)), float(np.float32(h / 2 - 0.5)))
     over = dict(n_levels=nl, first_level=nl - 1, last_level=0 if not early else 1, max_iters=6, early_exit=early, has_depth=1)
