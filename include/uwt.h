@@ -179,7 +179,10 @@ const char* uwt_source_id(void);
 /* ---- frames (the Frame data the tracker borrows: images_, depths_, gradientX_, gradientY_; include/System.h:85-89) */
 
 /* Frame::images_[0] / depths_[0] of one frame from host memory with row strides in BYTES (cv::Mat::step).
- * Replaces the imread result handed to the pyramid loop in System::AddFrame (src/System.cpp:228, 243). */
+ * Replaces the imread result handed to the pyramid loop in System::AddFrame (src/System.cpp:228, 243).  A strided image (a view
+ * into a wider one: images_[0] = distortion(ROI), src/System.cpp:235) crosses as ONE copy of the span its rows cover — first byte
+ * of the first row to last byte of the last, the bytes between the rows included: they must be readable, as they are inside a
+ * parent image — while the stride is at most four times the row; beyond that as a 2-D copy (slow: issued row by row). */
 int uwt_set_frame(uwt_ctx* ctx, int32_t slot, const uint8_t* gray, size_t row_stride,
                   const uint16_t* depth_or_null, size_t depth_row_stride);
 /* n tightly packed frames (w*h elements each) into slots first_slot .. first_slot+n-1 */

@@ -107,6 +107,15 @@ def test_level_geometry_pyramids_and_gradients(capi, O, size, form):
     # ... and so does a tightly packed one (one linear copy and a kernel that spreads the rows, like the batch uploads)
     ctx.set_frame(1, frames[2], depth[2])
     assert np.array_equal(ctx.get_plane(1, 0, capi.PLANE_IMAGE), frames[2]) and np.array_equal(ctx.get_plane(1, 0, capi.PLANE_DEPTH), depth[2])
+    # a view into the corner of a parent image (the reference's images_[0] = distortion(ROI), src/System.cpp:235): the rows' span —
+    # the bytes between the rows included — crosses in one copy and ends with the parent's last byte
+    parent, parent_d = rng.integers(0, 256, (h + 7, w + 19)).astype(np.uint8), rng.integers(0, 65536, (h + 7, w + 19)).astype(np.uint16)
+    ctx.set_frame(2, parent[7:, 19:], parent_d[7:, 19:])
+    assert np.array_equal(ctx.get_plane(2, 0, capi.PLANE_IMAGE), parent[7:, 19:]) and np.array_equal(ctx.get_plane(2, 0, capi.PLANE_DEPTH), parent_d[7:, 19:])
+    # a column out of a parent more than four times as wide: the 2-D copy
+    wide5, wide5_d = rng.integers(0, 256, (h, 5 * w)).astype(np.uint8), rng.integers(0, 65536, (h, 5 * w)).astype(np.uint16)
+    ctx.set_frame(2, wide5[:, w:2 * w], wide5_d[:, w:2 * w])
+    assert np.array_equal(ctx.get_plane(2, 0, capi.PLANE_IMAGE), wide5[:, w:2 * w]) and np.array_equal(ctx.get_plane(2, 0, capi.PLANE_DEPTH), wide5_d[:, w:2 * w])
     # the asynchronous upload from page-locked memory: a first call (the staging area is created), a larger one (it grows)
     pg, pd = capi.pinned_empty((n, h, w), np.uint8), capi.pinned_empty((n, h, w), np.uint16)
     pg[:], pd[:] = frames[::-1], depth[::-1]

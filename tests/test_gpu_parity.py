@@ -133,6 +133,10 @@ def test_batched_pyramids_and_gradients_in_slots(capi, O, synth):
     ctx.set_frame(1, big[:, :w], bigd[:, :w])
     assert np.array_equal(ctx.get_plane(1, 0, capi.PLANE_IMAGE), frames[3])
     assert np.array_equal(ctx.get_plane(1, 0, capi.PLANE_DEPTH), depth[3])
+    # ... and so does a view into the corner of a parent (the span of its rows ends with the parent's last byte)
+    ctx.set_frame(2, np.pad(frames[4], ((9, 0), (40, 0)))[9:, 40:], np.pad(depth[4], ((9, 0), (40, 0)))[9:, 40:])
+    assert np.array_equal(ctx.get_plane(2, 0, capi.PLANE_IMAGE), frames[4])
+    assert np.array_equal(ctx.get_plane(2, 0, capi.PLANE_DEPTH), depth[4])
 
 
 @pytest.mark.parametrize("shape", [(160, 96, 5), (640, 480, 5), (640, 480, 4), (72, 56, 3), (200, 120, 4), (1280, 960, 5), (192, 128, 7),

@@ -21,12 +21,20 @@ CASES = [("640x480 depth, 4 x 10", 640, 480, (525.0, 525.0, 319.5, 239.5), True,
          ("736x480 z=1, reference", 736, 480, E, False, {}),
          ("725x465 z=1, reference", 725, 465, E, False, {}),
          ("733x471 z=1, reference", 733, 471, E, False, {}),
-         ("735x479 z=1, reference", 735, 479, E, False, {})]
+         ("735x479 z=1, reference", 735, 479, E, False, {}),
+         # the frame as the reference holds it: a pageable cv::Mat VIEW into the rectified 752 x 480 image (images_[0] = distortion(ROI),
+         # src/System.cpp:235), handed to uwt_set_frame with the parent's step
+         ("725x465 z=1, reference, set_frame(view)", 725, 465, E, False, {}),
+         ("640x480 depth, reference, set_frame(view)", 640, 480, (525.0, 525.0, 319.5, 239.5), True, {})]
 N_DISTINCT = 12
 for name, w, h, intr, with_depth, over in CASES:
     out = synth.render_sequence(w, h, *intr, N_DISTINCT, 5, with_depth=with_depth, margin=(96, 64))
     frames, depths = out[0], out[1]
     ring = 3
+    view = "view" in name
+    if view:
+        parents = [np.pad(f, ((8, 7), (13, 14))) for f in frames]
+        parents_d = [np.pad(d, ((8, 7), (13, 14))) for d in depths] if with_depth else None
     ctx = capi.Context(capi.default_params(w, h, *intr, max_frames=ring, max_pairs=1, has_depth=int(with_depth), **over))
     pf = capi.pinned_empty((1, h, w), np.uint8)
     pd = capi.pinned_empty((1, h, w), np.uint16) if with_depth else None
@@ -39,10 +47,13 @@ for name, w, h, intr, with_depth, over in CASES:
     for k, fi in enumerate(order):
         slot = (prev + 1) % ring
         t0 = time.perf_counter()
-        pf[0] = frames[fi]                      # (the host's own copy into page-locked memory is part of a frame's cost)
-        if with_depth:
-            pd[0] = depths[fi]
-        ctx.upload_frames_async(slot, pf, pd)
+        if view:
+            ctx.set_frame(slot, parents[fi][8:8 + h, 13:13 + w], parents_d[fi][8:8 + h, 13:13 + w] if with_depth else None)
+        else:
+            pf[0] = frames[fi]                      # (the host's own copy into page-locked memory is part of a frame's cost)
+            if with_depth:
+                pd[0] = depths[fi]
+            ctx.upload_frames_async(slot, pf, pd)
         tk = ctx.track_batch_host_async(slot, 1, [prev], [slot], hp, hs, grad_refs_only=True)
         ctx.wait_ticket(tk)
         dt = time.perf_counter() - t0
@@ -51,6 +62,6 @@ for name, w, h, intr, with_depth, over in CASES:
             evals.append(int(hs[0, 1]))
         prev = slot
     ts = np.array(ts) * 1e3
-    print("%-26s %.3f ms per frame (median %.3f, p95 %.3f), %.1f evaluations on average, %d frames" %
+    print("%-42s %.3f ms per frame (median %.3f, p95 %.3f), %.1f evaluations on average, %d frames" %
           (name, ts.mean(), np.median(ts), np.percentile(ts, 95), np.mean(evals), len(ts)), flush=True)
     ctx.close()

@@ -236,19 +236,29 @@ int launch_resize(uwt_ctx* c, const T* src, T* dst, int sw, int sh, int src_pitc
   return UWT_OK;
 }
 
-// rows of w elements, tightly packed, into rows of `pitch` elements (the pad columns are never read): four elements per thread
+// rows of w elements, src_pitch elements apart, into rows dst_pitch elements apart (pad columns are never read): four elements per thread
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_spread_rows(const T* __restrict__ src, T* __restrict__ dst, int w, int pitch, size_t rows) {
+__global__ __launch_bounds__(kBlock) void k_spread_rows(const T* __restrict__ src, T* __restrict__ dst, int w, size_t src_pitch, size_t dst_pitch,
+                                                        size_t rows) {
   const int per_row = (w + 3) >> 2;
   const size_t total = rows * (size_t)per_row;
   for (size_t i = blockIdx.x * (size_t)kBlock + threadIdx.x; i < total; i += (size_t)gridDim.x * kBlock) {
     const size_t r = i / (size_t)per_row;
     const int x = (int)(i - r * (size_t)per_row) * 4;
-    const T* s = src + r * (size_t)w + x;
-    T* d = dst + r * (size_t)pitch + x;
+    const T* s = src + r * src_pitch + x;
+    T* d = dst + r * dst_pitch + x;
+    if (x + 3 < w) {   // a whole group: the device rows start on multiples of four elements (dst_pitch % 4 == 0), so one store
+      const T v0 = s[0], v1 = s[1], v2 = s[2], v3 = s[3];
+      if constexpr (sizeof(T) == 1) {
+        *reinterpret_cast<uint32_t*>(d) = (uint32_t)v0 | ((uint32_t)v1 << 8) | ((uint32_t)v2 << 16) | ((uint32_t)v3 << 24);
+      } else {
+        *reinterpret_cast<uint2*>(d) = make_uint2((uint32_t)v0 | ((uint32_t)v1 << 16), (uint32_t)v2 | ((uint32_t)v3 << 16));
+      }
+    } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (x + j < w) d[j] = s[j];
+      for (int j = 0; j < 3; ++j)
+        if (x + j < w) d[j] = s[j];
+    }
   }
 }
 
@@ -267,28 +277,48 @@ static int ensure_stage(uwt_ctx* c, int which, size_t bytes, hipStream_t s) {
   return UWT_OK;
 }
 
-// n tightly packed level-0 frames (width x height) into slots first_slot.. of a level-0 plane.  Where the rows are tight (width a
-// multiple of 4) that is one linear copy.  Otherwise the frames land, by one linear copy, in a staging area on the device and a
-// kernel spreads their rows to the pitched rows of the plane (a slot is pitch * height): a 2-D copy of n * height short rows
-// costs about 5 us PER ROW on this runtime (measured: 138 alignments/s streamed at 725 x 465 against 50 k through this path).
+// `rows` host rows of w elements, src_stride BYTES apart, into device rows dst_pitch elements apart: ONE linear copy of the host span
+// (first byte of the first row to last byte of the last; what lies between the rows of a strided view belongs to its parent image)
+// into the stream's staging area, then k_spread_rows.  A 2-D copy costs about 5 us PER ROW on this runtime (measured: 138
+// alignments/s streamed at 725 x 465 against 50 k through this path).  reserve: bytes the staging area should hold at least.
+static int rows_in(uwt_ctx* c, void* dst, size_t dst_pitch, const void* host, size_t elem, size_t w, size_t src_stride, size_t rows,
+                   hipStream_t s, int which, size_t reserve) {
+  const size_t span = (rows - 1) * src_stride + w * elem;
+  int st = ensure_stage(c, which, std::max(span, reserve), s);
+  if (st) return st;
+  HIPCHK(c, hipMemcpyAsync(c->stage[which], host, span, hipMemcpyHostToDevice, s));
+  const size_t work = rows * ((w + 3) / 4);
+  const unsigned blocks = (unsigned)std::min<size_t>((work + kBlock - 1) / kBlock, 1u << 16);
+  if (elem == 1)
+    hipLaunchKernelGGL(k_spread_rows<uint8_t>, dim3(blocks), dim3(kBlock), 0, s, (const uint8_t*)c->stage[which], (uint8_t*)dst, (int)w, src_stride,
+                       dst_pitch, rows);
+  else
+    hipLaunchKernelGGL(k_spread_rows<uint16_t>, dim3(blocks), dim3(kBlock), 0, s, (const uint16_t*)c->stage[which], (uint16_t*)dst, (int)w,
+                       src_stride / 2, dst_pitch, rows);
+  HIPCHK(c, hipGetLastError());
+  return UWT_OK;
+}
+
+// n tightly packed level-0 frames (width x height) into slots first_slot.. of a level-0 plane: one linear copy where the device
+// rows are tight too (width a multiple of 4), through the staging area otherwise (a slot is pitch * height)
 static int copy_frames_in(uwt_ctx* c, void* plane0, const void* host, size_t elem, int first_slot, int n, hipStream_t s, int which) {
   const size_t w = c->p.width, h = c->p.height, pitch = c->lv[0].pitch;
   unsigned char* dst = (unsigned char*)plane0 + (size_t)first_slot * c->lv[0].n * elem;
-  const size_t bytes = w * h * elem * n;
   if (pitch == w) {
-    HIPCHK(c, hipMemcpyAsync(dst, host, bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(dst, host, w * h * elem * n, hipMemcpyHostToDevice, s));
     return UWT_OK;
   }
-  int st = ensure_stage(c, which, w * h * n * (c->p.has_depth ? 2 : 1), s);   // the depth frames of the same call follow
-  if (st) return st;
-  HIPCHK(c, hipMemcpyAsync(c->stage[which], host, bytes, hipMemcpyHostToDevice, s));
-  const size_t rows = h * (size_t)n, work = rows * ((w + 3) / 4);
-  const unsigned blocks = (unsigned)std::min<size_t>((work + kBlock - 1) / kBlock, 1u << 16);
-  if (elem == 1)
-    hipLaunchKernelGGL(k_spread_rows<uint8_t>, dim3(blocks), dim3(kBlock), 0, s, (const uint8_t*)c->stage[which], (uint8_t*)dst, (int)w, (int)pitch, rows);
-  else
-    hipLaunchKernelGGL(k_spread_rows<uint16_t>, dim3(blocks), dim3(kBlock), 0, s, (const uint16_t*)c->stage[which], (uint16_t*)dst, (int)w, (int)pitch, rows);
-  HIPCHK(c, hipGetLastError());
+  return rows_in(c, dst, pitch, host, elem, w, w * elem, h * (size_t)n, s, which, w * h * n * (c->p.has_depth ? 2 : 1));   // (the depth frames of the call follow)
+}
+
+// one level-0 frame whose host rows are row_stride BYTES apart (a cv::Mat view: Frame::images_[0] = distortion(ROI), src/System.cpp:235)
+static int copy_strided_frame_in(uwt_ctx* c, void* plane0, const void* host, size_t elem, size_t row_stride, int slot, hipStream_t s) {
+  const size_t w = c->p.width, h = c->p.height, pitch = c->lv[0].pitch;
+  unsigned char* dst = (unsigned char*)plane0 + (size_t)slot * c->lv[0].n * elem;
+  if (row_stride == w * elem) return copy_frames_in(c, plane0, host, elem, slot, 1, s, 0);
+  if (row_stride % elem == 0 && row_stride <= 4 * w * elem)   // the span crosses whole: at most four times the frame's bytes
+    return rows_in(c, dst, pitch, host, elem, w, row_stride, h, s, 0, 0);
+  HIPCHK(c, hipMemcpy2DAsync(dst, pitch * elem, host, row_stride, w * elem, h, hipMemcpyHostToDevice, s));   // a column out of a very wide parent
   return UWT_OK;
 }
 
@@ -1355,27 +1385,15 @@ int uwt_set_frame(uwt_ctx* c, int32_t slot, const uint8_t* gray, size_t row_stri
                   size_t depth_row_stride) {
   if (c) (void)hipSetDevice(c->p.device);  // one context = one device; callers may have switched the thread's device
   if (!c || !gray || !slot_range_ok(c, slot, 1)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: bad slot/pointer");
-  const int w = c->p.width, h = c->p.height;
+  const int w = c->p.width;
   if (row_stride < (size_t)w) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: row stride < width");
   int st0 = compute_begin(c, slot, 1);
   if (st0) return st0;
-  const size_t pitch = c->lv[0].pitch, n0 = c->lv[0].n;
   if (c->p.has_depth && (!depth || depth_row_stride < (size_t)w * 2)) return fail(c, UWT_ERR_INVALID_ARG, "uwt_set_frame: depth required");
-  // tightly packed host rows take the batch upload's path (one linear copy; a kernel spreads the rows where they are pitched);
-  // a strided host image (a cv::Mat view) is a 2-D copy
-  if (row_stride == (size_t)w) {
-    if ((st0 = copy_frames_in(c, c->img[0], gray, 1, slot, 1, c->stream, 0))) return st0;
-  } else {
-    HIPCHK(c, hipMemcpy2DAsync(c->img[0] + (size_t)slot * n0, pitch, gray, row_stride, w, h, hipMemcpyHostToDevice, c->stream));
-  }
-  if (c->p.has_depth) {
-    if (depth_row_stride == (size_t)w * 2) {
-      if ((st0 = copy_frames_in(c, c->depth[0], depth, 2, slot, 1, c->stream, 0))) return st0;
-    } else {
-      HIPCHK(c, hipMemcpy2DAsync(c->depth[0] + (size_t)slot * n0, pitch * 2, depth, depth_row_stride, (size_t)w * 2, h,
-                                 hipMemcpyHostToDevice, c->stream));
-    }
-  }
+  // tight or strided host rows alike: one linear copy of the span the rows cover, and a kernel that spreads them where either side
+  // is pitched (a 2-D copy is issued row by row: 2.3 ms for a 725 x 465 view)
+  if ((st0 = copy_strided_frame_in(c, c->img[0], gray, 1, row_stride, slot, c->stream))) return st0;
+  if (c->p.has_depth && (st0 = copy_strided_frame_in(c, c->depth[0], depth, 2, depth_row_stride, slot, c->stream))) return st0;
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return UWT_OK;
 }
