@@ -202,6 +202,27 @@ def test_roi_sized_alignments_every_launch_form(capi, O, synth, size, sched):
 
 
 @pytest.mark.one_arith
+def test_first_upload_after_create_survives_the_create_time_clears(capi):
+    """uwt_create clears the planes of pitched levels with hipMemset — asynchronous, on the NULL stream, which the context's
+    non-blocking streams do not wait for.  Until uwt_create waited for it, the zeros could land on top of the first upload's rows
+    (12-17 of 30 contexts of this shape lost their first depth frame; profiles/r06/EXPERIMENTS.md 14).  Large planes make the clears
+    take milliseconds; one frame goes into the first or the last slot at once and is read back."""
+    w, h = 725, 465
+    rng = np.random.default_rng(3)
+    for case in range(8):
+        slots = int(rng.integers(400, 1000))
+        g = rng.integers(1, 256, (1, h, w), dtype=np.uint8)
+        d = rng.integers(1, 40000, (1, h, w)).astype(np.uint16)
+        ctx = capi.Context(capi.default_params(w, h, 0.8 * w, 0.8 * w, w / 2, h / 2, max_frames=slots, max_pairs=1, n_levels=1, first_level=0,
+                                               last_level=0, has_depth=1, weights=case % 3))
+        s = slots - 1 if case % 2 else 0
+        ctx.upload_frames(s, g, d)
+        assert np.array_equal(ctx.get_plane(s, 0, capi.PLANE_IMAGE), g[0]), (case, slots)
+        assert np.array_equal(ctx.get_plane(s, 0, capi.PLANE_DEPTH), d[0]), (case, slots)
+        ctx.close()
+
+
+@pytest.mark.one_arith
 @pytest.mark.parametrize("size", [(1279, 959, 5), (1281, 963, 6)], ids=lambda s: "%dx%dx%d" % s)
 def test_large_odd_sizes_alignments(capi, O, synth, size):
     """Config 3's scale (1280 x 960) one pixel to either side: level 0 of 1.2 M pixels in the sliced launches, rows of 1279 / 1281

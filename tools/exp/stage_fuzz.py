@@ -111,8 +111,15 @@ for case in range(cases):
                     ok = np.array_equal(out["A"].astype(np.float32).view(np.uint32), A_ref.view(np.uint32)) and \
                         np.array_equal((-out["jtr"]).astype(np.float32).view(np.uint32), b_ref.view(np.uint32))
                 if not ok:
+                    # where it parts: the inputs (planes of this level read back) or the evaluation (a second call)
+                    planes = dict(ref=int((ctx.get_plane(0, lvl, capi.PLANE_IMAGE) != a_img).sum()), tgt=int((ctx.get_plane(1, lvl, capi.PLANE_IMAGE) != b_img).sum()),
+                                  gx=int((ctx.get_plane(0, lvl, capi.PLANE_GRADX) != gx).sum()), gy=int((ctx.get_plane(0, lvl, capi.PLANE_GRADY) != gy).sum()))
+                    if depth:
+                        planes["depth"] = int((ctx.get_plane(0, lvl, capi.PLANE_DEPTH) != dp).sum())
+                    again = ctx.residual_jacobian_weighted(0, 1, lvl, pose)
                     differs("residual_jacobian_weighted", case=case, lvl=lvl, xi=xi.tolist(), over=over, size=(w, h), n_valid=(out["n_valid"], len(idx)),
-                            masks=int((out["valid"] != valid).sum()))
+                            masks=int((out["valid"] != valid).sum()), planes_differ=planes, second_call_n_valid=again["n_valid"],
+                            second_call_masks=int((again["valid"] != valid).sum()))
     ctx.close()
 print("stage fuzz seed %d: %d evaluations at extreme poses over %d contexts, %d differ from the oracle, %.0f s" % (seed, total, cases, bad, time.time() - t0))
 sys.exit(1 if bad else 0)

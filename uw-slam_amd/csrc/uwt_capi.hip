@@ -1261,6 +1261,10 @@ int uwt_create(const uwt_params* p, uwt_ctx** out) {
   CREATE_CHK(hipHostMalloc((void**)&c->h_active, 2 * sizeof(int)));
   CREATE_CHK(hipHostMalloc((void**)&c->h_pairs, sizeof(int) * 2 * p->max_pairs * uwt_ctx::kPairStages));
   std::memset(c->h_pairs, 0xff, sizeof(int) * 2 * p->max_pairs * uwt_ctx::kPairStages);
+  // hipMemset returns before the device has run it, and it runs on the NULL stream, which the context's streams (non-blocking) do not
+  // wait for: without this the zeros of the pitched planes could land on top of the first upload's rows (seen as rare parity events
+  // once uploads into pitched rows became a kernel: profiles/r06/EXPERIMENTS.md 14)
+  CREATE_CHK(hipStreamSynchronize(nullptr));
 #undef CREATE_CHK
   *out = c;
   return UWT_OK;
@@ -1369,6 +1373,7 @@ int uwt_update_params(uwt_ctx* c, const uwt_params* p) {
     HIPCHK(c, hipMalloc((void**)&c->hist, sizeof(unsigned int) * kHistBins * o.max_pairs));
     HIPCHK(c, hipMalloc((void**)&c->scale, sizeof(PairScale) * o.max_pairs));
     HIPCHK(c, hipMemset(c->scale, 0, sizeof(PairScale) * o.max_pairs));
+    HIPCHK(c, hipStreamSynchronize(nullptr));   // (the NULL stream's memset against the context's non-blocking streams: see uwt_create)
   }
   c->p = *p;
   c->spec_budget = c->spec_calm = 0;   // a new schedule: the speculative budget starts over
